@@ -1,0 +1,97 @@
+// C-ABI entry points for the convolution family (see include/hific_hip.h for the contract).
+#include "gconv.h"
+#include <string.h>
+
+extern "C" {
+
+int hific_version(void) { return 100; }
+
+// Returns 0 and fills (name[<=63], CU count, LDS bytes/CU) for the given device; never throws.
+int hific_device_info(int device, char* name, int* cus, int* lds_per_cu) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return HIFIC_ERR_ARG;
+    if (name) { strncpy(name, pr.gcnArchName, 63); name[63] = 0; }
+    if (cus) *cus = pr.multiProcessorCount;
+    if (lds_per_cu) *lds_per_cu = (int)pr.maxSharedMemoryPerMultiProcessor;
+    return HIFIC_OK;
+}
+
+size_t hific_conv2d_ws_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb,
+                             int pr, int dtype) {
+    ConvGeom g{N, C, H, W, K, R, S, stride, pt, pl, pb, pr, PAD_ZERO};
+    return gc_ws_bytes_conv(g, dtype);
+}
+size_t hific_conv_transpose2d_ws_bytes(int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad,
+                                       int outpad, int dtype) {
+    ConvTGeom g{N, Ci, H, W, Co, R, S, stride, pad, outpad};
+    return gc_ws_bytes_convT(g, dtype);
+}
+
+static bool geom_ok(const ConvGeom& g) {
+    return g.N > 0 && g.C > 0 && g.K > 0 && g.H > 0 && g.W > 0 && g.R > 0 && g.S > 0 && g.stride > 0 &&
+           g.pt >= 0 && g.pl >= 0 && g.pb >= 0 && g.pr >= 0 && g.OH() > 0 && g.OW() > 0 &&
+           (g.pad_mode == PAD_ZERO || (g.pad_mode == PAD_REFLECT && g.pt < g.H && g.pb < g.H && g.pl < g.W && g.pr < g.W));
+}
+static bool geomT_ok(const ConvTGeom& g) {
+    return g.N > 0 && g.Ci > 0 && g.Co > 0 && g.H > 0 && g.W > 0 && g.R > 0 && g.S > 0 && g.stride > 0 &&
+           g.pad >= 0 && g.outpad >= 0 && g.OH() > 0 && g.OW() > 0;
+}
+
+// y = act(conv2d(pad(x), w*w_scale) + bias [+ resid]);  x [N,C,H,W], w f32 [K,C,R,S], y [N,K,OH,OW]
+// flags: bit0 = x is f32 although dtype is bf16, bit1 = y (and resid) are f32 although dtype is bf16
+int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const float* bias, const void* resid, void* y,
+                     int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb, int pr,
+                     int pad_mode, int act, int dtype, int flags, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ConvGeom g{N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode};
+    if (!geom_ok(g) || !x || !w || !y) return HIFIC_ERR_ARG;
+    WsAlloc a{(char*)ws, ws_bytes, 0};
+    return gc_conv_fwd(g, x, w, w_scale, bias, y, resid, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
+}
+
+// dx = adjoint of the (padded, strided) convolution applied to dy.  flags: bit0 dy is f32, bit1 dx is f32
+int hific_conv2d_bwd_data(const void* dy, const float* w, const float* w_scale, void* dx, int N, int C, int H, int W,
+                          int K, int R, int S, int stride, int pt, int pl, int pb, int pr, int pad_mode, int dtype,
+                          int flags, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ConvGeom g{N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode};
+    if (!geom_ok(g) || !dy || !w || !dx) return HIFIC_ERR_ARG;
+    WsAlloc a{(char*)ws, ws_bytes, 0};
+    return gc_conv_bwd_data(g, dy, w, w_scale, dx, dtype, flags & 1, (flags >> 1) & 1, a, stream);
+}
+
+// dw f32 [K,C,R,S] (=|+=) sum_n,oy,ox dy * pad(x).  flags: bit0 x is f32, bit1 dy is f32
+int hific_conv2d_bwd_weight(const void* x, const void* dy, float* dw, int N, int C, int H, int W, int K, int R, int S,
+                            int stride, int pt, int pl, int pb, int pr, int pad_mode, int accumulate, int dtype,
+                            int flags, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ConvGeom g{N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode};
+    if (!geom_ok(g) || !x || !dy || !dw) return HIFIC_ERR_ARG;
+    WsAlloc a{(char*)ws, ws_bytes, 0};
+    return gc_conv_bwd_weight(g, x, dy, dw, accumulate, dtype, flags & 1, (flags >> 1) & 1, a, stream);
+}
+
+// nn.ConvTranspose2d: x [N,Ci,H,W], w f32 [Ci,Co,R,S], y [N,Co,OH,OW]
+int hific_conv_transpose2d_fwd(const void* x, const float* w, const float* bias, void* y, int N, int Ci, int H, int W,
+                               int Co, int R, int S, int stride, int pad, int outpad, int act, int dtype, int flags,
+                               void* ws, size_t ws_bytes, hipStream_t stream) {
+    ConvTGeom g{N, Ci, H, W, Co, R, S, stride, pad, outpad};
+    if (!geomT_ok(g) || !x || !w || !y) return HIFIC_ERR_ARG;
+    WsAlloc a{(char*)ws, ws_bytes, 0};
+    return gc_convT_fwd(g, x, w, bias, y, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
+}
+int hific_conv_transpose2d_bwd_data(const void* dy, const float* w, void* dx, int N, int Ci, int H, int W, int Co,
+                                    int R, int S, int stride, int pad, int outpad, int dtype, int flags, void* ws,
+                                    size_t ws_bytes, hipStream_t stream) {
+    ConvTGeom g{N, Ci, H, W, Co, R, S, stride, pad, outpad};
+    if (!geomT_ok(g) || !dy || !w || !dx) return HIFIC_ERR_ARG;
+    WsAlloc a{(char*)ws, ws_bytes, 0};
+    return gc_convT_bwd_data(g, dy, w, dx, dtype, flags & 1, (flags >> 1) & 1, a, stream);
+}
+int hific_conv_transpose2d_bwd_weight(const void* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co,
+                                      int R, int S, int stride, int pad, int outpad, int accumulate, int dtype,
+                                      int flags, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ConvTGeom g{N, Ci, H, W, Co, R, S, stride, pad, outpad};
+    if (!geomT_ok(g) || !x || !dy || !dw) return HIFIC_ERR_ARG;
+    WsAlloc a{(char*)ws, ws_bytes, 0};
+    return gc_convT_bwd_weight(g, x, dy, dw, accumulate, dtype, flags & 1, (flags >> 1) & 1, a, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Shared device/host helpers for libhific_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define HIFIC_OK 0
+#define HIFIC_ERR_ARG (-1)
+#define HIFIC_ERR_WS (-2)
+#define HIFIC_ERR_LAUNCH (-3)
+#define HIFIC_ERR_UNSUPPORTED (-4)
+
+enum { HIFIC_F32 = 0, HIFIC_BF16 = 1 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ float bf2f(bf16_t h) {
+    return __uint_as_float(((unsigned)h) << 16);
+}
+// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int code = HIFIC_F32;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int code = HIFIC_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// single-reflection index (ReflectionPad2d semantics, no edge repeat); requires pad < n
+__host__ __device__ __forceinline__ int reflect_idx(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int hific_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HIFIC_OK : HIFIC_ERR_LAUNCH;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b; }

@@ -1,0 +1,477 @@
+// Small HBM-bound kernels of the HiFIC step: activations' backward, residual adds, per-channel sums (bias
+// gradients), casts, max-pool (AlexNet), MSE distortion, BCE-with-logits GAN losses, nearest-upsample+concat
+// (Discriminator input), spectral norm, fused Adam.  All grid-stride, vectorisable, one pass over HBM each.
+// Reference call sites: src/network/generator.py:44,161 (adds), src/network/hyper.py:59-60,91-92 (ReLU),
+// src/network/discriminator.py:36,44,74-84, src/model.py:190-194 (MSE), src/loss/losses.py:30-41 (BCE),
+// torch.nn.utils.spectral_norm (discriminator.py:46-62), train.py:287-301 (Adam).
+#include "common.h"
+#include <math.h>
+
+#define EW_GRID(total) dim3((unsigned)((((total) + 255) / 256) > 16384 ? 16384 : (((total) + 255) / 256)))
+#define EW_LOOP(i, total) \
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (long long)gridDim.x * blockDim.x)
+
+// block-wide sum of one float per thread (256 threads); result valid on thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long long n,
+                               float slope) {
+    EW_LOOP(i, n) {
+        const float g = DT<T>::ld(dy + i);
+        DT<T>::st(dx + i, DT<T>::ld(y + i) > 0.f ? g : slope * g);
+    }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long n) {
+    EW_LOOP(i, n) DT<T>::st(o + i, DT<T>::ld(a + i) + DT<T>::ld(b + i));
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ a, TO* __restrict__ o, long long n) {
+    EW_LOOP(i, n) DT<TO>::st(o + i, DT<TI>::ld(a + i));
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
+                             float alpha, float beta, long long n) {
+    EW_LOOP(i, n) o[i] = alpha * a[i] + beta * b[i];
+}
+
+// part[split][c] = sum over a slice of (n, hw) of x[n][c][hw]
+template <typename T>
+__global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, float* __restrict__ part, int N, int C,
+                                                       int HW, int nsplit) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x, split = blockIdx.y;
+    const long long total = (long long)N * HW;
+    const long long per = (total + nsplit - 1) / nsplit;
+    const long long lo = split * per;
+    long long hi = lo + per; if (hi > total) hi = total;
+    float s = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const int n = (int)(i / HW);
+        const int hw = (int)(i - (long long)n * HW);
+        s += DT<T>::ld(x + ((size_t)n * C + c) * HW + hw);
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[(size_t)split * C + c] = s;
+}
+__global__ void chan_sum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nsplit,
+                                       int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * C + c];
+    if (accumulate) out[c] += s; else out[c] = s;
+}
+
+// ---- MaxPool2d(kernel 3, stride 2, no padding) -----------------------------------------------------
+template <typename T>
+__global__ void maxpool3s2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long planes, int H, int W,
+                                      int OH, int OW) {
+    const long long total = planes * OH * OW;
+    EW_LOOP(i, total) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const long long pc = i / ((long long)OW * OH);
+        const T* xp = x + pc * H * W;
+        float m = -INFINITY;
+        for (int r = 0; r < 3; ++r)
+            for (int s = 0; s < 3; ++s) m = fmaxf(m, DT<T>::ld(xp + (size_t)(oy * 2 + r) * W + ox * 2 + s));
+        DT<T>::st(y + i, m);
+    }
+}
+// gather form of the adjoint: dx[iy,ix] = sum over windows containing (iy,ix) whose arg-max (first max in
+// row-major window order, torch semantics) is (iy,ix)
+template <typename T>
+__global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                      long long planes, int H, int W, int OH, int OW) {
+    const long long total = planes * H * W;
+    EW_LOOP(i, total) {
+        const int ix = (int)(i % W), iy = (int)((i / W) % H);
+        const long long pc = i / ((long long)W * H);
+        const T* xp = x + pc * H * W;
+        const T* gp = dy + pc * OH * OW;
+        float acc = 0.f;
+        int oy_lo = (iy - 2 + 1) / 2; if (iy - 2 < 0) oy_lo = 0;
+        int ox_lo = (ix - 2 + 1) / 2; if (ix - 2 < 0) ox_lo = 0;
+        for (int oy = oy_lo; oy <= iy / 2 && oy < OH; ++oy)
+            for (int ox = ox_lo; ox <= ix / 2 && ox < OW; ++ox) {
+                float m = -INFINITY; int am = -1;
+                for (int r = 0; r < 3; ++r)
+                    for (int s = 0; s < 3; ++s) {
+                        const float v = DT<T>::ld(xp + (size_t)(oy * 2 + r) * W + ox * 2 + s);
+                        if (v > m || am < 0) { m = v; am = r * 3 + s; }
+                    }
+                if (am == (iy - oy * 2) * 3 + (ix - ox * 2)) acc += DT<T>::ld(gp + (size_t)oy * OW + ox);
+            }
+        DT<T>::st(dx + i, acc);
+    }
+}
+
+// ---- squared-error sum: part[b] = sum (s*a - s*b)^2 ; final = sum(part) -----------------------------
+template <typename TA>
+__global__ __launch_bounds__(256) void sqdiff_partial_kernel(const TA* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ part, long long n, float scale) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    EW_LOOP(i, n) { const float d = scale * DT<TA>::ld(a + i) - scale * b[i]; s += d * d; }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ part, int n, float mul,
+                                                        float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) *out = s * mul;
+}
+// da = g * 2*scale^2*(a-b)/n
+template <typename TA>
+__global__ void sqdiff_bwd_kernel(const TA* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
+                                  TA* __restrict__ da, long long n, float coef) {
+    const float gg = *g * coef;
+    EW_LOOP(i, n) DT<TA>::st(da + i, gg * (DT<TA>::ld(a + i) - b[i]));
+}
+
+// ---- BCE with logits against a constant target, mean over n ----------------------------------------
+__global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ z, float target,
+                                                          float* __restrict__ part, long long n) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    EW_LOOP(i, n) {
+        const float x = z[i];
+        s += fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// dz (=|+=) g * (sigmoid(z) - target)/n
+__global__ void bce_bwd_kernel(const float* __restrict__ z, float target, const float* __restrict__ g,
+                               float* __restrict__ dz, long long n, float inv_n, int accumulate) {
+    const float gg = *g * inv_n;
+    EW_LOOP(i, n) {
+        const float v = gg * (1.f / (1.f + expf(-z[i])) - target);
+        if (accumulate) dz[i] += v; else dz[i] = v;
+    }
+}
+__global__ void sigmoid_kernel(const float* __restrict__ z, float* __restrict__ o, long long n) {
+    EW_LOOP(i, n) o[i] = 1.f / (1.f + expf(-z[i]));
+}
+
+// ---- Discriminator input: out[n, 0:Ci] = img[n], out[n, Ci:Ci+Cc] = nearest-upsample(ctx[n], x f) ---
+template <typename T>
+__global__ void upcat_fwd_kernel(const T* __restrict__ img, const T* __restrict__ ctx, T* __restrict__ out, int N,
+                                 int Ci, int Cc, int H, int W, int f) {
+    const int C = Ci + Cc, h = H / f, w = W / f;
+    const long long total = (long long)N * C * H * W;
+    EW_LOOP(i, total) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int c = (int)((i / ((long long)W * H)) % C);
+        const int n = (int)(i / ((long long)W * H * C));
+        T v;
+        if (c < Ci) v = img[(((size_t)n * Ci + c) * H + y) * W + x];
+        else v = ctx[(((size_t)n * Cc + (c - Ci)) * h + y / f) * w + x / f];
+        out[i] = v;
+    }
+}
+// dimg = dout[:, :Ci] (nimg leading images only; others have no grad), dctx = block sums of dout[:, Ci:]
+template <typename T>
+__global__ void upcat_bwd_img_kernel(const T* __restrict__ dout, T* __restrict__ dimg, int n0, int N, int Ci, int Cc,
+                                     int H, int W) {
+    const int C = Ci + Cc;
+    const long long total = (long long)N * Ci * H * W;
+    EW_LOOP(i, total) {
+        const long long hw = i % ((long long)H * W);
+        const int c = (int)((i / ((long long)H * W)) % Ci);
+        const int n = (int)(i / ((long long)H * W * Ci));
+        dimg[i] = dout[((size_t)(n0 + n) * C + c) * H * W + hw];
+    }
+}
+template <typename T>
+__global__ void upcat_bwd_ctx_kernel(const T* __restrict__ dout, T* __restrict__ dctx, int N, int Ci, int Cc, int H,
+                                     int W, int f) {
+    const int C = Ci + Cc, h = H / f, w = W / f;
+    const long long total = (long long)N * Cc * h * w * 64;   // one wave per output element
+    const int lane = threadIdx.x & 63;
+    for (long long gi = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; gi < total / 64;
+         gi += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const int x = (int)(gi % w), y = (int)((gi / w) % h);
+        const int c = (int)((gi / ((long long)w * h)) % Cc);
+        const int n = (int)(gi / ((long long)w * h * Cc));
+        const T* p = dout + (((size_t)n * C + Ci + c) * H + (size_t)y * f) * W + (size_t)x * f;
+        float s = 0.f;
+        for (int k = lane; k < f * f; k += 64) s += DT<T>::ld(p + (size_t)(k / f) * W + (k % f));
+        s = wave_sum(s);
+        if (lane == 0) DT<T>::st(dctx + gi, s);
+    }
+}
+
+// ---- spectral norm (one power iteration, torch.nn.utils.spectral_norm semantics) --------------------
+// W: [K, M] row-major f32.  step 1: vraw[m] = sum_k W[k,m] u[k]
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ W, const float* __restrict__ u,
+                                                     float* __restrict__ vraw, int K, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += W[(size_t)k * M + m] * u[k];
+    vraw[m] = s;
+}
+// x <- x / max(||x||, eps)   (single block)
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ x, float* __restrict__ o, int n,
+                                                           float eps) {
+    __shared__ float sh[4];
+    __shared__ float inv;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) inv = 1.f / fmaxf(sqrtf(s), eps);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) o[i] = x[i] * inv;
+}
+// step 2: wv[k] = sum_m W[k,m] v[m]   (one block per row)
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                                    float* __restrict__ wv, int K, int M) {
+    __shared__ float sh[4];
+    const int k = blockIdx.x;
+    float s = 0.f;
+    for (int m = threadIdx.x; m < M; m += 256) s += W[(size_t)k * M + m] * v[m];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) wv[k] = s;
+}
+// sigma = u . wv ; inv_sigma = 1/sigma  (single block)
+__global__ __launch_bounds__(256) void sn_sigma_kernel(const float* __restrict__ u, const float* __restrict__ wv,
+                                                       float* __restrict__ sigma_out, int K) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < K; i += 256) s += u[i] * wv[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) { sigma_out[0] = s; sigma_out[1] = 1.f / s; }
+}
+// backward: dWorig = (dW - (sum dW*Worig)/sigma * u v^T) / sigma
+__global__ __launch_bounds__(256) void sn_dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ part, long long n) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    EW_LOOP(i, n) s += a[i] * b[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void sn_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ u, const float* __restrict__ v,
+                              const float* __restrict__ sigma, const float* __restrict__ dot,
+                              float* __restrict__ dWorig, int K, int M, int accumulate) {
+    const float inv = sigma[1];
+    const float coef = *dot * inv * inv;   // (sum dW*Worig)/sigma^2
+    const long long total = (long long)K * M;
+    EW_LOOP(i, total) {
+        const int m = (int)(i % M), k = (int)(i / M);
+        const float val = dW[i] * inv - coef * u[k] * v[m];
+        if (accumulate) dWorig[i] += val; else dWorig[i] = val;
+    }
+}
+
+// ---- fused Adam over a flat parameter arena (torch.optim.Adam, amsgrad=False, weight_decay=0) --------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, float grad_scale) {
+    EW_LOOP(i, n) {
+        const float gi = g[i] * grad_scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+extern "C" {
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+    do { if ((dtype) == HIFIC_F32) { CALL_F32; } else if ((dtype) == HIFIC_BF16) { CALL_BF16; } else return HIFIC_ERR_ARG; } while (0)
+
+int hific_act_bwd(const void* dy, const void* y, void* dx, long long n, float slope, int dtype, hipStream_t st) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(act_bwd_kernel<float>, EW_GRID(n), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n, slope),
+        hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, EW_GRID(n), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n, slope));
+    return hific_launch_status();
+}
+
+int hific_add(const void* a, const void* b, void* o, long long n, int dtype, hipStream_t st) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(add_kernel<float>, EW_GRID(n), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)o, n),
+        hipLaunchKernelGGL(add_kernel<bf16_t>, EW_GRID(n), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)o, n));
+    return hific_launch_status();
+}
+
+int hific_cast(const void* a, int src_dtype, void* o, int dst_dtype, long long n, hipStream_t st) {
+    if (src_dtype == HIFIC_F32 && dst_dtype == HIFIC_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), EW_GRID(n), dim3(256), 0, st, (const float*)a, (bf16_t*)o, n);
+    else if (src_dtype == HIFIC_BF16 && dst_dtype == HIFIC_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), EW_GRID(n), dim3(256), 0, st, (const bf16_t*)a, (float*)o, n);
+    else if (src_dtype == HIFIC_F32 && dst_dtype == HIFIC_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), EW_GRID(n), dim3(256), 0, st, (const float*)a, (float*)o, n);
+    else if (src_dtype == HIFIC_BF16 && dst_dtype == HIFIC_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), EW_GRID(n), dim3(256), 0, st, (const bf16_t*)a, (bf16_t*)o, n);
+    else return HIFIC_ERR_ARG;
+    return hific_launch_status();
+}
+
+int hific_axpby_f32(const float* a, const float* b, float* o, float alpha, float beta, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(axpby_kernel, EW_GRID(n), dim3(256), 0, st, a, b, o, alpha, beta, n);
+    return hific_launch_status();
+}
+
+// out[c] (=|+=) sum_{n,hw} x[n,c,hw]; ws >= 64*C floats
+int hific_channel_sum(const void* x, float* out, int N, int C, int HW, int accumulate, int dtype, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
+    long long total = (long long)N * HW;
+    int nsplit = cdiv(1024, C); if (nsplit > 64) nsplit = 64;
+    if ((long long)nsplit * 256 > total) nsplit = (int)((total + 255) / 256);
+    if (nsplit < 1) nsplit = 1;
+    if ((size_t)nsplit * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
+    float* part = (float*)ws;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(chan_sum_kernel<float>, dim3(C, nsplit), dim3(256), 0, st, (const float*)x, part, N, C, HW, nsplit),
+        hipLaunchKernelGGL(chan_sum_kernel<bf16_t>, dim3(C, nsplit), dim3(256), 0, st, (const bf16_t*)x, part, N, C, HW, nsplit));
+    hipLaunchKernelGGL(chan_sum_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, out, C, nsplit, accumulate);
+    return hific_launch_status();
+}
+
+int hific_maxpool3s2_fwd(const void* x, void* y, long long planes, int H, int W, int dtype, hipStream_t st) {
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const long long total = planes * OH * OW;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(maxpool3s2_fwd_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)x, (float*)y, planes, H, W, OH, OW),
+        hipLaunchKernelGGL(maxpool3s2_fwd_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, planes, H, W, OH, OW));
+    return hific_launch_status();
+}
+int hific_maxpool3s2_bwd(const void* x, const void* dy, void* dx, long long planes, int H, int W, int dtype,
+                         hipStream_t st) {
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const long long total = planes * H * W;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(maxpool3s2_bwd_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, planes, H, W, OH, OW),
+        hipLaunchKernelGGL(maxpool3s2_bwd_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, planes, H, W, OH, OW));
+    return hific_launch_status();
+}
+
+// out[0] = mean((scale*a - scale*b)^2); a dtype, b f32 (the input image); ws >= 1024 floats
+int hific_mse_fwd(const void* a, const float* b, float* out, long long n, float scale, int dtype, void* ws,
+                  size_t ws_bytes, hipStream_t st) {
+    const int nb = 1024;
+    if (ws_bytes < nb * sizeof(float)) return HIFIC_ERR_WS;
+    float* part = (float*)ws;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(sqdiff_partial_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a, b, part, n, scale),
+        hipLaunchKernelGGL(sqdiff_partial_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a, b, part, n, scale));
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f / (float)n, out);
+    return hific_launch_status();
+}
+// da = (*g) * 2*scale^2*(a-b)/n
+int hific_mse_bwd(const void* a, const float* b, const float* g, void* da, long long n, float scale, int dtype,
+                  hipStream_t st) {
+    const float coef = 2.f * scale * scale / (float)n;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(sqdiff_bwd_kernel<float>, EW_GRID(n), dim3(256), 0, st, (const float*)a, b, g, (float*)da, n, coef),
+        hipLaunchKernelGGL(sqdiff_bwd_kernel<bf16_t>, EW_GRID(n), dim3(256), 0, st, (const bf16_t*)a, b, g, (bf16_t*)da, n, coef));
+    return hific_launch_status();
+}
+
+// out[0] = mean BCEWithLogits(z, target); ws >= 256 floats
+int hific_bce_fwd(const float* z, float target, float* out, long long n, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int nb = 256;
+    if (ws_bytes < nb * sizeof(float)) return HIFIC_ERR_WS;
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(bce_partial_kernel, dim3(nb), dim3(256), 0, st, z, target, part, n);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f / (float)n, out);
+    return hific_launch_status();
+}
+int hific_bce_bwd(const float* z, float target, const float* g, float* dz, long long n, int accumulate,
+                  hipStream_t st) {
+    hipLaunchKernelGGL(bce_bwd_kernel, EW_GRID(n), dim3(256), 0, st, z, target, g, dz, n, 1.f / (float)n, accumulate);
+    return hific_launch_status();
+}
+int hific_sigmoid_f32(const float* z, float* o, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(sigmoid_kernel, EW_GRID(n), dim3(256), 0, st, z, o, n);
+    return hific_launch_status();
+}
+
+int hific_upcat_fwd(const void* img, const void* ctx, void* out, int N, int Ci, int Cc, int H, int W, int f, int dtype,
+                    hipStream_t st) {
+    if (H % f || W % f) return HIFIC_ERR_ARG;
+    const long long total = (long long)N * (Ci + Cc) * H * W;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(upcat_fwd_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)img, (const float*)ctx, (float*)out, N, Ci, Cc, H, W, f),
+        hipLaunchKernelGGL(upcat_fwd_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)img, (const bf16_t*)ctx, (bf16_t*)out, N, Ci, Cc, H, W, f));
+    return hific_launch_status();
+}
+// dimg: [nimg,Ci,H,W] taken from images [n0, n0+nimg) of dout (pass nimg=0 to skip); dctx: [N,Cc,H/f,W/f] or null
+int hific_upcat_bwd(const void* dout, void* dimg, int n0, int nimg, void* dctx, int N, int Ci, int Cc, int H, int W,
+                    int f, int dtype, hipStream_t st) {
+    if (dimg && nimg > 0) {
+        const long long total = (long long)nimg * Ci * H * W;
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL(upcat_bwd_img_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)dout, (float*)dimg, n0, nimg, Ci, Cc, H, W),
+            hipLaunchKernelGGL(upcat_bwd_img_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dimg, n0, nimg, Ci, Cc, H, W));
+    }
+    if (dctx) {
+        const long long total = (long long)N * Cc * (H / f) * (W / f) * 64;
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL(upcat_bwd_ctx_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)dout, (float*)dctx, N, Ci, Cc, H, W, f),
+            hipLaunchKernelGGL(upcat_bwd_ctx_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dctx, N, Ci, Cc, H, W, f));
+    }
+    return hific_launch_status();
+}
+
+// One power iteration in place on (u [K], v [M]); sigma_out[0]=sigma, [1]=1/sigma. ws >= (K+M) floats.
+// do_iter=0 (eval mode): only sigma from the stored u, v.
+int hific_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma_out, int K, int M, int do_iter, float eps,
+                            void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws_bytes < (size_t)(K + M) * sizeof(float)) return HIFIC_ERR_WS;
+    float* tmpM = (float*)ws;
+    float* tmpK = tmpM + M;
+    if (do_iter) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, W, u, tmpM, K, M);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, tmpM, v, M, eps);
+        hipLaunchKernelGGL(sn_wv_kernel, dim3(K), dim3(256), 0, st, W, v, tmpK, K, M);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, tmpK, u, K, eps);
+    } else {
+        hipLaunchKernelGGL(sn_wv_kernel, dim3(K), dim3(256), 0, st, W, v, tmpK, K, M);
+    }
+    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, st, u, tmpK, sigma_out, K);
+    return hific_launch_status();
+}
+// dWorig (=|+=) (dW - (sum dW*Worig)/sigma * u v^T)/sigma ; ws >= 257 floats
+int hific_spectral_norm_bwd(const float* dW, const float* Worig, const float* u, const float* v, const float* sigma,
+                            float* dWorig, int K, int M, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int nb = 256;
+    if (ws_bytes < (nb + 1) * sizeof(float)) return HIFIC_ERR_WS;
+    float* part = (float*)ws;
+    float* dot = part + nb;
+    const long long n = (long long)K * M;
+    hipLaunchKernelGGL(sn_dot_partial_kernel, dim3(nb), dim3(256), 0, st, dW, Worig, part, n);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f, dot);
+    hipLaunchKernelGGL(sn_bwd_kernel, EW_GRID(n), dim3(256), 0, st, dW, u, v, sigma, dot, dWorig, K, M, accumulate);
+    return hific_launch_status();
+}
+
+// torch.optim.Adam step t (1-based) over flat f32 buffers; grad_scale multiplies g first (1/world for DDP means)
+int hific_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                    float eps, int step, float grad_scale, hipStream_t st) {
+    if (step < 1) return HIFIC_ERR_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, EW_GRID(n), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2), grad_scale);
+    return hific_launch_status();
+}
+
+}  // extern "C"

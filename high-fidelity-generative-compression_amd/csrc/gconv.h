@@ -1,0 +1,92 @@
+// Generic tap-table implicit-GEMM convolution engine for gfx950 (MFMA, LDS-staged NCHW tiles).
+//
+// One kernel family covers every dense contraction on the HiFIC hot path:
+//   conv2d fwd, conv2d bwd-data (as stride-phase sub-convs + reflect fold), conv-transpose fwd
+//   (sub-pixel phases, no zero insertion), conv-transpose bwd-data, and the weight-gradient GEMM.
+// Reference call sites this replaces (all nn.Conv2d / nn.ConvTranspose2d -> ATen/cuDNN there):
+//   src/network/encoder.py:56-101, src/network/generator.py:28-42,98-142, src/network/hyper.py:52-54,83-85,
+//   src/network/discriminator.py:35,53-64, src/loss/perceptual_similarity/pretrained_networks.py:59-75.
+#pragma once
+#include "common.h"
+
+#define GC_MAXPH 16
+#define GC_MAXTAPS 128
+#define GC_NPIX 128      // pixels per tile (GEMM N per workgroup)
+#define GC_TG 9          // taps accumulated per workgroup in the weight-gradient kernel
+
+struct GcPhase {
+    int ntaps, tap0;     // taps [tap0, tap0+ntaps) of the tap table
+    int ooy, oox;        // output position = u*ost + ooy (masked to the full plane)
+    int OHt, OWt;        // extent of the (u,v) tile domain
+    int dy_min, dx_min;  // min tap offset (patch origin)
+    int PH, PW;          // LDS patch extent per image
+    int tiles_x, tiles_y;
+    long long wp_off;    // element offset of this phase's packed weights
+};
+
+struct GcParams {
+    const void* in;      // [N, C, IH, IW]
+    const void* wp;      // packed weights, per phase [Kpad][ntaps][Cpad]
+    const float* bias;   // [K] or null
+    void* out;           // [N, K, OHf, OWf]
+    const void* resid;   // same shape as out, or null
+    int N, C, IH, IW, K, OHf, OWf, Cpad, Kpad;
+    int ist, ost, bmode, act, in_f32, out_f32;
+    int TH, TW, NI, tiles_n;
+    int nphase;
+    GcPhase ph[GC_MAXPH];
+    short tap_dy[GC_MAXTAPS], tap_dx[GC_MAXTAPS];
+    short tap_r[GC_MAXTAPS], tap_s[GC_MAXTAPS];
+};
+
+struct WgParams {
+    const void* a;       // [N, M, AH, AW]   output-side operand (dY, or x for conv-transpose)
+    const void* b;       // [N, C, BH, BW]   input-side operand, sampled at (u*ist+dy, v*ist+dx)
+    float* ws;           // partials [nsplit][Mpad][ntaps][Cpad]
+    int N, M, C, AH, AW, BH, BW, Mpad, Cpad;
+    int ist, bmode, a_f32, b_f32;
+    int TH, TW, NI, tiles_y, tiles_x, tiles_n, ntiles, tiles_per_split, nsplit;
+    int ntaps, ngroups;
+    GcPhase grp[GC_MAXPH];
+    short tap_dy[GC_MAXTAPS], tap_dx[GC_MAXTAPS];
+    short tap_r[GC_MAXTAPS], tap_s[GC_MAXTAPS];
+};
+
+// geometry of a conv layer as the reference constructs it (nn.Conv2d semantics)
+struct ConvGeom {
+    int N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode;
+    int OH() const { return (H + pt + pb - R) / stride + 1; }
+    int OW() const { return (W + pl + pr - S) / stride + 1; }
+};
+// nn.ConvTranspose2d semantics: x[N,Ci,H,W], w[Ci,Co,R,S]
+struct ConvTGeom {
+    int N, Ci, H, W, Co, R, S, stride, pad, outpad;
+    int OH() const { return (H - 1) * stride - 2 * pad + R + outpad; }
+    int OW() const { return (W - 1) * stride - 2 * pad + S + outpad; }
+};
+
+struct WsAlloc {   // bump allocator over the caller-provided workspace
+    char* base; size_t cap; size_t off;
+    void* take(size_t bytes) {
+        size_t a = (off + 255) & ~(size_t)255;
+        if (a + bytes > cap) return nullptr;
+        off = a + bytes;
+        return base + a;
+    }
+};
+
+int gc_conv_fwd(const ConvGeom& g, const void* x, const float* w, const float* w_scale, const float* bias,
+                void* y, const void* resid, int act, int dtype, int in_f32, int out_f32,
+                WsAlloc& ws, hipStream_t st);
+int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const float* w_scale, void* dx,
+                     int dtype, int in_f32, int out_f32, WsAlloc& ws, hipStream_t st);
+int gc_conv_bwd_weight(const ConvGeom& g, const void* x, const void* dy, float* dw, int accumulate,
+                       int dtype, int x_f32, int dy_f32, WsAlloc& ws, hipStream_t st);
+int gc_convT_fwd(const ConvTGeom& g, const void* x, const float* w, const float* bias, void* y, int act,
+                 int dtype, int in_f32, int out_f32, WsAlloc& ws, hipStream_t st);
+int gc_convT_bwd_data(const ConvTGeom& g, const void* dy, const float* w, void* dx, int dtype, int in_f32,
+                      int out_f32, WsAlloc& ws, hipStream_t st);
+int gc_convT_bwd_weight(const ConvTGeom& g, const void* x, const void* dy, float* dw, int accumulate,
+                        int dtype, int x_f32, int dy_f32, WsAlloc& ws, hipStream_t st);
+size_t gc_ws_bytes_conv(const ConvGeom& g, int dtype);
+size_t gc_ws_bytes_convT(const ConvTGeom& g, int dtype);

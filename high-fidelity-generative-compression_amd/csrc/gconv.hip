@@ -1,0 +1,829 @@
+// Tap-table implicit-GEMM convolution kernels (gfx950): see gconv.h for the op coverage.
+//
+// GEMM view per workgroup:  D[BM out-channels][128 pixels] += W[BM][tap,c] * X[tap,c][128 pixels]
+//   * pixels tile = NI images x TH rows x TW cols of the (u,v) output domain of one stride phase
+//   * the NCHW input halo patch of a c-chunk is read once from HBM (coalesced along W), transposed
+//     through registers into LDS as [patch pixel][c] and re-used by every tap (im2col-free)
+//   * packed weights [k][tap][c] stream through a double-buffered LDS tile, one (tap, c-chunk) per step
+//   * bf16: v_mfma_f32_32x32x16_bf16, f32 parity mode: v_mfma_f32_32x32x2_f32 (exact f32 fma chain)
+// Weight-gradient kernel: D[64 m][64 c] per tap += A^T[pixels][m] * Xpatch^T[pixels + tap][c], reduction over
+// pixels; both operands use the same transposed LDS image, bf16 fragments come from ds_read_b64_tr_b16.
+#include "gconv.h"
+#include <type_traits>
+#include <string.h>
+#include <stdlib.h>
+
+template <typename T> struct GcCfg;
+template <> struct GcCfg<bf16_t> { static constexpr int BC = 32, KS = 16, PITCH = 80; };
+template <> struct GcCfg<float>  { static constexpr int BC = 16, KS = 2,  PITCH = 68; };
+
+// ---------------------------------------------------------------------------------------------------
+// Transposing stage: NCHW global -> LDS image [NI*PH*PW rows][DWR dwords], row pitch PITCH bytes.
+// bf16: one dword = channels (c0+2*dw, c0+2*dw+1); f32: one dword = channel c0+dw.
+// Consecutive threads take consecutive patch pixels => coalesced global reads along W.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int DWR, int PITCH>
+__device__ __forceinline__ void stage_T(unsigned char* lds, const void* src, int src_f32,
+                                        int N, int C, int H, int W, int bmode,
+                                        int n0, int NI, int y0, int x0, int ystep_unused, int PH, int PW,
+                                        int c0, int tid, int nthreads) {
+    const int npp = PH * PW;
+    const int npatch = NI * npp;
+    const int nitems = npatch * DWR;
+    const size_t plane = (size_t)H * W;
+    for (int it = tid; it < nitems; it += nthreads) {
+        const int dw = it / npatch;
+        const int q = it - dw * npatch;
+        const int img = q / npp;
+        const int r = q - img * npp;
+        const int py = r / PW;
+        const int px = r - py * PW;
+        int iy = y0 + py, ix = x0 + px;
+        const int n = n0 + img;
+        if (bmode == PAD_REFLECT) { iy = reflect_idx(iy, H); ix = reflect_idx(ix, W); }
+        const bool ok = (n < N) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+        unsigned val = 0;
+        if (ok) {
+            const size_t base = (size_t)n * C * plane + (size_t)iy * W + ix;
+            if constexpr (std::is_same<T, float>::value) {
+                const int c = c0 + dw;
+                if (c < C) val = __float_as_uint(((const float*)src)[base + (size_t)c * plane]);
+            } else {
+                const int c = c0 + 2 * dw;
+                unsigned lo = 0, hi = 0;
+                if (src_f32) {
+                    const float* s = (const float*)src;
+                    if (c < C) lo = f2bf(s[base + (size_t)c * plane]);
+                    if (c + 1 < C) hi = f2bf(s[base + (size_t)(c + 1) * plane]);
+                } else {
+                    const bf16_t* s = (const bf16_t*)src;
+                    if (c < C) lo = s[base + (size_t)c * plane];
+                    if (c + 1 < C) hi = s[base + (size_t)(c + 1) * plane];
+                }
+                val = lo | (hi << 16);
+            }
+        }
+        *(unsigned*)(lds + (size_t)q * PITCH + dw * 4) = val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Forward-type kernel
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
+    using Cfg = GcCfg<T>;
+    constexpr int BC = Cfg::BC, KS = Cfg::KS, PITCH = Cfg::PITCH;
+    constexpr int BM = WGM * WM * 32;
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(WGN * WN * 32 == GC_NPIX, "128 pixels per tile");
+    constexpr int WBYTES = BM * PITCH;
+    constexpr int NWP = (BM * 4 + 255) / 256;   // 16-byte weight pieces per thread per step
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const GcPhase& ph = p.ph[blockIdx.z];
+    const int ntile_ph = p.tiles_n * ph.tiles_y * ph.tiles_x;
+    if ((int)blockIdx.x >= ntile_ph) return;
+    const int tile = blockIdx.x;
+    const int tx = tile % ph.tiles_x;
+    const int ty = (tile / ph.tiles_x) % ph.tiles_y;
+    const int tn = tile / (ph.tiles_x * ph.tiles_y);
+    const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
+    const int m0 = blockIdx.y * BM;
+    const int PH = ph.PH, PW = ph.PW;
+    const int npp = PH * PW;
+    const int npatch = p.NI * npp;
+    const int iy0 = u0 * p.ist + ph.dy_min, ix0 = v0 * p.ist + ph.dx_min;
+
+    unsigned char* wbuf = smem;                       // 2 x WBYTES
+    unsigned char* patch = smem + 2 * WBYTES;         // npatch x PITCH
+
+    // per-lane pixel decode for the B (pixel) operand and the epilogue
+    int qb[WN], pu[WN], pv[WN], pn[WN];
+    bool pvalid[WN];
+    const int thw = p.TH * p.TW;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int pt = (wn * WN + ni) * 32 + l31;
+        const int img = pt / thw;
+        const int rem = pt - img * thw;
+        const int ty_ = rem / p.TW;
+        const int tx_ = rem - ty_ * p.TW;
+        const bool v = img < p.NI;
+        pvalid[ni] = v;
+        qb[ni] = v ? (img * npp + ty_ * p.ist * PW + tx_ * p.ist) : 0;
+        pu[ni] = u0 + ty_; pv[ni] = v0 + tx_; pn[ni] = n0 + img;
+    }
+
+    f32x16_t acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nt = ph.ntaps;
+    const int nchunks = p.Cpad / BC;
+    const int nsteps = nchunks * nt;
+    const unsigned char* wp_ph = (const unsigned char*)p.wp + (size_t)ph.wp_off * sizeof(T);
+    const size_t wrow_bytes = (size_t)nt * p.Cpad * sizeof(T);   // one m-row of this phase
+
+    uint4 wreg[NWP];
+    auto load_w = [&](int chunk, int t) {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int piece = tid + i * 256;
+            if (piece < BM * 4) {
+                const int row = piece >> 2, part = piece & 3;
+                const unsigned char* g = wp_ph + (size_t)(m0 + row) * wrow_bytes +
+                                         ((size_t)t * p.Cpad + (size_t)chunk * BC) * sizeof(T) + part * 16;
+                wreg[i] = *(const uint4*)g;
+            }
+        }
+    };
+    auto store_w = [&](unsigned char* wb) {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int piece = tid + i * 256;
+            if (piece < BM * 4) {
+                const int row = piece >> 2, part = piece & 3;
+                unsigned char* d = wb + row * PITCH + part * 16;
+                if constexpr (PITCH % 16 == 0) {
+                    *(uint4*)d = wreg[i];
+                } else {
+                    ((unsigned*)d)[0] = wreg[i].x; ((unsigned*)d)[1] = wreg[i].y;
+                    ((unsigned*)d)[2] = wreg[i].z; ((unsigned*)d)[3] = wreg[i].w;
+                }
+            }
+        }
+    };
+
+    if (nsteps > 0) load_w(0, 0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        stage_T<T, 16, PITCH>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode,
+                              n0, p.NI, iy0, ix0, 0, PH, PW, chunk * BC, tid, 256);
+        for (int t = 0; t < nt; ++t) {
+            const int step = chunk * nt + t;
+            unsigned char* wb = wbuf + (step & 1) * WBYTES;
+            store_w(wb);
+            __syncthreads();
+            if (step + 1 < nsteps) {
+                if (t + 1 < nt) load_w(chunk, t + 1); else load_w(chunk + 1, 0);
+            }
+            const int tdy = (int)p.tap_dy[ph.tap0 + t] - ph.dy_min;
+            const int tdx = (int)p.tap_dx[ph.tap0 + t] - ph.dx_min;
+            const int toff = tdy * PW + tdx;
+            const unsigned char* arow = wb + (wm * WM * 32 + l31) * PITCH;
+#pragma unroll
+            for (int kk = 0; kk < BC / KS; ++kk) {
+                if constexpr (std::is_same<T, float>::value) {
+                    float a[WM], b[WN];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+                        a[mi] = *(const float*)(arow + mi * 32 * PITCH + (kk * 2 + lhi) * 4);
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        b[ni] = *(const float*)(patch + (size_t)(qb[ni] + toff) * PITCH + (kk * 2 + lhi) * 4);
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < WN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                } else {
+                    bf16x8_t a[WM], b[WN];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+                        a[mi] = *(const bf16x8_t*)(arow + mi * 32 * PITCH + kk * 32 + lhi * 16);
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        b[ni] = *(const bf16x8_t*)(patch + (size_t)(qb[ni] + toff) * PITCH + kk * 32 + lhi * 16);
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < WN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: bias + residual + activation, NCHW store (32 consecutive pixels per store instruction)
+    const bool out_f32 = std::is_same<T, float>::value || p.out_f32;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int oy = pu[ni] * p.ost + ph.ooy, ox = pv[ni] * p.ost + ph.oox;
+        const bool okp = pvalid[ni] && pn[ni] < p.N && pu[ni] < ph.OHt && pv[ni] < ph.OWt &&
+                         (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
+        if (!okp) continue;
+        const size_t pbase = (size_t)pn[ni] * p.K * p.OHf * p.OWf + (size_t)oy * p.OWf + ox;
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < p.K) {
+                    float v = acc[mi][ni][r];
+                    if (p.bias) v += p.bias[m];
+                    const size_t idx = pbase + (size_t)m * p.OHf * p.OWf;
+                    if (p.resid) v += out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
+                    if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
+                    if (out_f32) ((float*)p.out)[idx] = v; else ((bf16_t*)p.out)[idx] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight packing: wp[phase][m][t][c] = w[m*sm + c*sc + r_t*sr + s_t*ss] * scale   (zero padded)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_w_kernel(const GcParams p, const float* __restrict__ w, const float* scale,
+                              long long sm, long long sc, long long sr, long long ss) {
+    const GcPhase& ph = p.ph[blockIdx.y];
+    const long long total = (long long)p.Kpad * ph.ntaps * p.Cpad;
+    const float sc_ = scale ? *scale : 1.f;
+    T* dst = (T*)p.wp + ph.wp_off;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % p.Cpad);
+        const long long j = i / p.Cpad;
+        const int t = (int)(j % ph.ntaps);
+        const int m = (int)(j / ph.ntaps);
+        float v = 0.f;
+        if (m < p.K && c < p.C) {
+            const int r = p.tap_r[ph.tap0 + t], s = p.tap_s[ph.tap0 + t];
+            v = w[m * sm + c * sc + r * sr + s * ss] * sc_;
+        }
+        DT<T>::st(dst + i, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Reflect fold: dx[y,x] = sum over padded positions that the reflection pad maps onto (y,x)
+// (adjoint of ReflectionPad2d, torch reflection_pad2d_backward)
+// ---------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void reflect_fold_kernel(const float* __restrict__ src, TO* __restrict__ dst, long long planes,
+                                    int H, int W, int pt, int pl, int pb, int pr) {
+    const int Hp = H + pt + pb, Wp = W + pl + pr;
+    const long long total = planes * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const long long pc = i / ((long long)W * H);
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + pt;
+        if (y >= 1 && y <= pt) ys[ny++] = pt - y;
+        if (y <= H - 2 && y >= H - 1 - pb) ys[ny++] = pt + 2 * (H - 1) - y;
+        xs[nx++] = x + pl;
+        if (x >= 1 && x <= pl) xs[nx++] = pl - x;
+        if (x <= W - 2 && x >= W - 1 - pr) xs[nx++] = pl + 2 * (W - 1) - x;
+        const float* s = src + pc * Hp * Wp;
+        float acc = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) acc += s[(long long)ys[a] * Wp + xs[b]];
+        DT<TO>::st(dst + i, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight-gradient kernel
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct WgCfg;
+template <> struct WgCfg<bf16_t> { static constexpr int DWR = 32, PITCH = 144, KS = 16; };
+template <> struct WgCfg<float>  { static constexpr int DWR = 64, PITCH = 260, KS = 2; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
+    using Cfg = WgCfg<T>;
+    constexpr int PITCH = Cfg::PITCH, KS = Cfg::KS, DWR = Cfg::DWR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const GcPhase& gp = p.grp[blockIdx.y];
+    const int ctiles = p.Cpad / 64;
+    const int m0 = (blockIdx.x / ctiles) * 64;
+    const int c0 = (blockIdx.x % ctiles) * 64;
+    const int split = blockIdx.z;
+    const int PH = gp.PH, PW = gp.PW, npp = PH * PW;
+    const int npix = p.NI * p.TH * p.TW;          // multiple of 16
+    const int npatch = p.NI * npp;
+
+    int* qtab = (int*)smem;                                   // [128]
+    unsigned char* at = smem + 512;                           // [npix][PITCH]
+    unsigned char* patch = at + (size_t)GC_NPIX * PITCH;      // [npatch][PITCH]
+
+    const int thw = p.TH * p.TW;
+    if (tid < GC_NPIX) {
+        const int img = tid / thw;
+        const int rem = tid - img * thw;
+        const int ty_ = rem / p.TW, tx_ = rem - ty_ * p.TW;
+        qtab[tid] = (tid < npix) ? (img * npp + ty_ * p.ist * PW + tx_ * p.ist) : 0;
+    }
+    int toffs[GC_TG];
+#pragma unroll
+    for (int t = 0; t < GC_TG; ++t) {
+        const int tt = t < gp.ntaps ? t : 0;
+        toffs[t] = ((int)p.tap_dy[gp.tap0 + tt] - gp.dy_min) * PW + ((int)p.tap_dx[gp.tap0 + tt] - gp.dx_min);
+    }
+
+    f32x16_t acc[GC_TG];
+#pragma unroll
+    for (int t = 0; t < GC_TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int tile_lo = split * p.tiles_per_split;
+    int tile_hi = tile_lo + p.tiles_per_split;
+    if (tile_hi > p.ntiles) tile_hi = p.ntiles;
+
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        const int tx = tile % p.tiles_x;
+        const int ty = (tile / p.tiles_x) % p.tiles_y;
+        const int tn = tile / (p.tiles_x * p.tiles_y);
+        const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
+        __syncthreads();
+        stage_T<T, DWR, PITCH>(at, p.a, p.a_f32, p.N, p.M, p.AH, p.AW, PAD_ZERO,
+                               n0, p.NI, u0, v0, 0, p.TH, p.TW, m0, tid, 256);
+        stage_T<T, DWR, PITCH>(patch, p.b, p.b_f32, p.N, p.C, p.BH, p.BW, p.bmode,
+                               n0, p.NI, u0 * p.ist + gp.dy_min, v0 * p.ist + gp.dx_min, 0, PH, PW, c0, tid, 256);
+        __syncthreads();
+        for (int ks = 0; ks < npix / KS; ++ks) {
+            if constexpr (std::is_same<T, float>::value) {
+                const int r = ks * 2 + lhi;
+                const float a = *(const float*)(at + (size_t)r * PITCH + (wm * 32 + l31) * 4);
+                const unsigned char* brow = patch + (size_t)qtab[r] * PITCH + (wn * 32 + l31) * 4;
+#pragma unroll
+                for (int t = 0; t < GC_TG; ++t) {
+                    if (t < gp.ntaps) {
+                        const float b = *(const float*)(brow + (size_t)toffs[t] * PITCH);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            } else {
+                // ds_read_b64_tr_b16: each 16-lane group reads a [4 rows][16 cols] bf16 block; lane i supplies the
+                // address of row (i>>2), col chunk (i&3)*4 and receives column i of the 4 rows.
+                const int g = lane >> 4, i16 = lane & 15;
+                const int rb = ks * 16 + (g >> 1) * 8 + (i16 >> 2);
+                const int colb = ((g & 1) * 16 + (i16 & 3) * 4) * 2;
+                typedef __attribute__((address_space(3))) short4_t* lds_s4;
+                const unsigned char* a0p = at + (size_t)rb * PITCH + wm * 64 + colb;
+                const unsigned char* a1p = at + (size_t)(rb + 4) * PITCH + wm * 64 + colb;
+                short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)a0p);
+                short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)a1p);
+                bf16x8_t a;
+                {
+                    typedef __attribute__((ext_vector_type(8))) short short8_t;
+                    short8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    a = __builtin_bit_cast(bf16x8_t, av);
+                }
+                const int q0 = qtab[rb], q1 = qtab[rb + 4];
+                const unsigned char* b0row = patch + (size_t)q0 * PITCH + wn * 64 + colb;
+                const unsigned char* b1row = patch + (size_t)q1 * PITCH + wn * 64 + colb;
+#pragma unroll
+                for (int t = 0; t < GC_TG; ++t) {
+                    if (t < gp.ntaps) {
+                        short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b0row + (size_t)toffs[t] * PITCH));
+                        short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b1row + (size_t)toffs[t] * PITCH));
+                        typedef __attribute__((ext_vector_type(8))) short short8_t;
+                        short8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                        bf16x8_t b = __builtin_bit_cast(bf16x8_t, bv);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // partials: ws[split][m][tap][c]
+#pragma unroll
+    for (int t = 0; t < GC_TG; ++t) {
+        if (t < gp.ntaps) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int c = c0 + wn * 32 + l31;
+                p.ws[(((size_t)split * p.Mpad + m) * p.ntaps + (gp.tap0 + t)) * p.Cpad + c] = acc[t][r];
+            }
+        }
+    }
+}
+
+// dw[m*sm + c*sc + r*sr + s*ss] (=|+=) sum_split ws[split][m][t][c]
+__global__ void wgrad_finalize_kernel(const WgParams p, float* __restrict__ dw, long long sm, long long sc,
+                                      long long sr, long long ss, int accumulate) {
+    const long long total = (long long)p.M * p.C * p.ntaps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % p.ntaps);
+        const long long j = i / p.ntaps;
+        const int c = (int)(j % p.C);
+        const int m = (int)(j / p.C);
+        float s = 0.f;
+        for (int sp = 0; sp < p.nsplit; ++sp)
+            s += p.ws[(((size_t)sp * p.Mpad + m) * p.ntaps + t) * p.Cpad + c];
+        const long long o = m * sm + c * sc + p.tap_r[t] * sr + p.tap_s[t] * ss;
+        if (accumulate) dw[o] += s; else dw[o] = s;
+    }
+}
+
+// ===================================================================================================
+// Host-side planning
+// ===================================================================================================
+static int p2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
+static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s ? atoi(s) : dflt; }
+
+static const int kLdsBudget = 150 * 1024;
+
+// choose (TH, TW, NI) for a (u,v) domain; patch extent depends on tap span and input stride
+static bool choose_tile(int N, int OHt, int OWt, int ist, int span_y, int span_x, int pitch, int fixed_bytes,
+                        int pref_budget, int& TH, int& TW, int& NI) {
+    TW = p2ceil(OWt); if (TW > 16) TW = 16; if (TW < 1) TW = 1;
+    TH = p2ceil(OHt); if (TH > GC_NPIX / TW) TH = GC_NPIX / TW;
+    NI = GC_NPIX / (TH * TW); { int n2 = p2ceil(N); if (NI > n2) NI = n2; }
+    auto bytes = [&](int th, int tw, int ni) {
+        long long ph = (long long)(th - 1) * ist + span_y, pw = (long long)(tw - 1) * ist + span_x;
+        return (long long)ni * ph * pw * pitch + fixed_bytes;
+    };
+    int budget = pref_budget;
+    for (int pass = 0; pass < 2; ++pass) {
+        int th = TH, tw = TW, ni = NI;
+        while (bytes(th, tw, ni) > budget) {
+            if (ni > 1) ni >>= 1;
+            else if (th > 1 && th >= tw) th >>= 1;
+            else if (tw > 4) tw >>= 1;
+            else if (th > 1) th >>= 1;
+            else break;
+        }
+        if (bytes(th, tw, ni) <= budget) { TH = th; TW = tw; NI = ni; return true; }
+        budget = kLdsBudget;
+    }
+    return false;
+}
+
+struct TapList { int n; short dy[GC_MAXTAPS], dx[GC_MAXTAPS], r[GC_MAXTAPS], s[GC_MAXTAPS]; };
+
+static void finish_phase(GcPhase& ph, const GcParams& p) {
+    int dymin = 0, dymax = 0, dxmin = 0, dxmax = 0;
+    for (int t = 0; t < ph.ntaps; ++t) {
+        int dy = p.tap_dy[ph.tap0 + t], dx = p.tap_dx[ph.tap0 + t];
+        if (t == 0) { dymin = dymax = dy; dxmin = dxmax = dx; }
+        if (dy < dymin) dymin = dy; if (dy > dymax) dymax = dy;
+        if (dx < dxmin) dxmin = dx; if (dx > dxmax) dxmax = dx;
+    }
+    ph.dy_min = dymin; ph.dx_min = dxmin;
+    ph.PH = dymax - dymin + 1; ph.PW = dxmax - dxmin + 1;   // spans; converted to patch extents later
+}
+
+template <typename T>
+static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
+                          long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+    using Cfg = GcCfg<T>;
+    // M tile
+    int bm;
+    {
+        long long w128 = cdivl(p.K, 128) * 128, w64 = cdivl(p.K, 64) * 64;
+        if (p.K <= 32) bm = 32;
+        else if (w128 * 100 > w64 * 105) bm = 64;
+        else bm = 128;
+        int e = env_int("HIFIC_BM", 0);
+        if (e == 32 || e == 64 || e == 128) bm = e;
+    }
+    p.Kpad = cdiv(p.K, bm) * bm;
+    p.Cpad = cdiv(p.C, Cfg::BC) * Cfg::BC;
+    // tile shape: common to all phases (largest span decides)
+    int span_y = 1, span_x = 1, OHt = 1, OWt = 1;
+    for (int i = 0; i < p.nphase; ++i) {
+        if (p.ph[i].PH > span_y) span_y = p.ph[i].PH;
+        if (p.ph[i].PW > span_x) span_x = p.ph[i].PW;
+        if (p.ph[i].OHt > OHt) OHt = p.ph[i].OHt;
+        if (p.ph[i].OWt > OWt) OWt = p.ph[i].OWt;
+    }
+    const int wbytes = 2 * bm * Cfg::PITCH;
+    if (!choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, Cfg::PITCH, wbytes, 64 * 1024, p.TH, p.TW, p.NI))
+        return HIFIC_ERR_UNSUPPORTED;
+    p.tiles_n = cdiv(p.N, p.NI);
+    long long wp_elems = 0;
+    int max_tiles = 0;
+    size_t lds = 0;
+    for (int i = 0; i < p.nphase; ++i) {
+        GcPhase& ph = p.ph[i];
+        const int sy = ph.PH, sx = ph.PW;
+        ph.PH = (p.TH - 1) * p.ist + sy;
+        ph.PW = (p.TW - 1) * p.ist + sx;
+        ph.tiles_y = cdiv(ph.OHt, p.TH);
+        ph.tiles_x = cdiv(ph.OWt, p.TW);
+        ph.wp_off = wp_elems;
+        wp_elems += (long long)p.Kpad * ph.ntaps * p.Cpad;
+        int nt = p.tiles_n * ph.tiles_y * ph.tiles_x;
+        if (nt > max_tiles) max_tiles = nt;
+        size_t b = (size_t)wbytes + (size_t)p.NI * ph.PH * ph.PW * Cfg::PITCH;
+        if (b > lds) lds = b;
+    }
+    if (lds > (size_t)kLdsBudget) return HIFIC_ERR_UNSUPPORTED;
+    void* wp = ws.take((size_t)(wp_elems > 0 ? wp_elems : 1) * sizeof(T));
+    if (!wp) return HIFIC_ERR_WS;
+    p.wp = wp;
+    // pack
+    {
+        long long mx = 0;
+        for (int i = 0; i < p.nphase; ++i) {
+            long long e = (long long)p.Kpad * p.ph[i].ntaps * p.Cpad;
+            if (e > mx) mx = e;
+        }
+        if (mx > 0) {
+            int gx = (int)((mx + 255) / 256); if (gx > 4096) gx = 4096;
+            hipLaunchKernelGGL(pack_w_kernel<T>, dim3(gx, p.nphase), dim3(256), 0, st, p, w, w_scale, sm, sc, sr, ss);
+        }
+    }
+    dim3 grid(max_tiles, p.Kpad / bm, p.nphase);
+#define GC_LAUNCH(WGM, WGN, WM, WN)                                                                      \
+    do {                                                                                                 \
+        auto kfn = gconv_kernel<T, WGM, WGN, WM, WN>;                                                    \
+        if (lds > 48 * 1024)                                                                             \
+            hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);                                            \
+    } while (0)
+    if (bm == 128) GC_LAUNCH(2, 2, 2, 2);
+    else if (bm == 64) GC_LAUNCH(2, 2, 1, 2);
+    else GC_LAUNCH(1, 4, 1, 1);
+#undef GC_LAUNCH
+    return hific_launch_status();
+}
+
+static int launch_gconv(GcParams& p, int dtype, const float* w, const float* w_scale, long long sm, long long sc,
+                        long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+    if (dtype == HIFIC_F32) { p.in_f32 = 1; p.out_f32 = 1; return launch_gconv_t<float>(p, w, w_scale, sm, sc, sr, ss, ws, st); }
+    if (dtype == HIFIC_BF16) return launch_gconv_t<bf16_t>(p, w, w_scale, sm, sc, sr, ss, ws, st);
+    return HIFIC_ERR_ARG;
+}
+
+static void add_tap(GcParams& p, int& nt, int dy, int dx, int r, int s) {
+    p.tap_dy[nt] = (short)dy; p.tap_dx[nt] = (short)dx; p.tap_r[nt] = (short)r; p.tap_s[nt] = (short)s; ++nt;
+}
+
+int gc_conv_fwd(const ConvGeom& g, const void* x, const float* w, const float* w_scale, const float* bias,
+                void* y, const void* resid, int act, int dtype, int in_f32, int out_f32,
+                WsAlloc& ws, hipStream_t st) {
+    if (g.R * g.S > GC_MAXTAPS) return HIFIC_ERR_UNSUPPORTED;
+    GcParams p; memset(&p, 0, sizeof(p));
+    p.in = x; p.bias = bias; p.out = y; p.resid = resid;
+    p.N = g.N; p.C = g.C; p.IH = g.H; p.IW = g.W; p.K = g.K; p.OHf = g.OH(); p.OWf = g.OW();
+    p.ist = g.stride; p.ost = 1; p.bmode = g.pad_mode; p.act = act; p.in_f32 = in_f32; p.out_f32 = out_f32;
+    p.nphase = 1;
+    int nt = 0;
+    for (int r = 0; r < g.R; ++r) for (int s = 0; s < g.S; ++s) add_tap(p, nt, r - g.pt, s - g.pl, r, s);
+    GcPhase& ph = p.ph[0];
+    ph.ntaps = nt; ph.tap0 = 0; ph.ooy = 0; ph.oox = 0; ph.OHt = p.OHf; ph.OWt = p.OWf;
+    finish_phase(ph, p);
+    const long long RS = (long long)g.R * g.S;
+    return launch_gconv(p, dtype, w, w_scale, (long long)g.C * RS, RS, g.S, 1, ws, st);
+}
+
+// data gradient of a strided conv: stride-phase decomposition over the padded input domain
+int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const float* w_scale, void* dx,
+                     int dtype, int in_f32, int out_f32, WsAlloc& ws, hipStream_t st) {
+    const int stv = g.stride;
+    if (stv * stv > GC_MAXPH || g.R * g.S > GC_MAXTAPS) return HIFIC_ERR_UNSUPPORTED;
+    const bool has_pad = (g.pt | g.pl | g.pb | g.pr) != 0;
+    const bool fold = has_pad && g.pad_mode == PAD_REFLECT;
+    const int Hp = g.H + g.pt + g.pb, Wp = g.W + g.pl + g.pr;
+    GcParams p; memset(&p, 0, sizeof(p));
+    p.in = dy; p.bias = nullptr; p.resid = nullptr;
+    p.N = g.N; p.C = g.K; p.IH = g.OH(); p.IW = g.OW(); p.K = g.C;
+    p.ist = 1; p.ost = stv; p.bmode = PAD_ZERO; p.act = ACT_NONE; p.in_f32 = in_f32;
+    float* padbuf = nullptr;
+    if (fold) {
+        padbuf = (float*)ws.take((size_t)g.N * g.C * Hp * Wp * sizeof(float));
+        if (!padbuf) return HIFIC_ERR_WS;
+        p.out = padbuf; p.out_f32 = 1; p.OHf = Hp; p.OWf = Wp;
+    } else {
+        p.out = dx; p.out_f32 = out_f32; p.OHf = g.H; p.OWf = g.W;
+    }
+    int nt = 0, np = 0;
+    for (int py = 0; py < stv; ++py) for (int px = 0; px < stv; ++px) {
+        GcPhase& ph = p.ph[np];
+        ph.tap0 = nt;
+        for (int r = 0; r < g.R; ++r) {
+            if ((r - py) % stv != 0) continue;
+            for (int s = 0; s < g.S; ++s) {
+                if ((s - px) % stv != 0) continue;
+                add_tap(p, nt, (py - r) / stv, (px - s) / stv, r, s);
+            }
+        }
+        ph.ntaps = nt - ph.tap0;
+        ph.OHt = (Hp - py + stv - 1) / stv; ph.OWt = (Wp - px + stv - 1) / stv;
+        if (ph.OHt <= 0 || ph.OWt <= 0) { nt = ph.tap0; continue; }
+        ph.ooy = fold ? py : py - g.pt; ph.oox = fold ? px : px - g.pl;
+        finish_phase(ph, p);
+        ++np;
+    }
+    p.nphase = np;
+    const long long RS = (long long)g.R * g.S;
+    // out-channel m = c (stride RS), reduction channel = k (stride C*RS)
+    int rc = launch_gconv(p, dtype, w, w_scale, RS, (long long)g.C * RS, g.S, 1, ws, st);
+    if (rc != HIFIC_OK) return rc;
+    if (fold) {
+        const long long planes = (long long)g.N * g.C;
+        long long total = planes * g.H * g.W;
+        int gx = (int)((total + 255) / 256); if (gx > 8192) gx = 8192;
+        const bool of32 = (dtype == HIFIC_F32) || out_f32;
+        if (of32)
+            hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(gx), dim3(256), 0, st, padbuf, (float*)dx, planes,
+                               g.H, g.W, g.pt, g.pl, g.pb, g.pr);
+        else
+            hipLaunchKernelGGL(reflect_fold_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, padbuf, (bf16_t*)dx, planes,
+                               g.H, g.W, g.pt, g.pl, g.pb, g.pr);
+        return hific_launch_status();
+    }
+    return HIFIC_OK;
+}
+
+int gc_convT_fwd(const ConvTGeom& g, const void* x, const float* w, const float* bias, void* y, int act,
+                 int dtype, int in_f32, int out_f32, WsAlloc& ws, hipStream_t st) {
+    const int stv = g.stride;
+    if (stv * stv > GC_MAXPH || g.R * g.S > GC_MAXTAPS) return HIFIC_ERR_UNSUPPORTED;
+    GcParams p; memset(&p, 0, sizeof(p));
+    p.in = x; p.bias = bias; p.out = y; p.resid = nullptr;
+    p.N = g.N; p.C = g.Ci; p.IH = g.H; p.IW = g.W; p.K = g.Co; p.OHf = g.OH(); p.OWf = g.OW();
+    p.ist = 1; p.ost = stv; p.bmode = PAD_ZERO; p.act = act; p.in_f32 = in_f32; p.out_f32 = out_f32;
+    int nt = 0, np = 0;
+    for (int py = 0; py < stv; ++py) for (int px = 0; px < stv; ++px) {
+        GcPhase& ph = p.ph[np];
+        ph.tap0 = nt;
+        for (int r = 0; r < g.R; ++r) {
+            if ((py + g.pad - r) % stv != 0) continue;
+            for (int s = 0; s < g.S; ++s) {
+                if ((px + g.pad - s) % stv != 0) continue;
+                // floor-exact because the numerator is a multiple of stride
+                add_tap(p, nt, (py + g.pad - r) / stv, (px + g.pad - s) / stv, r, s);
+            }
+        }
+        ph.ntaps = nt - ph.tap0;
+        ph.OHt = (p.OHf - py + stv - 1) / stv; ph.OWt = (p.OWf - px + stv - 1) / stv;
+        if (ph.OHt <= 0 || ph.OWt <= 0) { nt = ph.tap0; continue; }
+        ph.ooy = py; ph.oox = px;
+        finish_phase(ph, p);
+        ++np;
+    }
+    p.nphase = np;
+    const long long RS = (long long)g.R * g.S;
+    // w[ci][co][r][s]: m = co (stride RS), reduction channel ci (stride Co*RS)
+    return launch_gconv(p, dtype, w, nullptr, RS, (long long)g.Co * RS, g.S, 1, ws, st);
+}
+
+int gc_convT_bwd_data(const ConvTGeom& g, const void* dy, const float* w, void* dx, int dtype, int in_f32,
+                      int out_f32, WsAlloc& ws, hipStream_t st) {
+    if (g.R * g.S > GC_MAXTAPS) return HIFIC_ERR_UNSUPPORTED;
+    GcParams p; memset(&p, 0, sizeof(p));
+    p.in = dy; p.out = dx;
+    p.N = g.N; p.C = g.Co; p.IH = g.OH(); p.IW = g.OW(); p.K = g.Ci; p.OHf = g.H; p.OWf = g.W;
+    p.ist = g.stride; p.ost = 1; p.bmode = PAD_ZERO; p.act = ACT_NONE; p.in_f32 = in_f32; p.out_f32 = out_f32;
+    p.nphase = 1;
+    int nt = 0;
+    for (int r = 0; r < g.R; ++r) for (int s = 0; s < g.S; ++s) add_tap(p, nt, r - g.pad, s - g.pad, r, s);
+    GcPhase& ph = p.ph[0];
+    ph.ntaps = nt; ph.tap0 = 0; ph.OHt = g.H; ph.OWt = g.W;
+    finish_phase(ph, p);
+    const long long RS = (long long)g.R * g.S;
+    // m = ci (stride Co*RS), reduction channel co (stride RS)
+    return launch_gconv(p, dtype, w, nullptr, (long long)g.Co * RS, RS, g.S, 1, ws, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, long long sr, long long ss,
+                          int accumulate, WsAlloc& ws, hipStream_t st) {
+    using Cfg = WgCfg<T>;
+    p.Mpad = cdiv(p.M, 64) * 64; p.Cpad = cdiv(p.C, 64) * 64;
+    // tap groups of <= GC_TG consecutive taps
+    p.ngroups = cdiv(p.ntaps, GC_TG);
+    if (p.ngroups > GC_MAXPH) return HIFIC_ERR_UNSUPPORTED;
+    int span_y = 1, span_x = 1;
+    for (int gi = 0; gi < p.ngroups; ++gi) {
+        GcPhase& gp = p.grp[gi];
+        gp.tap0 = gi * GC_TG;
+        gp.ntaps = p.ntaps - gp.tap0 < GC_TG ? p.ntaps - gp.tap0 : GC_TG;
+        int dymin = 0, dymax = 0, dxmin = 0, dxmax = 0;
+        for (int t = 0; t < gp.ntaps; ++t) {
+            int dy = p.tap_dy[gp.tap0 + t], dx = p.tap_dx[gp.tap0 + t];
+            if (t == 0) { dymin = dymax = dy; dxmin = dxmax = dx; }
+            if (dy < dymin) dymin = dy; if (dy > dymax) dymax = dy;
+            if (dx < dxmin) dxmin = dx; if (dx > dxmax) dxmax = dx;
+        }
+        gp.dy_min = dymin; gp.dx_min = dxmin;
+        gp.PH = dymax - dymin + 1; gp.PW = dxmax - dxmin + 1;
+        if (gp.PH > span_y) span_y = gp.PH;
+        if (gp.PW > span_x) span_x = gp.PW;
+    }
+    const int fixed = 512 + GC_NPIX * Cfg::PITCH;
+    if (!choose_tile(p.N, p.AH, p.AW, p.ist, span_y, span_x, Cfg::PITCH, fixed, 72 * 1024, p.TH, p.TW, p.NI))
+        return HIFIC_ERR_UNSUPPORTED;
+    if ((p.NI * p.TH * p.TW) % 16 != 0) {   // reduction granule of the bf16 MFMA
+        // tiny planes with tiny batch: widen the (masked) tile instead
+        while ((p.NI * p.TH * p.TW) % 16 != 0) { if (p.TW < 16) p.TW <<= 1; else p.TH <<= 1; }
+    }
+    size_t lds = 0;
+    for (int gi = 0; gi < p.ngroups; ++gi) {
+        GcPhase& gp = p.grp[gi];
+        gp.PH = (p.TH - 1) * p.ist + gp.PH;
+        gp.PW = (p.TW - 1) * p.ist + gp.PW;
+        size_t b = (size_t)fixed + (size_t)p.NI * gp.PH * gp.PW * Cfg::PITCH;
+        if (b > lds) lds = b;
+    }
+    if (lds > (size_t)kLdsBudget) return HIFIC_ERR_UNSUPPORTED;
+    p.tiles_y = cdiv(p.AH, p.TH); p.tiles_x = cdiv(p.AW, p.TW); p.tiles_n = cdiv(p.N, p.NI);
+    p.ntiles = p.tiles_n * p.tiles_y * p.tiles_x;
+    const int base_blocks = (p.Mpad / 64) * (p.Cpad / 64) * p.ngroups;
+    int nsplit = cdiv(768, base_blocks);
+    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    if (nsplit < 1) nsplit = 1;
+    p.tiles_per_split = cdiv(p.ntiles, nsplit);
+    p.nsplit = cdiv(p.ntiles, p.tiles_per_split);
+    const size_t wsb = (size_t)p.nsplit * p.Mpad * p.ntaps * p.Cpad * sizeof(float);
+    p.ws = (float*)ws.take(wsb);
+    if (!p.ws) return HIFIC_ERR_WS;
+    dim3 grid((p.Mpad / 64) * (p.Cpad / 64), p.ngroups, p.nsplit);
+    auto kfn = wgrad_kernel<T>;
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+    int rc = hific_launch_status();
+    if (rc != HIFIC_OK) return rc;
+    long long total = (long long)p.M * p.C * p.ntaps;
+    int gx = (int)((total + 255) / 256); if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(gx), dim3(256), 0, st, p, dw, sm, sc, sr, ss, accumulate);
+    return hific_launch_status();
+}
+
+static int launch_wgrad(WgParams& p, int dtype, float* dw, long long sm, long long sc, long long sr, long long ss,
+                        int accumulate, WsAlloc& ws, hipStream_t st) {
+    if (dtype == HIFIC_F32) { p.a_f32 = 1; p.b_f32 = 1; return launch_wgrad_t<float>(p, dw, sm, sc, sr, ss, accumulate, ws, st); }
+    if (dtype == HIFIC_BF16) return launch_wgrad_t<bf16_t>(p, dw, sm, sc, sr, ss, accumulate, ws, st);
+    return HIFIC_ERR_ARG;
+}
+
+int gc_conv_bwd_weight(const ConvGeom& g, const void* x, const void* dy, float* dw, int accumulate,
+                       int dtype, int x_f32, int dy_f32, WsAlloc& ws, hipStream_t st) {
+    if (g.R * g.S > GC_MAXTAPS) return HIFIC_ERR_UNSUPPORTED;
+    WgParams p; memset(&p, 0, sizeof(p));
+    p.a = dy; p.b = x; p.N = g.N; p.M = g.K; p.C = g.C; p.AH = g.OH(); p.AW = g.OW(); p.BH = g.H; p.BW = g.W;
+    p.ist = g.stride; p.bmode = g.pad_mode; p.a_f32 = dy_f32; p.b_f32 = x_f32;
+    int nt = 0;
+    for (int r = 0; r < g.R; ++r) for (int s = 0; s < g.S; ++s) {
+        p.tap_dy[nt] = (short)(r - g.pt); p.tap_dx[nt] = (short)(s - g.pl); p.tap_r[nt] = (short)r; p.tap_s[nt] = (short)s; ++nt;
+    }
+    p.ntaps = nt;
+    const long long RS = (long long)g.R * g.S;
+    return launch_wgrad(p, dtype, dw, (long long)g.C * RS, RS, g.S, 1, accumulate, ws, st);
+}
+
+int gc_convT_bwd_weight(const ConvTGeom& g, const void* x, const void* dy, float* dw, int accumulate,
+                        int dtype, int x_f32, int dy_f32, WsAlloc& ws, hipStream_t st) {
+    if (g.R * g.S > GC_MAXTAPS) return HIFIC_ERR_UNSUPPORTED;
+    WgParams p; memset(&p, 0, sizeof(p));
+    // dw[ci,co,r,s] = sum x[ci,i] * dOut[co, st*i - pad + r]
+    p.a = x; p.b = dy; p.N = g.N; p.M = g.Ci; p.C = g.Co; p.AH = g.H; p.AW = g.W; p.BH = g.OH(); p.BW = g.OW();
+    p.ist = g.stride; p.bmode = PAD_ZERO; p.a_f32 = x_f32; p.b_f32 = dy_f32;
+    int nt = 0;
+    for (int r = 0; r < g.R; ++r) for (int s = 0; s < g.S; ++s) {
+        p.tap_dy[nt] = (short)(r - g.pad); p.tap_dx[nt] = (short)(s - g.pad); p.tap_r[nt] = (short)r; p.tap_s[nt] = (short)s; ++nt;
+    }
+    p.ntaps = nt;
+    const long long RS = (long long)g.R * g.S;
+    return launch_wgrad(p, dtype, dw, (long long)g.Co * RS, RS, g.S, 1, accumulate, ws, st);
+}
+
+// conservative workspace bound for any op on this layer (packed weights + padded-grad buffer + wgrad partials)
+size_t gc_ws_bytes_conv(const ConvGeom& g, int dtype) {
+    const size_t es = dtype == HIFIC_F32 ? 4 : 2;
+    const size_t kp = (size_t)cdiv(g.K, 128) * 128 + 128, cp = (size_t)cdiv(g.C, 64) * 64 + 64;
+    size_t packed = kp * cp * g.R * g.S * es;
+    size_t padbuf = (size_t)g.N * g.C * (g.H + g.pt + g.pb) * (g.W + g.pl + g.pr) * 4;
+    size_t part = kp * cp * g.R * g.S * 4 * 16;
+    return packed + padbuf + part + 4096;
+}
+size_t gc_ws_bytes_convT(const ConvTGeom& g, int dtype) {
+    const size_t es = dtype == HIFIC_F32 ? 4 : 2;
+    const size_t kp = (size_t)cdiv(g.Co, 128) * 128 + 128, cp = (size_t)cdiv(g.Ci, 64) * 64 + 64;
+    size_t packed = kp * cp * g.R * g.S * es;
+    size_t part = kp * cp * g.R * g.S * 4 * 16;
+    return packed + part + 4096;
+}

@@ -1,0 +1,160 @@
+"""Drop-in for the reference's src/hyperprior.py training/validation path (CodingModel, Hyperprior.forward,
+HyperInfo): same constructor signature, attribute names (`analysis_net`, `synthesis_mu`, `synthesis_std`,
+`hyperlatent_likelihood`, `amortization_models`) and the same order of noise draws from torch's global RNG
+(hyperlatent noise, then latent noise: src/hyperprior.py:283,305).  All arithmetic runs in csrc/entropy.hip.
+
+The EVALUATION-mode methods (compress_forward / decompress_forward, src/hyperprior.py:195-274) hand numpy arrays
+to the host rANS coder and are out of scope for this round."""
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .network import hyper
+from .compression import hyperprior_model
+
+MIN_SCALE = 0.11
+LOG_SCALES_MIN = -3.
+MIN_LIKELIHOOD = 1e-9
+MAX_LIKELIHOOD = 1e3
+SMALL_HYPERLATENT_FILTERS = 192
+LARGE_HYPERLATENT_FILTERS = 320
+
+HyperInfo = namedtuple(
+    "HyperInfo",
+    "decoded "
+    "latent_nbpp hyperlatent_nbpp total_nbpp latent_qbpp hyperlatent_qbpp total_qbpp",
+)
+
+
+def lower_bound_toward(x, bound):
+    return ops.LowerBoundFn.apply(x.contiguous(), bound)
+
+
+class CodingModel(nn.Module):
+    """Entropy estimation pieces of src/hyperprior.py:44-139."""
+
+    def __init__(self, n_channels, min_likelihood=MIN_LIKELIHOOD, max_likelihood=MAX_LIKELIHOOD):
+        super().__init__()
+        self.n_channels = n_channels
+        self.min_likelihood = float(min_likelihood)
+        self.max_likelihood = float(max_likelihood)
+        self.likelihood_logistic = 0
+
+    def _draw_noise(self, x):
+        # same RNG call as the reference (_quantize: torch.nn.init.uniform_(torch.zeros_like(x), -0.5, 0.5))
+        return torch.nn.init.uniform_(torch.zeros_like(x), -0.5, 0.5)
+
+    def _quantize(self, x, mode='noise', means=None):
+        if mode == 'noise':
+            return ops.AddNoiseFn.apply(x.contiguous(), self._draw_noise(x))
+        if mode == 'quantize':
+            return ops.RoundFn.apply(x.contiguous(), None if means is None else means.contiguous())
+        raise NotImplementedError
+
+    def _estimate_entropy(self, likelihood, spatial_shape):
+        EPS = 1e-9
+        quotient = -np.log(2.)
+        batch_size = likelihood.size()[0]
+        assert len(spatial_shape) == 2, 'Mispecified spatial dims'
+        n_pixels = np.prod(spatial_shape)
+        n_bits = ops.LogSumFn.apply(likelihood.contiguous(), EPS, 1.0 / (batch_size * quotient))
+        bpp = n_bits / n_pixels
+        return n_bits, bpp
+
+    def quantize_latents_st(self, inputs, means=None):
+        return ops.RoundSTFn.apply(inputs.contiguous(), None if means is None else means.contiguous())
+
+    def latent_likelihood(self, x, mean, scale):
+        return ops.GaussLikFn.apply(x.contiguous(), mean.contiguous(), scale.contiguous(), self.min_likelihood,
+                                    self.likelihood_logistic)
+
+
+class Hyperprior(CodingModel):
+    def __init__(self, bottleneck_capacity=220, hyperlatent_filters=LARGE_HYPERLATENT_FILTERS, mode='large',
+                 likelihood_type='gaussian', scale_lower_bound=MIN_SCALE, entropy_code=False,
+                 vectorize_encoding=True, block_encode=True):
+        super().__init__(n_channels=bottleneck_capacity)
+        self.bottleneck_capacity = bottleneck_capacity
+        self.scale_lower_bound = scale_lower_bound
+        if mode == 'small':
+            hyperlatent_filters = SMALL_HYPERLATENT_FILTERS
+        self.analysis_net = hyper.HyperpriorAnalysis(C=bottleneck_capacity, N=hyperlatent_filters)
+        self.synthesis_mu = hyper.HyperpriorSynthesis(C=bottleneck_capacity, N=hyperlatent_filters)
+        self.synthesis_std = hyper.HyperpriorSynthesis(C=bottleneck_capacity, N=hyperlatent_filters)
+        self.amortization_models = [self.analysis_net, self.synthesis_mu, self.synthesis_std]
+        self.hyperlatent_likelihood = hyperprior_model.HyperpriorDensity(n_channels=hyperlatent_filters)
+        if likelihood_type == 'gaussian':
+            self.likelihood_logistic = 0
+        elif likelihood_type == 'logistic':
+            self.likelihood_logistic = 1
+        else:
+            raise ValueError('Unknown likelihood model: {}'.format(likelihood_type))
+        if entropy_code is True:
+            raise NotImplementedError(
+                "entropy_code=True builds the host rANS tables (reference src/compression/*): out of scope for the "
+                "MI355X hot path; use the reference's host coder with this module's outputs")
+
+    def compress_forward(self, *a, **k):
+        raise NotImplementedError("host rANS coding path (src/hyperprior.py:195) is out of scope this round")
+
+    def decompress_forward(self, *a, **k):
+        raise NotImplementedError("host rANS coding path (src/hyperprior.py:248) is out of scope this round")
+
+    def forward(self, latents, spatial_shape, **kwargs):
+        if latents.dtype != torch.float32:
+            latents = ops.cast_grad(latents, torch.float32)
+        lat_a, lat_b = ops.fork(latents)
+        lat_c, lat_d = ops.fork(lat_b)
+        lat_e, lat_f = ops.fork(lat_d)
+
+        hyperlatents = self.analysis_net(lat_a)
+        hyp_n, hyp_q = ops.fork(hyperlatents)
+
+        # differential entropy, hyperlatents
+        noisy_hyperlatents = self._quantize(hyp_n, mode='noise')
+        nh_lik, nh_dec = ops.fork(noisy_hyperlatents)
+        noisy_hyperlatent_likelihood = self.hyperlatent_likelihood(nh_lik)
+        _, noisy_hyperlatent_bpp = self._estimate_entropy(noisy_hyperlatent_likelihood, spatial_shape)
+
+        # discrete entropy, hyperlatents
+        quantized_hyperlatents = self._quantize(hyp_q, mode='quantize')
+        qh_lik, qh_dec = ops.fork(quantized_hyperlatents)
+        quantized_hyperlatent_likelihood = self.hyperlatent_likelihood(qh_lik)
+        _, quantized_hyperlatent_bpp = self._estimate_entropy(quantized_hyperlatent_likelihood, spatial_shape)
+
+        hyperlatents_decoded = nh_dec if self.training is True else qh_dec
+        hd_mu, hd_std = ops.fork(hyperlatents_decoded)
+
+        latent_means = self.synthesis_mu(hd_mu)
+        latent_scales = self.synthesis_std(hd_std)
+        latent_scales = lower_bound_toward(latent_scales, self.scale_lower_bound)
+
+        mu_a, mu_b = ops.fork(latent_means)
+        mu_c, mu_d = ops.fork(mu_b)
+        mu_e, mu_f = ops.fork(mu_d)
+        sc_a, sc_b = ops.fork(latent_scales)
+
+        # differential entropy, latents (the reference adds noise to the latents irrespective of `means`)
+        noisy_latents = self._quantize(lat_c, mode='noise', means=mu_a)
+        noisy_latent_likelihood = self.latent_likelihood(noisy_latents, mean=mu_c, scale=sc_a)
+        _, noisy_latent_bpp = self._estimate_entropy(noisy_latent_likelihood, spatial_shape)
+
+        # discrete entropy, latents
+        quantized_latents = self._quantize(lat_e, mode='quantize', means=mu_e)
+        quantized_latent_likelihood = self.latent_likelihood(quantized_latents, mean=mu_f, scale=sc_b)
+        _, quantized_latent_bpp = self._estimate_entropy(quantized_latent_likelihood, spatial_shape)
+
+        latents_decoded = self.quantize_latents_st(lat_f, mu_a)
+
+        return HyperInfo(
+            decoded=latents_decoded,
+            latent_nbpp=noisy_latent_bpp,
+            hyperlatent_nbpp=noisy_hyperlatent_bpp,
+            total_nbpp=noisy_latent_bpp + noisy_hyperlatent_bpp,
+            latent_qbpp=quantized_latent_bpp,
+            hyperlatent_qbpp=quantized_hyperlatent_bpp,
+            total_qbpp=quantized_latent_bpp + quantized_hyperlatent_bpp,
+        )

@@ -1,0 +1,148 @@
+"""ctypes binding of libhific_hip.so (the C-ABI declared in include/hific_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this module raises,
+and every op raises when handed CPU tensors.  PyTorch is used only for device memory, streams and autograd
+bookkeeping; all arithmetic of the hot path runs inside the library.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_float, c_void_p, c_size_t, c_longlong, c_char_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhific_hip.so")
+
+HIFIC_F32, HIFIC_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+_ERR = {0: "ok", -1: "bad argument", -2: "workspace too small", -3: "kernel launch failed", -4: "unsupported shape"}
+
+P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_longlong
+
+# name -> (restype, argtypes)   (kept in the same order as include/hific_hip.h)
+SIGNATURES = {
+    "hific_version": (I, []),
+    "hific_device_info": (I, [I, c_char_p, POINTER(c_int), POINTER(c_int)]),
+    "hific_conv2d_ws_bytes": (Z, [I] * 13),
+    "hific_conv_transpose2d_ws_bytes": (Z, [I] * 11),
+    "hific_conv2d_fwd": (I, [P, P, P, P, P, P] + [I] * 16 + [P, Z, P]),
+    "hific_conv2d_bwd_data": (I, [P, P, P, P] + [I] * 15 + [P, Z, P]),
+    "hific_conv2d_bwd_weight": (I, [P, P, P] + [I] * 16 + [P, Z, P]),
+    "hific_conv_transpose2d_fwd": (I, [P, P, P, P] + [I] * 13 + [P, Z, P]),
+    "hific_conv_transpose2d_bwd_data": (I, [P, P, P] + [I] * 12 + [P, Z, P]),
+    "hific_conv_transpose2d_bwd_weight": (I, [P, P, P] + [I] * 13 + [P, Z, P]),
+    "hific_channelnorm_fwd": (I, [P, P, P, P, P, P, I, I, I, F, I, I, P]),
+    "hific_channelnorm_bwd_ws_bytes": (Z, [I, I, I]),
+    "hific_channelnorm_bwd": (I, [P] * 9 + [I, I, I, I, I, I, P, Z, P]),
+    "hific_act_bwd": (I, [P, P, P, L, F, I, P]),
+    "hific_add": (I, [P, P, P, L, I, P]),
+    "hific_cast": (I, [P, I, P, I, L, P]),
+    "hific_axpby_f32": (I, [P, P, P, F, F, L, P]),
+    "hific_channel_sum": (I, [P, P, I, I, I, I, I, P, Z, P]),
+    "hific_maxpool3s2_fwd": (I, [P, P, L, I, I, I, P]),
+    "hific_maxpool3s2_bwd": (I, [P, P, P, L, I, I, I, P]),
+    "hific_mse_fwd": (I, [P, P, P, L, F, I, P, Z, P]),
+    "hific_mse_bwd": (I, [P, P, P, P, L, F, I, P]),
+    "hific_bce_fwd": (I, [P, F, P, L, P, Z, P]),
+    "hific_bce_bwd": (I, [P, F, P, P, L, I, P]),
+    "hific_sigmoid_f32": (I, [P, P, L, P]),
+    "hific_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
+    "hific_upcat_bwd": (I, [P, P, I, I, P, I, I, I, I, I, I, I, P]),
+    "hific_spectral_norm_fwd": (I, [P, P, P, P, I, I, I, F, P, Z, P]),
+    "hific_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, I, P, Z, P]),
+    "hific_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+    "hific_round_f32": (I, [P, P, P, L, P]),
+    "hific_lower_bound_fwd": (I, [P, F, P, L, P]),
+    "hific_lower_bound_bwd": (I, [P, P, F, P, L, P]),
+    "hific_logsum_fwd": (I, [P, P, L, F, F, P, Z, P]),
+    "hific_logsum_bwd": (I, [P, P, P, L, F, F, I, P]),
+    "hific_gauss_lik_fwd": (I, [P, P, P, P, L, F, I, P]),
+    "hific_gauss_lik_bwd": (I, [P, P, P, P, P, P, P, L, F, I, I, I, P]),
+    "hific_factorized_lik_fwd": (I, [P, POINTER(c_void_p), P, I, I, I, F, P]),
+    "hific_factorized_lik_bwd": (I, [P, POINTER(c_void_p), P, P, POINTER(c_void_p), I, I, I, F, I, P, Z, P]),
+    "hific_lpips_prep": (I, [P, I, P, I, P, I, I, I, I, P]),
+    "hific_lpips_prep_bwd": (I, [P, P, I, I, I, I, I, P]),
+    "hific_lpips_tap_fwd": (I, [P, P, P, I, I, I, I, I, P, Z, P]),
+    "hific_lpips_tap_bwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+}
+
+
+class HificError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the HiFIC hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = _load()
+
+
+def raw(name):
+    return getattr(_lib, name)
+
+
+def call(name, *args):
+    rc = getattr(_lib, name)(*args)
+    if rc != 0:
+        raise HificError(f"{name} failed: {_ERR.get(rc, rc)} (rc={rc})")
+
+
+# ---- torch-side plumbing (device memory, stream) -----------------------------------------------------
+import torch  # noqa: E402
+
+_workspaces = {}
+_WS_BYTES = int(os.environ.get("HIFIC_WS_MB", "1536")) << 20
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return HIFIC_F32
+    if t.dtype == torch.bfloat16:
+        return HIFIC_BF16
+    raise HificError(f"unsupported tensor dtype {t.dtype}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HificError("hific_amd ops need GPU (ROCm) tensors: the HIP library is the only implementation "
+                             "of the hot path (no CPU fallback)")
+        if not t.is_contiguous():
+            raise HificError("hific_amd ops need contiguous NCHW tensors")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(device, min_bytes=0):
+    """Persistent per-device scratch (packed weights, split-K partials, padded-grad buffers).  Re-used by every op:
+    safe because all ops are stream-ordered on the current stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    need = max(_WS_BYTES, min_bytes)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def exported_symbols():
+    return sorted(SIGNATURES)

@@ -1,0 +1,181 @@
+"""Drop-in for the reference's LPIPS perceptual loss as HiFIC uses it
+(src/loss/perceptual_similarity/perceptual_loss.py:13-46 -> dist_model.py:105-113 -> networks_basic.py:61-88,
+model='net-lin', net='alex', version 0.1, spatial=False).
+
+PerceptualLoss.forward(pred, target, normalize) -> (N,1,1,1), differentiable w.r.t. `pred` only (the backbone is
+frozen and the target image carries no gradient on the HiFIC path, src/model.py:196-199).  The whole
+forward/backward is ONE autograd node: both images run through AlexNet as one 2N batch on the gconv kernels, the
+five taps are fused normalise/diff/lin/mean kernels (csrc/lpips.hip), the backward walks the gen half only.
+
+Backbone weights: the reference downloads torchvision's ImageNet AlexNet at run time (pretrained_networks.py:59);
+there is no network here, so the backbone is initialised from a fixed seed unless `load_backbone_state_dict` is
+given real weights (keys `features.{0,3,6,8,10}.{weight,bias}`, torchvision layout).  The learned linear heads are
+the reference's own v0.1 weights (loss/weights/lpips_alex_lin_v0.1.npz, made by tools/extract_lpips_lin.py).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .. import lib, ops
+from ..lib import call, ptr, stream
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# (C_in, C_out, kernel, stride, pad, maxpool-after-relu) of torchvision AlexNet.features up to relu5
+ALEX_CFG = [(3, 64, 11, 4, 2, True), (64, 192, 5, 1, 2, True), (192, 384, 3, 1, 1, False),
+            (384, 256, 3, 1, 1, False), (256, 256, 3, 1, 1, False)]
+ALEX_FEATURE_IDX = [0, 3, 6, 8, 10]
+
+
+def _conv_fwd(x, w, b, stride, pad, cd):
+    N, C, H, W = x.shape
+    K, _, R, S = w.shape
+    OH = (H + 2 * pad - R) // stride + 1
+    OW = (W + 2 * pad - S) // stride + 1
+    y = torch.empty((N, K, OH, OW), dtype=x.dtype, device=x.device)
+    ws = lib.workspace(x.device)
+    call("hific_conv2d_fwd", ptr(x), ptr(w), None, ptr(b), None, ptr(y), N, C, H, W, K, R, S, stride, pad, pad, pad,
+         pad, lib.PAD_ZERO, lib.ACT_RELU, cd, 0, ws.data_ptr(), ws.numel(), stream())
+    return y
+
+
+def _conv_bwd_data(dy, w, xshape, stride, pad, cd):
+    N, C, H, W = xshape
+    K, _, R, S = w.shape
+    dx = torch.empty(xshape, dtype=dy.dtype, device=dy.device)
+    ws = lib.workspace(dy.device)
+    call("hific_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(dx), N, C, H, W, K, R, S, stride, pad, pad, pad, pad,
+         lib.PAD_ZERO, cd, 0, ws.data_ptr(), ws.numel(), stream())
+    return dx
+
+
+def _maxpool(x):
+    N, C, H, W = x.shape
+    OH, OW = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device)
+    call("hific_maxpool3s2_fwd", ptr(x), ptr(y), N * C, H, W, lib.dtype_code(x), stream())
+    return y
+
+
+class LpipsFn(Function):
+    @staticmethod
+    def forward(ctx, pred, target, normalize, lins, *wb):
+        lib.require_gpu(pred, target, *lins, *wb)
+        cdt = ops.get_compute_dtype()
+        cd = lib.HIFIC_F32 if cdt == torch.float32 else lib.HIFIC_BF16
+        B, _, H, W = pred.shape
+        x = torch.empty((2 * B, 3, H, W), dtype=cdt, device=pred.device)
+        # in0 = target, in1 = pred (perceptual_loss.py:40: self.model.forward(target, pred))
+        call("hific_lpips_prep", ptr(target), 1 if target.dtype == torch.float32 else 0, ptr(pred),
+             1 if pred.dtype == torch.float32 else 0, ptr(x), B, H * W, int(normalize), cd, stream())
+        feats, pools = [], []
+        val = torch.empty(B, dtype=torch.float32, device=pred.device)
+        ws = lib.workspace(pred.device)
+        h = x
+        for li, (ci, co, k, s, p, pool) in enumerate(ALEX_CFG):
+            f = _conv_fwd(h, wb[2 * li], wb[2 * li + 1], s, p, cd)
+            feats.append(f)
+            call("hific_lpips_tap_fwd", ptr(f), ptr(lins[li]), ptr(val), B, co, f.shape[2] * f.shape[3],
+                 0 if li == 0 else 1, cd, ws.data_ptr(), ws.numel(), stream())
+            if pool and li < len(ALEX_CFG) - 1:
+                h = _maxpool(f)
+                pools.append(h)
+            else:
+                h = f
+                pools.append(None)
+        ctx.normalize, ctx.cd, ctx.B, ctx.in_shape, ctx.pred_dtype = int(normalize), cd, B, (B, 3, H, W), pred.dtype
+        ctx.lins = lins
+        ctx.save_for_backward(x, *feats, *wb)
+        return val.view(B, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        x, feats, wb = saved[0], saved[1:6], saved[6:]
+        B, cd = ctx.B, ctx.cd
+        gval = g.contiguous().view(B).float()
+        grad = None                        # gradient w.r.t. feats[li][B:] (post-ReLU, gen half)
+        for li in reversed(range(5)):
+            ci, co, k, s, p, pool = ALEX_CFG[li]
+            f = feats[li]
+            fgen = f[B:]
+            if grad is None:
+                grad = torch.empty_like(fgen)
+                acc = 0
+            else:
+                acc = 1
+            call("hific_lpips_tap_bwd", ptr(f), ptr(ctx.lins[li]), ptr(gval), ptr(grad), B, co,
+                 f.shape[2] * f.shape[3], acc, cd, stream())
+            dz = torch.empty_like(grad)
+            call("hific_act_bwd", ptr(grad), ptr(fgen), ptr(dz), grad.numel(), 0.0, lib.dtype_code(grad), stream())
+            # input of conv li: pooled feats[li-1] (li in {1,2}), feats[li-1] (li in {3,4}), or the prepped image
+            if li == 0:
+                in_shape = (B,) + tuple(x.shape[1:])
+            else:
+                prev = feats[li - 1]
+                if ALEX_CFG[li - 1][5]:
+                    in_shape = (B, prev.shape[1], (prev.shape[2] - 3) // 2 + 1, (prev.shape[3] - 3) // 2 + 1)
+                else:
+                    in_shape = (B,) + tuple(prev.shape[1:])
+            din = _conv_bwd_data(dz, wb[2 * li], in_shape, s, p, cd)
+            if li > 0 and ALEX_CFG[li - 1][5]:
+                prev_gen = feats[li - 1][B:]
+                dprev = torch.empty_like(prev_gen)
+                call("hific_maxpool3s2_bwd", ptr(prev_gen), ptr(din), ptr(dprev), B * prev_gen.shape[1],
+                     prev_gen.shape[2], prev_gen.shape[3], lib.dtype_code(prev_gen), stream())
+                grad = dprev
+            else:
+                grad = din
+        # grad is now d/d(prepped gen image) -> d/d pred
+        dpred = torch.empty(ctx.in_shape, dtype=ctx.pred_dtype, device=g.device)
+        # lpips_prep_bwd reads the [2B,...] layout: pass a pointer such that (ptr + half) lands on `grad`
+        half_bytes = grad.numel() * grad.element_size()
+        call("hific_lpips_prep_bwd", grad.data_ptr() - half_bytes, ptr(dpred), B, ctx.in_shape[2] * ctx.in_shape[3],
+             ctx.normalize, cd, 1 if ctx.pred_dtype == torch.float32 else 0, stream())
+        return (dpred, None, None, None) + (None,) * len(wb)
+
+
+class PerceptualLoss(nn.Module):
+    def __init__(self, model='net-lin', net='alex', colorspace='rgb', spatial=False, use_gpu=True, gpu_ids=[0],
+                 version='0.1', backbone_seed=1234):
+        super().__init__()
+        if model != 'net-lin' or net != 'alex' or colorspace != 'rgb' or spatial or version != '0.1':
+            raise NotImplementedError("hific_amd PerceptualLoss implements the configuration HiFIC uses: "
+                                      "model='net-lin', net='alex', colorspace='rgb', spatial=False, version='0.1'")
+        self.use_gpu, self.gpu_ids, self.spatial = use_gpu, gpu_ids, spatial
+        # backbone parameters in torchvision's `features` indexing; frozen like the reference (requires_grad=False)
+        gen = torch.Generator().manual_seed(backbone_seed)
+        feats = {}
+        for idx, (ci, co, k, s, p, _) in zip(ALEX_FEATURE_IDX, ALEX_CFG):
+            conv = nn.Conv2d(ci, co, k, stride=s, padding=p)
+            with torch.no_grad():
+                bound = 1.0 / np.sqrt(ci * k * k)
+                conv.weight.copy_((torch.rand(conv.weight.shape, generator=gen) * 2 - 1) * bound)
+                conv.bias.copy_((torch.rand(conv.bias.shape, generator=gen) * 2 - 1) * bound)
+            feats[str(idx)] = conv
+        self.features = nn.ModuleDict(feats)
+        lin = np.load(os.path.join(_HERE, "weights", "lpips_alex_lin_v0.1.npz"))
+        for i in range(5):
+            self.register_buffer(f"lin{i}", torch.from_numpy(lin[f"lin{i}"].copy()), persistent=False)
+        for prm in self.parameters():
+            prm.requires_grad = False
+
+    def load_backbone_state_dict(self, sd):
+        """Accepts torchvision alexnet keys (`features.N.weight`) or bare `N.weight`."""
+        with torch.no_grad():
+            for idx in ALEX_FEATURE_IDX:
+                for nm in ("weight", "bias"):
+                    key = f"features.{idx}.{nm}" if f"features.{idx}.{nm}" in sd else f"{idx}.{nm}"
+                    getattr(self.features[str(idx)], nm).copy_(sd[key])
+
+    def forward(self, pred, target, normalize=False):
+        if target.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the LPIPS target image is not implemented (not on the HiFIC path)")
+        lins = tuple(getattr(self, f"lin{i}") for i in range(5))
+        wb = []
+        for idx in ALEX_FEATURE_IDX:
+            wb += [self.features[str(idx)].weight, self.features[str(idx)].bias]
+        return LpipsFn.apply(pred.contiguous(), target.contiguous(), normalize, lins, *wb)

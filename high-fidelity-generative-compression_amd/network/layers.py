@@ -1,0 +1,40 @@
+"""Parameter holders that initialise exactly like torch.nn.Conv2d / ConvTranspose2d (same RNG consumption, same
+state_dict keys) but whose forward runs the gfx950 implicit-GEMM kernels (csrc/gconv.hip)."""
+import torch.nn as nn
+
+from .. import ops, lib
+
+
+class HipConv2d(nn.Conv2d):
+    """Conv2d with explicit (top, left, bottom, right) padding of mode 'zeros' | 'reflect' folded into the kernel's
+    tile loader (never materialised), optional fused activation, optional float32 output in bf16 mode."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, pads=(0, 0, 0, 0), pad_mode="zeros",
+                 act=None, out_f32=False, bias=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=0, bias=bias)
+        self.pads = tuple(int(p) for p in pads)
+        self.hip_pad_mode = lib.PAD_REFLECT if pad_mode == "reflect" else lib.PAD_ZERO
+        self.act = act
+        self.out_f32 = out_f32
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], pads=self.pads,
+                          pad_mode=self.hip_pad_mode, act=self.act, out_f32=self.out_f32)
+
+    def extra_repr(self):
+        return super().extra_repr() + f", pads(t,l,b,r)={self.pads}, hip_act={self.act}"
+
+
+class HipConvTranspose2d(nn.ConvTranspose2d):
+    """ConvTranspose2d as stride-phase sub-convolutions (no zero insertion), optional fused activation."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, act=None,
+                 out_f32=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                         output_padding=output_padding)
+        self.act = act
+        self.out_f32 = out_f32
+
+    def forward(self, x):
+        return ops.conv_transpose2d(x, self.weight, self.bias, self.stride[0], self.padding[0],
+                                    self.output_padding[0], act=self.act, out_f32=self.out_f32)

@@ -1,0 +1,598 @@
+"""torch.autograd.Function wrappers over the C-ABI (one Function per reference op call site).
+
+Conventions
+  * activations are contiguous NCHW, float32 (parity mode) or bfloat16 (fast mode); parameters are float32
+  * `cd` = compute dtype code (lib.HIFIC_F32 / lib.HIFIC_BF16); in bf16 mode an op may read f32 inputs or
+    write f32 outputs (flags) so the entropy-model chain stays f32 at the tensor level
+  * nothing here computes with torch ops: torch allocates outputs and records the graph
+"""
+import ctypes
+import torch
+from torch.autograd import Function
+
+from . import lib
+from .lib import call, ptr, stream, workspace, require_gpu, HIFIC_F32, HIFIC_BF16
+
+_compute_dtype = torch.float32
+
+
+def set_compute_dtype(dt):
+    """torch.float32 (parity, f32 MFMA) or torch.bfloat16 (bf16 MFMA, f32 accumulate)."""
+    global _compute_dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _compute_dtype = dt
+
+
+def get_compute_dtype():
+    return _compute_dtype
+
+
+def _cd():
+    return HIFIC_F32 if _compute_dtype == torch.float32 else HIFIC_BF16
+
+
+def _is_f32(t):
+    return 1 if t.dtype == torch.float32 else 0
+
+
+def _ws(t):
+    w = workspace(t.device)
+    return w.data_ptr(), w.numel()
+
+
+def _act_code(act):
+    return {None: lib.ACT_NONE, "none": lib.ACT_NONE, "relu": lib.ACT_RELU, "leaky_relu": lib.ACT_LEAKY}[act]
+
+
+# ------------------------------------------------------------------------------------------------------
+class Conv2dFn(Function):
+    """y = act(conv2d(pad(x)) + b).  geom = (stride, pt, pl, pb, pr, pad_mode)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, act, out_f32, w_scale):
+        require_gpu(x, weight, bias)
+        cd = _cd()
+        stride, pt, pl, pb, pr, pad_mode = geom
+        N, C, H, W = x.shape
+        K, Cw, R, S = weight.shape
+        assert Cw == C, "channel mismatch"
+        OH = (H + pt + pb - R) // stride + 1
+        OW = (W + pl + pr - S) // stride + 1
+        ydt = torch.float32 if (cd == HIFIC_F32 or out_f32) else torch.bfloat16
+        if cd == HIFIC_F32 and x.dtype != torch.float32:
+            raise lib.HificError("float32 compute mode needs float32 activations")
+        y = torch.empty((N, K, OH, OW), dtype=ydt, device=x.device)
+        flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | ((1 if ydt == torch.float32 else 0) << 1 if cd == HIFIC_BF16 else 0)
+        wsp, wsb = _ws(x)
+        call("hific_conv2d_fwd", ptr(x), ptr(weight), ptr(w_scale), ptr(bias), None, ptr(y),
+             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, stream())
+        ctx.geom = geom
+        ctx.act = act
+        ctx.cd = cd
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, w_scale, y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, w_scale, y = ctx.saved_tensors
+        stride, pt, pl, pb, pr, pad_mode = ctx.geom
+        cd = ctx.cd
+        N, C, H, W = x.shape
+        K, _, R, S = weight.shape
+        dy = dy.contiguous()
+        wsp, wsb = _ws(x)
+        if y is not None:
+            dz = torch.empty_like(dy)
+            slope = 0.0 if ctx.act == "relu" else 0.2
+            call("hific_act_bwd", ptr(dy), ptr(y), ptr(dz), dy.numel(), slope, lib.dtype_code(dy), stream())
+            dy = dz
+        dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
+            call("hific_conv2d_bwd_data", ptr(dy), ptr(weight), ptr(w_scale), ptr(dx), N, C, H, W, K, R, S, stride,
+                 pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
+            call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dw), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                 pad_mode, 0, cd, flags, wsp, wsb, stream())
+            # NOTE: with w_scale (spectral norm) dw is the gradient w.r.t. the *scaled* weight; see SpectralNormFn
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(K, dtype=torch.float32, device=x.device)
+            call("hific_channel_sum", ptr(dy), ptr(db), N, K, dy.shape[2] * dy.shape[3], 0, lib.dtype_code(dy),
+                 wsp, wsb, stream())
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias, stride=1, pads=(0, 0, 0, 0), pad_mode=lib.PAD_ZERO, act=None, out_f32=False, w_scale=None):
+    pt, pl, pb, pr = pads
+    return Conv2dFn.apply(x.contiguous(), weight, bias, (stride, pt, pl, pb, pr, pad_mode), act, out_f32, w_scale)
+
+
+class ConvTranspose2dFn(Function):
+    """nn.ConvTranspose2d semantics: weight [Cin, Cout, R, S]; geom = (stride, pad, outpad)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, act, out_f32):
+        require_gpu(x, weight, bias)
+        cd = _cd()
+        stride, pad, outpad = geom
+        N, Ci, H, W = x.shape
+        Ciw, Co, R, S = weight.shape
+        assert Ciw == Ci
+        OH = (H - 1) * stride - 2 * pad + R + outpad
+        OW = (W - 1) * stride - 2 * pad + S + outpad
+        ydt = torch.float32 if (cd == HIFIC_F32 or out_f32) else torch.bfloat16
+        if cd == HIFIC_F32 and x.dtype != torch.float32:
+            raise lib.HificError("float32 compute mode needs float32 activations")
+        y = torch.empty((N, Co, OH, OW), dtype=ydt, device=x.device)
+        flags = 0
+        if cd == HIFIC_BF16:
+            flags = _is_f32(x) | (_is_f32(y) << 1)
+        wsp, wsb = _ws(x)
+        call("hific_conv_transpose2d_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), N, Ci, H, W, Co, R, S, stride, pad,
+             outpad, _act_code(act), cd, flags, wsp, wsb, stream())
+        ctx.geom, ctx.act, ctx.cd, ctx.has_bias = geom, act, cd, bias is not None
+        ctx.save_for_backward(x, weight, y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, outpad = ctx.geom
+        cd = ctx.cd
+        N, Ci, H, W = x.shape
+        _, Co, R, S = weight.shape
+        dy = dy.contiguous()
+        wsp, wsb = _ws(x)
+        if y is not None:
+            dz = torch.empty_like(dy)
+            slope = 0.0 if ctx.act == "relu" else 0.2
+            call("hific_act_bwd", ptr(dy), ptr(y), ptr(dz), dy.numel(), slope, lib.dtype_code(dy), stream())
+            dy = dz
+        dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
+            call("hific_conv_transpose2d_bwd_data", ptr(dy), ptr(weight), ptr(dx), N, Ci, H, W, Co, R, S, stride, pad,
+                 outpad, cd, flags, wsp, wsb, stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
+            call("hific_conv_transpose2d_bwd_weight", ptr(x), ptr(dy), ptr(dw), N, Ci, H, W, Co, R, S, stride, pad,
+                 outpad, 0, cd, flags, wsp, wsb, stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Co, dtype=torch.float32, device=x.device)
+            call("hific_channel_sum", ptr(dy), ptr(db), N, Co, dy.shape[2] * dy.shape[3], 0, lib.dtype_code(dy),
+                 wsp, wsb, stream())
+        return dx, dw, db, None, None, None
+
+
+def conv_transpose2d(x, weight, bias, stride, pad, outpad, act=None, out_f32=False):
+    return ConvTranspose2dFn.apply(x.contiguous(), weight, bias, (stride, pad, outpad), act, out_f32)
+
+
+# ------------------------------------------------------------------------------------------------------
+class ChannelNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        require_gpu(x, gamma, beta)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("hific_channelnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), N, C, H * W,
+             float(eps), int(relu), lib.dtype_code(x), stream())
+        ctx.relu = int(relu)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            raise lib.HificError("ChannelNorm backward: grad dtype mismatch")
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(beta)
+        wsp, wsb = _ws(x)
+        call("hific_channelnorm_bwd", ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dg),
+             ptr(db), N, C, H * W, ctx.relu, 0, lib.dtype_code(x), wsp, wsb, stream())
+        return dx, dg, db, None, None
+
+
+def channel_norm(x, gamma, beta, eps=1e-3, relu=False):
+    return ChannelNormFn.apply(x.contiguous(), gamma, beta, eps, relu)
+
+
+# ------------------------------------------------------------------------------------------------------
+def _add(a, b):
+    o = torch.empty_like(a)
+    call("hific_add", ptr(a), ptr(b), ptr(o), a.numel(), lib.dtype_code(a), stream())
+    return o
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        require_gpu(a, b)
+        assert a.shape == b.shape and a.dtype == b.dtype
+        return _add(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return AddFn.apply(a.contiguous(), b.contiguous())
+
+
+class ForkFn(Function):
+    """Explicit fan-out: returns two aliases of x; backward sums the two incoming gradients with the HIP add kernel
+    (instead of leaving the accumulation to the autograd engine's ATen add)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None:
+            return g2
+        if g2 is None:
+            return g1
+        g1 = g1.contiguous()
+        g2 = g2.contiguous()
+        if g1.dtype != g2.dtype:
+            if g1.dtype == torch.float32:
+                g2 = cast(g2, torch.float32)
+            else:
+                g1 = cast(g1, torch.float32)
+        return _add(g1, g2)
+
+
+def fork(x):
+    return ForkFn.apply(x)
+
+
+def cast(x, dt):
+    """dtype conversion on the HIP side (no autograd)."""
+    require_gpu(x)
+    o = torch.empty(x.shape, dtype=dt, device=x.device)
+    call("hific_cast", ptr(x), lib.dtype_code(x), ptr(o), lib.dtype_code(o), x.numel(), stream())
+    return o
+
+
+class CastFn(Function):
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.src = x.dtype
+        return cast(x.contiguous(), dt)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast(g.contiguous(), ctx.src), None
+
+
+def cast_grad(x, dt):
+    if x.dtype == dt:
+        return x
+    return CastFn.apply(x, dt)
+
+
+# ------------------------------------------------------------------------------------------------------
+# entropy-model ops (all float32)
+class AddNoiseFn(Function):
+    """x + noise (noise drawn by the caller from torch's RNG, like the reference's uniform_)."""
+
+    @staticmethod
+    def forward(ctx, x, noise):
+        require_gpu(x, noise)
+        return _add(x, noise)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class RoundFn(Function):
+    """floor(x - mean + 0.5) + mean (hard quantisation, reference _quantize mode='quantize'): zero gradient to x,
+    identity gradient to mean."""
+
+    @staticmethod
+    def forward(ctx, x, mean):
+        require_gpu(x, mean)
+        o = torch.empty_like(x)
+        call("hific_round_f32", ptr(x), ptr(mean), ptr(o), x.numel(), stream())
+        ctx.has_mean = mean is not None
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, (g if ctx.has_mean else None)
+
+
+class RoundSTFn(Function):
+    """quantize_latents_st: forward = floor(x - mean + .5) + mean, backward: d/dx = 1, d/dmean = 0."""
+
+    @staticmethod
+    def forward(ctx, x, mean):
+        require_gpu(x, mean)
+        o = torch.empty_like(x)
+        call("hific_round_f32", ptr(x), ptr(mean), ptr(o), x.numel(), stream())
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class LowerBoundFn(Function):
+    @staticmethod
+    def forward(ctx, x, bound):
+        require_gpu(x)
+        o = torch.empty_like(x)
+        call("hific_lower_bound_fwd", ptr(x), float(bound), ptr(o), x.numel(), stream())
+        ctx.bound = float(bound)
+        ctx.save_for_backward(x)
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        call("hific_lower_bound_bwd", ptr(x), ptr(g), ctx.bound, ptr(dx), x.numel(), stream())
+        return dx, None
+
+
+class GaussLikFn(Function):
+    """latent_likelihood: max(Phi((.5-|x-m|)/s) - Phi(-(.5+|x-m|)/s), min_lik) with the LowerBoundToward gradient."""
+
+    @staticmethod
+    def forward(ctx, x, mean, scale, min_lik, logistic):
+        require_gpu(x, mean, scale)
+        lik = torch.empty_like(x)
+        call("hific_gauss_lik_fwd", ptr(x), ptr(mean), ptr(scale), ptr(lik), x.numel(), float(min_lik), int(logistic),
+             stream())
+        ctx.min_lik, ctx.logistic = float(min_lik), int(logistic)
+        ctx.save_for_backward(x, mean, scale)
+        return lik
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, scale = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dm = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        ds = torch.empty_like(x) if ctx.needs_input_grad[2] else None
+        call("hific_gauss_lik_bwd", ptr(x), ptr(mean), ptr(scale), ptr(g), ptr(dx), ptr(dm), ptr(ds), x.numel(),
+             ctx.min_lik, ctx.logistic, 0, 0, stream())
+        return dx, dm, ds, None, None
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class FactorizedLikFn(Function):
+    """HyperpriorDensity.likelihood for x [N,C,H,W]; params = H_0..H_3, a_0..a_3, b_0..b_3."""
+
+    @staticmethod
+    def forward(ctx, x, min_lik, *params):
+        require_gpu(x, *params)
+        N, C, H, W = x.shape
+        lik = torch.empty_like(x)
+        call("hific_factorized_lik_fwd", ptr(x), _ptr_array(params), ptr(lik), N, C, H * W, float(min_lik), stream())
+        ctx.min_lik = float(min_lik)
+        ctx.save_for_backward(x, *params)
+        return lik
+
+    @staticmethod
+    def backward(ctx, g):
+        x, *params = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dparams = [torch.empty_like(p) for p in params]
+        wsp, wsb = _ws(x)
+        call("hific_factorized_lik_bwd", ptr(x), _ptr_array(params), ptr(g), ptr(dx), _ptr_array(dparams), N, C, H * W,
+             ctx.min_lik, 0, wsp, wsb, stream())
+        return (dx, None, *dparams)
+
+
+class LogSumFn(Function):
+    """mul * sum(log(p + eps)) -> 0-d tensor (the entropy estimate of src/hyperprior.py:80-93)."""
+
+    @staticmethod
+    def forward(ctx, p, eps, mul):
+        require_gpu(p)
+        out = torch.empty((), dtype=torch.float32, device=p.device)
+        wsp, wsb = _ws(p)
+        call("hific_logsum_fwd", ptr(p), ptr(out), p.numel(), float(eps), float(mul), wsp, wsb, stream())
+        ctx.eps, ctx.mul = float(eps), float(mul)
+        ctx.save_for_backward(p)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        dp = torch.empty_like(p)
+        call("hific_logsum_bwd", ptr(p), ptr(g), ptr(dp), p.numel(), ctx.eps, ctx.mul, 0, stream())
+        return dp, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+class MSEFn(Function):
+    """mean((scale*a - scale*b)^2); a = reconstruction (compute dtype), b = float32 input image (no grad)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        require_gpu(a, b)
+        assert b.dtype == torch.float32 and a.shape == b.shape
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        wsp, wsb = _ws(a)
+        call("hific_mse_fwd", ptr(a), ptr(b), ptr(out), a.numel(), float(scale), lib.dtype_code(a), wsp, wsb, stream())
+        ctx.scale = float(scale)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous().float()
+        da = torch.empty_like(a)
+        call("hific_mse_bwd", ptr(a), ptr(b), ptr(g), ptr(da), a.numel(), ctx.scale, lib.dtype_code(a), stream())
+        return da, None, None
+
+
+class BCELogitsFn(Function):
+    """mean BCE-with-logits of z (float32) against a constant target (ones / zeros)."""
+
+    @staticmethod
+    def forward(ctx, z, target):
+        require_gpu(z)
+        out = torch.empty((), dtype=torch.float32, device=z.device)
+        wsp, wsb = _ws(z)
+        call("hific_bce_fwd", ptr(z), float(target), ptr(out), z.numel(), wsp, wsb, stream())
+        ctx.target = float(target)
+        ctx.save_for_backward(z)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        dz = torch.empty_like(z)
+        call("hific_bce_bwd", ptr(z), ctx.target, ptr(g), ptr(dz), z.numel(), 0, stream())
+        return dz, None
+
+
+def sigmoid(z):
+    require_gpu(z)
+    o = torch.empty_like(z)
+    call("hific_sigmoid_f32", ptr(z), ptr(o), z.numel(), stream())
+    return o
+
+
+class UpsampleConcatFn(Function):
+    """cat([img, nearest_upsample(ctx, f)], dim=1) without materialising the upsampled context separately."""
+
+    @staticmethod
+    def forward(ctx_, img, ctxt, f):
+        require_gpu(img, ctxt)
+        N, Ci, H, W = img.shape
+        Cc = ctxt.shape[1]
+        out = torch.empty((N, Ci + Cc, H, W), dtype=img.dtype, device=img.device)
+        call("hific_upcat_fwd", ptr(img), ptr(ctxt), ptr(out), N, Ci, Cc, H, W, int(f), lib.dtype_code(img), stream())
+        ctx_.dims = (N, Ci, Cc, H, W, int(f))
+        return out
+
+    @staticmethod
+    def backward(ctx_, g):
+        N, Ci, Cc, H, W, f = ctx_.dims
+        g = g.contiguous()
+        dimg = dctx = None
+        if ctx_.needs_input_grad[0]:
+            dimg = torch.empty((N, Ci, H, W), dtype=g.dtype, device=g.device)
+        if ctx_.needs_input_grad[1]:
+            dctx = torch.empty((N, Cc, H // f, W // f), dtype=g.dtype, device=g.device)
+        call("hific_upcat_bwd", ptr(g), ptr(dimg), 0, N if dimg is not None else 0, ptr(dctx), N, Ci, Cc, H, W, f,
+             lib.dtype_code(g), stream())
+        return dimg, dctx, None
+
+
+def spectral_norm_power_iteration(weight_orig, u, v, do_iter, eps=1e-12):
+    """In place on the (u, v) buffers, no autograd (torch.nn.utils.spectral_norm semantics: one iteration per
+    training-mode forward).  Returns a 2-element tensor [sigma, 1/sigma]."""
+    require_gpu(weight_orig, u, v)
+    K = weight_orig.shape[0]
+    M = weight_orig.numel() // K
+    sig = torch.empty(2, dtype=torch.float32, device=weight_orig.device)
+    wsp, wsb = _ws(weight_orig)
+    call("hific_spectral_norm_fwd", ptr(weight_orig), ptr(u), ptr(v), ptr(sig), K, M, int(do_iter), float(eps),
+         wsp, wsb, stream())
+    return sig
+
+
+class SNConv2dFn(Function):
+    """Conv2d with weight = weight_orig / sigma(u, v).  `sig` = [sigma, 1/sigma] from the power iteration; (u, v)
+    are the post-iteration buffers (treated as constants, as in torch's spectral_norm)."""
+
+    @staticmethod
+    def forward(ctx, x, weight_orig, bias, u, v, sig, geom, act, out_f32):
+        require_gpu(x, weight_orig, bias, u, v, sig)
+        cd = _cd()
+        stride, pt, pl, pb, pr, pad_mode = geom
+        N, C, H, W = x.shape
+        K, _, R, S = weight_orig.shape
+        OH = (H + pt + pb - R) // stride + 1
+        OW = (W + pl + pr - S) // stride + 1
+        ydt = torch.float32 if (cd == HIFIC_F32 or out_f32) else torch.bfloat16
+        y = torch.empty((N, K, OH, OW), dtype=ydt, device=x.device)
+        flags = 0
+        if cd == HIFIC_BF16:
+            flags = _is_f32(x) | (_is_f32(y) << 1)
+        wsp, wsb = _ws(x)
+        inv_sigma = sig[1:]
+        call("hific_conv2d_fwd", ptr(x), ptr(weight_orig), ptr(inv_sigma), ptr(bias), None, ptr(y),
+             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, stream())
+        ctx.geom, ctx.act, ctx.cd = geom, act, cd
+        ctx.save_for_backward(x, weight_orig, u.clone(), v.clone(), sig, y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight_orig, u, v, sig, y = ctx.saved_tensors
+        stride, pt, pl, pb, pr, pad_mode = ctx.geom
+        cd = ctx.cd
+        N, C, H, W = x.shape
+        K, _, R, S = weight_orig.shape
+        dy = dy.contiguous()
+        wsp, wsb = _ws(x)
+        if y is not None:
+            dz = torch.empty_like(dy)
+            slope = 0.0 if ctx.act == "relu" else 0.2
+            call("hific_act_bwd", ptr(dy), ptr(y), ptr(dz), dy.numel(), slope, lib.dtype_code(dy), stream())
+            dy = dz
+        dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
+        inv_sigma = sig[1:]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
+            call("hific_conv2d_bwd_data", ptr(dy), ptr(weight_orig), ptr(inv_sigma), ptr(dx), N, C, H, W, K, R, S,
+                 stride, pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, stream())
+        if ctx.needs_input_grad[1]:
+            dws = torch.empty_like(weight_orig)       # gradient w.r.t. the normalised weight
+            flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
+            call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dws), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                 pad_mode, 0, cd, flags, wsp, wsb, stream())
+            dw = torch.empty_like(weight_orig)
+            M = weight_orig.numel() // K
+            call("hific_spectral_norm_bwd", ptr(dws), ptr(weight_orig), ptr(u), ptr(v), ptr(sig), ptr(dw), K, M, 0,
+                 wsp, wsb, stream())
+        if ctx.needs_input_grad[2]:
+            db = torch.empty(K, dtype=torch.float32, device=x.device)
+            call("hific_channel_sum", ptr(dy), ptr(db), N, K, dy.shape[2] * dy.shape[3], 0, lib.dtype_code(dy),
+                 wsp, wsb, stream())
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    require_gpu(p, g, m, v)
+    call("hific_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), int(step), float(grad_scale), stream())

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """Make sure libhific_hip.so exists (cross-compiles on CPU-only hosts)."""
+    import __graft_entry__ as g
+    so = os.path.join(g.PKG, "libhific_hip.so")
+    if not os.path.exists(so):
+        g.build()
+    return so
+
+
+@pytest.fixture(scope="session")
+def hific(built_lib):
+    import hific_amd
+    return hific_amd
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,148 @@
+"""GPU parity of the convolution engine (csrc/gconv.hip) through the C-ABI: forward, data-gradient and
+weight-gradient of every conv / conv-transpose geometry on the HiFIC hot path, against torch CPU float32 ops
+(the arithmetic the reference executes: nn.Conv2d / nn.ConvTranspose2d / ReflectionPad2d).
+Tolerances: float32 mode 2e-4 of the output scale (f32 MFMA is an exact fma chain; only the summation order
+differs from oneDNN); bf16 mode 2e-2 (inputs are pre-rounded to bf16 on both sides, f32 accumulate)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# name: (N, C, H, W, K, R, stride, (pt, pl, pb, pr), mode)
+CONV_CASES = {
+    "E1_7x7_reflect3":      (2, 3, 64, 64, 60, 7, 1, (3, 3, 3, 3), "reflect"),
+    "E2_3x3s2_asym":        (2, 60, 64, 64, 120, 3, 2, (1, 0, 0, 1), "reflect"),
+    "E5_3x3s2_asym_480":    (2, 480, 32, 32, 960, 3, 2, (1, 0, 0, 1), "reflect"),
+    "R_3x3_960":            (2, 960, 16, 16, 960, 3, 1, (1, 1, 1, 1), "reflect"),
+    "E6_960_220":           (2, 960, 16, 16, 220, 3, 1, (1, 1, 1, 1), "reflect"),
+    "A1_zero":              (2, 220, 16, 16, 320, 3, 1, (1, 1, 1, 1), "zeros"),
+    "A2_5x5s2_reflect2":    (2, 320, 16, 16, 320, 5, 2, (2, 2, 2, 2), "reflect"),
+    "A3_5x5s2_8x8":         (3, 320, 8, 8, 320, 5, 2, (2, 2, 2, 2), "reflect"),
+    "G9_7x7_to3":           (2, 60, 64, 64, 3, 7, 1, (3, 3, 3, 3), "reflect"),
+    "D1_4x4s2":             (2, 15, 64, 64, 64, 4, 2, (1, 1, 1, 1), "reflect"),
+    "D4_4x4s2_256_512":     (2, 256, 32, 32, 512, 4, 2, (1, 1, 1, 1), "reflect"),
+    "D5_1x1_to1":           (2, 512, 16, 16, 1, 1, 1, (0, 0, 0, 0), "zeros"),
+    "L1_11x11s4":           (2, 3, 128, 128, 64, 11, 4, (2, 2, 2, 2), "zeros"),
+    "L2_5x5":               (2, 64, 31, 31, 192, 5, 1, (2, 2, 2, 2), "zeros"),
+    "L3_3x3_15":            (2, 192, 15, 15, 384, 3, 1, (1, 1, 1, 1), "zeros"),
+    "odd_sizes":            (1, 5, 13, 17, 7, 3, 1, (1, 1, 1, 1), "reflect"),
+    "odd_s2":               (3, 9, 11, 10, 33, 3, 2, (1, 1, 1, 1), "zeros"),
+}
+# name: (N, Ci, H, W, Co, R, stride, pad, outpad)
+CONVT_CASES = {
+    "U1_960_480":  (2, 960, 16, 16, 480, 3, 2, 1, 1),
+    "U4_120_60":   (2, 120, 32, 32, 60, 3, 2, 1, 1),
+    "S1_5x5s2":    (2, 320, 4, 4, 320, 5, 2, 2, 1),
+    "S2_5x5s2_8":  (3, 320, 8, 8, 320, 5, 2, 2, 1),
+    "S3_3x3s1":    (2, 320, 16, 16, 220, 3, 1, 1, 0),
+    "odd":         (1, 7, 5, 6, 9, 3, 2, 1, 1),
+}
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2e-2}
+
+
+def _rnd(shape, seed, dt):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.rand(shape, generator=g) * 2 - 1
+    return t.to(dt).float() if dt == torch.bfloat16 else t
+
+
+def _relerr(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-20)
+
+
+def _ref_conv(x, w, b, stride, pads, mode):
+    pt, pl, pb, pr = pads
+    xp = F.pad(x, (pl, pr, pt, pb), mode="reflect" if mode == "reflect" else "constant")
+    return F.conv2d(xp, w, b, stride=stride)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv2d_fwd_bwd(hific, dev, name, dt):
+    from hific_amd import ops, lib
+    N, C, H, W, K, R, stride, pads, mode = CONV_CASES[name]
+    hific.set_compute_dtype(dt)
+    x = _rnd((N, C, H, W), 1, dt)
+    w = _rnd((K, C, R, R), 2, dt) * (1.0 / (C * R * R) ** 0.5)
+    w = w.to(dt).float() if dt == torch.bfloat16 else w
+    b = _rnd((K,), 3, torch.float32) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = _ref_conv(xr, wr, br, stride, pads, mode)
+    gy = _rnd(tuple(yr.shape), 4, dt)
+    yr.backward(gy)
+
+    xd = x.to(dev).to(dt).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    pm = lib.PAD_REFLECT if mode == "reflect" else lib.PAD_ZERO
+    y = ops.conv2d(xd, wd, bd, stride=stride, pads=pads, pad_mode=pm)
+    assert y.shape == yr.shape and y.dtype == dt
+    y.backward(gy.to(dev).to(dt))
+    torch.cuda.synchronize()
+    tol = TOL[dt]
+    e_y = _relerr(y.detach().float().cpu(), yr.detach())
+    e_dx = _relerr(xd.grad.float().cpu(), xr.grad)
+    e_dw = _relerr(wd.grad.cpu(), wr.grad)
+    e_db = _relerr(bd.grad.cpu(), br.grad)
+    print(f"{name} {dt}: y {e_y:.2e} dx {e_dx:.2e} dw {e_dw:.2e} db {e_db:.2e}")
+    assert e_y < tol, f"fwd {e_y}"
+    assert e_dx < tol, f"bwd_data {e_dx}"
+    assert e_dw < tol, f"bwd_weight {e_dw}"
+    assert e_db < tol, f"bias grad {e_db}"
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CONVT_CASES))
+def test_conv_transpose2d_fwd_bwd(hific, dev, name, dt):
+    from hific_amd import ops
+    N, Ci, H, W, Co, R, stride, pad, outpad = CONVT_CASES[name]
+    hific.set_compute_dtype(dt)
+    x = _rnd((N, Ci, H, W), 1, dt)
+    w = _rnd((Ci, Co, R, R), 2, dt) * (1.0 / (Ci * R * R) ** 0.5)
+    w = w.to(dt).float() if dt == torch.bfloat16 else w
+    b = _rnd((Co,), 3, torch.float32) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, br, stride=stride, padding=pad, output_padding=outpad)
+    gy = _rnd(tuple(yr.shape), 4, dt)
+    yr.backward(gy)
+    xd = x.to(dev).to(dt).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    y = ops.conv_transpose2d(xd, wd, bd, stride, pad, outpad)
+    assert y.shape == yr.shape
+    y.backward(gy.to(dev).to(dt))
+    torch.cuda.synchronize()
+    tol = TOL[dt]
+    e_y = _relerr(y.detach().float().cpu(), yr.detach())
+    e_dx = _relerr(xd.grad.float().cpu(), xr.grad)
+    e_dw = _relerr(wd.grad.cpu(), wr.grad)
+    e_db = _relerr(bd.grad.cpu(), br.grad)
+    print(f"{name} {dt}: y {e_y:.2e} dx {e_dx:.2e} dw {e_dw:.2e} db {e_db:.2e}")
+    assert e_y < tol and e_dx < tol and e_dw < tol and e_db < tol, (e_y, e_dx, e_dw, e_db)
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky_relu"])
+def test_conv_fused_activation_and_mixed_io(hific, dev, act):
+    """bf16 compute with float32 input and float32 output (the entropy-model boundary) + fused activation."""
+    from hific_amd import ops, lib
+    hific.set_compute_dtype(torch.bfloat16)
+    x = _rnd((2, 24, 16, 16), 1, torch.bfloat16)
+    w = _rnd((40, 24, 3, 3), 2, torch.bfloat16) * 0.1
+    w = w.to(torch.bfloat16).float()
+    b = _rnd((40,), 3, torch.float32) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    z = _ref_conv(xr, wr, b, 1, (1, 1, 1, 1), "zeros")
+    yr = F.relu(z) if act == "relu" else F.leaky_relu(z, 0.2)
+    gy = _rnd(tuple(yr.shape), 4, torch.float32)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_(True)           # float32 activations into a bf16-compute conv
+    wd = w.to(dev).requires_grad_(True)
+    y = ops.conv2d(xd, wd, b.to(dev), 1, (1, 1, 1, 1), lib.PAD_ZERO, act=act, out_f32=True)
+    assert y.dtype == torch.float32
+    y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    assert _relerr(y.detach().cpu(), yr.detach()) < 2e-2
+    assert _relerr(xd.grad.cpu(), xr.grad) < 3e-2
+    assert _relerr(wd.grad.cpu(), wr.grad) < 3e-2

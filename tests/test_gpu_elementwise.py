@@ -1,0 +1,228 @@
+"""GPU parity of the HBM-bound kernels (norm / entropy model / LPIPS taps / pooling / losses / Adam / spectral norm)
+against torch CPU float32 restatements of the reference ops (oracle/hific_oracle.py primitives)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hific_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+def _relerr(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-20)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape,relu", [((2, 60, 24, 24), True), ((2, 960, 16, 16), False), ((3, 220, 5, 7), True)])
+def test_channelnorm(hific, dev, shape, relu, dt, tol):
+    from hific_amd import ops
+    x = _rnd(shape, 1, -2, 2)
+    if dt == torch.bfloat16:
+        x = x.to(dt).float()
+    C = shape[1]
+    gamma = _rnd((1, C, 1, 1), 2, 0.5, 1.5)
+    beta = _rnd((1, C, 1, 1), 3, -0.3, 0.3)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = O.channel_norm(xr, gr, br)
+    if relu:
+        yr = F.relu(yr)
+    gy = _rnd(shape, 4)
+    if dt == torch.bfloat16:
+        gy = gy.to(dt).float()
+    yr.backward(gy)
+    xd = x.to(dev).to(dt).requires_grad_(True)
+    gd, bd = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    y = ops.channel_norm(xd, gd, bd, 1e-3, relu=relu)
+    y.backward(gy.to(dev).to(dt))
+    torch.cuda.synchronize()
+    assert _relerr(y.detach().float().cpu(), yr.detach()) < tol
+    assert _relerr(xd.grad.float().cpu(), xr.grad) < tol * 3
+    assert _relerr(gd.grad.cpu(), gr.grad) < tol * 3
+    assert _relerr(bd.grad.cpu(), br.grad) < tol * 3
+
+
+def test_factorized_likelihood(hific, dev):
+    from hific_amd import ops
+    N, C, H, W = 3, 20, 4, 4
+    sd = {k: v for k, v in O.make_state_dict(seed=5, C=12, N=C, n_res=0, gan=False).items()
+          if "hyperlatent_likelihood" in k}
+    pref = "Hyperprior.hyperlatent_likelihood."
+    z = _rnd((N, C, H, W), 7, -4, 4)
+    z[0, 0, 0, 0] = 40.0       # deep tail -> lower-bounded likelihood, exercises the LowerBoundToward gate
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    zr = z.clone().requires_grad_(True)
+    lik_r = O.factorized_likelihood(sdr, zr, pref)
+    gl = _rnd((N, C, H, W), 8)
+    lik_r.backward(gl)
+    params = [sd[pref + f"{n}_{k}"].to(dev).requires_grad_(True) for n in ("H", "a", "b") for k in range(4)]
+    zd = z.to(dev).requires_grad_(True)
+    lik = ops.FactorizedLikFn.apply(zd, 1e-9, *params)
+    lik.backward(gl.to(dev))
+    torch.cuda.synchronize()
+    assert _relerr(lik.detach().cpu(), lik_r.detach()) < 1e-4
+    assert _relerr(zd.grad.cpu(), zr.grad) < 1e-3
+    i = 0
+    for n in ("H", "a", "b"):
+        for k in range(4):
+            assert _relerr(params[i].grad.cpu(), sdr[pref + f"{n}_{k}"].grad) < 2e-3, (n, k)
+            i += 1
+
+
+@pytest.mark.parametrize("ltype", ["gaussian", "logistic"])
+def test_latent_likelihood_and_entropy(hific, dev, ltype):
+    from hific_amd import ops
+    shape = (2, 22, 8, 8)
+    x = _rnd(shape, 1, -6, 6)
+    mean = _rnd(shape, 2, -2, 2)
+    raw = _rnd(shape, 3, -0.5, 2.0)       # part below the 0.11 bound
+    xr, mr, rr = (t.clone().requires_grad_(True) for t in (x, mean, raw))
+    sc_r = O.lower_bound_toward(rr, 0.11)
+    lik_r = O.latent_likelihood(xr, mr, sc_r, ltype)
+    _, bpp_r = O.estimate_entropy(lik_r, (128, 128))
+    bpp_r.backward()
+    xd, md, rd = (t.to(dev).requires_grad_(True) for t in (x, mean, raw))
+    sc = ops.LowerBoundFn.apply(rd, 0.11)
+    lik = ops.GaussLikFn.apply(xd, md, sc, 1e-9, 1 if ltype == "logistic" else 0)
+    nbits = ops.LogSumFn.apply(lik, 1e-9, 1.0 / (shape[0] * -math.log(2.0)))
+    bpp = nbits / (128 * 128)
+    bpp.backward()
+    torch.cuda.synchronize()
+    assert _relerr(lik.detach().cpu(), lik_r.detach()) < 1e-4
+    assert abs(float(bpp) - float(bpp_r)) < 1e-4 * abs(float(bpp_r))
+    assert _relerr(xd.grad.cpu(), xr.grad) < 2e-3
+    assert _relerr(md.grad.cpu(), mr.grad) < 2e-3
+    assert _relerr(rd.grad.cpu(), rr.grad) < 2e-3
+
+
+def test_round_ops_bit_exact(hific, dev):
+    from hific_amd import ops
+    x = _rnd((2, 22, 8, 8), 1, -8, 8)
+    m = _rnd((2, 22, 8, 8), 2, -1, 1)
+    q = ops.RoundFn.apply(x.to(dev), m.to(dev)).cpu()
+    assert torch.equal(q, torch.floor(x - m + 0.5) + m)
+    q0 = ops.RoundFn.apply(x.to(dev), None).cpu()
+    assert torch.equal(q0, torch.floor(x + 0.5))
+    xd = x.to(dev).requires_grad_(True)
+    md = m.to(dev).requires_grad_(True)
+    st = ops.RoundSTFn.apply(xd, md)
+    st.sum().backward()
+    assert torch.equal(st.detach().cpu(), torch.floor(x - m + 0.5) + m)
+    assert torch.equal(xd.grad.cpu(), torch.ones_like(x)) and md.grad is None
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)], ids=["f32", "bf16"])
+def test_lpips_forward_backward(hific, dev, dt, tol):
+    from hific_amd.loss.perceptual_loss import PerceptualLoss
+    hific.set_compute_dtype(dt)
+    B, H = 2, 96
+    bb = O.make_alex_backbone()
+    pl = PerceptualLoss().to(dev)
+    pl.load_backbone_state_dict(bb)
+    lins = [getattr(pl, f"lin{i}").cpu() for i in range(5)]
+    target = O.make_image(3, B, H, H)
+    pred = (target + 0.1 * _rnd((B, 3, H, H), 5)).clamp(0, 1)
+    pr = pred.clone().requires_grad_(True)
+    vr = O.lpips_forward(bb, lins, pr, target, normalize=True)
+    vr.mean().backward()
+    pd = pred.to(dev).to(dt).requires_grad_(True)
+    v = pl(pd, target.to(dev), normalize=True)
+    v.mean().backward()
+    torch.cuda.synchronize()
+    assert v.shape == (B, 1, 1, 1)
+    assert _relerr(v.detach().cpu(), vr.detach()) < tol
+    assert _relerr(pd.grad.float().cpu(), pr.grad) < max(tol * 5, 1e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_maxpool_fwd_bwd(hific, dev, dt):
+    from hific_amd import lib
+    x = F.relu(_rnd((2, 5, 15, 31), 1))
+    x = x.to(dt).float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2)
+    gy = _rnd(tuple(yr.shape), 2).to(dt).float()
+    yr.backward(gy)
+    xd = x.to(dev).to(dt)
+    y = torch.empty(yr.shape, dtype=dt, device=dev)
+    lib.call("hific_maxpool3s2_fwd", xd.data_ptr(), y.data_ptr(), 10, 15, 31, lib.dtype_code(xd), lib.stream())
+    dx = torch.empty_like(xd)
+    gyd = gy.to(dev).to(dt)
+    lib.call("hific_maxpool3s2_bwd", xd.data_ptr(), gyd.data_ptr(), dx.data_ptr(), 10, 15, 31, lib.dtype_code(xd),
+             lib.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y.float().cpu(), yr.detach())
+    assert _relerr(dx.float().cpu(), xr.grad) < (1e-6 if dt == torch.float32 else 1e-2)
+
+
+def test_mse_and_bce(hific, dev):
+    from hific_amd import ops
+    a = _rnd((2, 3, 32, 32), 1, 0, 1)
+    b = _rnd((2, 3, 32, 32), 2, 0, 1)
+    ar = a.clone().requires_grad_(True)
+    lr = torch.mean((ar * 255. - b * 255.) ** 2)
+    lr.backward()
+    ad = a.to(dev).requires_grad_(True)
+    l = ops.MSEFn.apply(ad, b.to(dev), 255.0)
+    l.backward()
+    assert abs(float(l) - float(lr)) < 1e-5 * float(lr)
+    assert _relerr(ad.grad.cpu(), ar.grad) < 1e-5
+    z = _rnd((512,), 3, -5, 5)
+    for target in (0.0, 1.0):
+        zr = z.clone().requires_grad_(True)
+        lr = F.binary_cross_entropy_with_logits(zr, torch.full_like(zr, target))
+        lr.backward()
+        zd = z.to(dev).requires_grad_(True)
+        l = ops.BCELogitsFn.apply(zd, target)
+        l.backward()
+        assert abs(float(l) - float(lr)) < 1e-5 * abs(float(lr))
+        assert _relerr(zd.grad.cpu(), zr.grad) < 1e-5
+
+
+def test_adam_matches_torch(hific, dev):
+    from hific_amd import ops
+    p0 = _rnd((1000,), 1)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-4)
+    p = p0.to(dev)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for step in range(1, 4):
+        g = _rnd((1000,), 10 + step)
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g.to(dev), m, v, 1e-4, 0.9, 0.999, 1e-8, step)
+    torch.cuda.synchronize()
+    assert (p.cpu() - ref.detach()).abs().max().item() < 1e-7
+
+
+def test_spectral_norm_and_upcat(hific, dev):
+    from hific_amd import ops
+    w = _rnd((8, 5, 4, 4), 1)
+    u = F.normalize(_rnd((8,), 2), dim=0)
+    v = F.normalize(_rnd((80,), 3), dim=0)
+    wn_r, u_r, v_r = O.spectral_norm_weight(w, u, v, training=True)
+    ud, vd = u.to(dev).clone(), v.to(dev).clone()
+    sig = ops.spectral_norm_power_iteration(w.to(dev), ud, vd, do_iter=True)
+    torch.cuda.synchronize()
+    assert _relerr(ud.cpu(), u_r) < 1e-5 and _relerr(vd.cpu(), v_r) < 1e-5
+    assert _relerr(w / sig[0].cpu(), wn_r) < 1e-5
+    img = _rnd((2, 3, 32, 32), 4)
+    ctx = _rnd((2, 4, 2, 2), 5)
+    ir, cr = img.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    outr = torch.cat((ir, F.interpolate(cr, scale_factor=16, mode="nearest")), dim=1)
+    g = _rnd(tuple(outr.shape), 6)
+    outr.backward(g)
+    idv, cdv = img.to(dev).requires_grad_(True), ctx.to(dev).requires_grad_(True)
+    out = ops.UpsampleConcatFn.apply(idv, cdv, 16)
+    out.backward(g.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(out.detach().cpu(), outr.detach())
+    assert _relerr(idv.grad.cpu(), ir.grad) < 1e-6 and _relerr(cdv.grad.cpu(), cr.grad) < 1e-5
