@@ -64,7 +64,7 @@ __device__ __forceinline__ float std_cdf(float t, int logistic) {
     return logistic ? sigmoid_t(t) : 0.5f * erfcf(t * -0.70710678118654752440f);
 }
 __device__ __forceinline__ float std_pdf(float t, int logistic) {
-    if (logistic) { const float s = sigmoid_t(t); return s * (1.f - s); }
+    if (logistic) { const float s = sigmoid_t(-fabsf(t)); return s * (1.f - s); }   // small-side sigmoid: no 1-s cancellation
     return 0.39894228040143267794f * expf(-0.5f * t * t);
 }
 __global__ void gauss_lik_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,

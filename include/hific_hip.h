@@ -1,0 +1,165 @@
+/* libhific_hip.so — C-ABI of the MI355X (gfx950) HiFIC hot path.
+ *
+ * Drop-in boundary.  The reference (Justin-Tan/high-fidelity-generative-compression) has no FFI: its hot path is
+ * a chain of torch.nn modules whose arithmetic runs in ATen/cuDNN.  This library replaces exactly that arithmetic.
+ * Every entry point below names the reference call site (file:line under /root/reference) whose tensor op it
+ * replaces; the Python binding (hific_amd/lib.py, ctypes) is the "reference-side stub" (see INTEGRATION.md).
+ *
+ * Contract (all functions):
+ *   - plain pointers and sizes only; every buffer is DEVICE memory owned by the caller (workspace included);
+ *     the library never allocates, never synchronises, never throws; it enqueues kernels on `stream` and returns
+ *   - return value: 0 ok, -1 bad argument, -2 workspace too small, -3 launch failed, -4 unsupported shape
+ *   - tensors are contiguous NCHW; `dtype` is the compute/storage type of activations:
+ *       HIFIC_F32 (0)  float32 storage, v_mfma_f32_32x32x2_f32   (parity mode: exact f32 fma chains)
+ *       HIFIC_BF16 (1) bfloat16 storage, v_mfma_f32_32x32x16_bf16 (f32 accumulate)
+ *     weights, biases, norm parameters, statistics, losses and all gradients of parameters are float32
+ *   - `flags` on conv entry points, meaningful for HIFIC_BF16 only: bit0 = the input activation tensor is float32,
+ *     bit1 = the output activation tensor is float32 (entropy-model boundary stays float32)
+ *   - thread-safe for distinct streams as long as the workspaces are distinct
+ */
+#ifndef HIFIC_HIP_H
+#define HIFIC_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+#define HIFIC_F32 0
+#define HIFIC_BF16 1
+#define HIFIC_ACT_NONE 0
+#define HIFIC_ACT_RELU 1
+#define HIFIC_ACT_LEAKY 2   /* LeakyReLU(0.2), src/network/discriminator.py:44 */
+#define HIFIC_PAD_ZERO 0
+#define HIFIC_PAD_REFLECT 1 /* nn.ReflectionPad2d / padding_mode='reflect' */
+
+int hific_version(void);
+int hific_device_info(int device, char* name64, int* cus, int* lds_per_cu);
+
+/* ---- convolutions (csrc/gconv.hip) ------------------------------------------------------------------------
+ * Replaces nn.Conv2d (+ the nn.ReflectionPad2d in front of it, + the activation behind it):
+ *   src/network/encoder.py:56-101, src/network/generator.py:28-29,98-103,139-142, src/network/hyper.py:52-54,
+ *   src/network/discriminator.py:35,53-64, torchvision AlexNet features used at
+ *   src/loss/perceptual_similarity/pretrained_networks.py:59-75.
+ * x [N,C,H,W], w f32 [K,C,R,S], bias f32 [K] or NULL, y [N,K,OH,OW], OH=(H+pt+pb-R)/stride+1.
+ * w_scale: NULL or device pointer to one float multiplied into w while packing (1/sigma of spectral norm).
+ * resid: NULL or tensor shaped like y added before the activation. */
+size_t hific_conv2d_ws_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb,
+                             int pr, int dtype);
+int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const float* bias, const void* resid,
+                     void* y, int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb,
+                     int pr, int pad_mode, int act, int dtype, int flags, void* ws, size_t ws_bytes,
+                     hipStream_t stream);
+/* adjoint w.r.t. x (autograd of the above; includes the reflection-pad adjoint). flags: bit0 dy f32, bit1 dx f32 */
+int hific_conv2d_bwd_data(const void* dy, const float* w, const float* w_scale, void* dx, int N, int C, int H,
+                          int W, int K, int R, int S, int stride, int pt, int pl, int pb, int pr, int pad_mode,
+                          int dtype, int flags, void* ws, size_t ws_bytes, hipStream_t stream);
+/* dw f32 [K,C,R,S] (= or += when accumulate). flags: bit0 x f32, bit1 dy f32 */
+int hific_conv2d_bwd_weight(const void* x, const void* dy, float* dw, int N, int C, int H, int W, int K, int R,
+                            int S, int stride, int pt, int pl, int pb, int pr, int pad_mode, int accumulate,
+                            int dtype, int flags, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* Replaces nn.ConvTranspose2d: src/network/generator.py:115-137 (k3 s2 p1 op1), src/network/hyper.py:83-85
+ * (k5 s2 p2 op1, k3 s1 p1).  x [N,Ci,H,W], w f32 [Ci,Co,R,S], y [N,Co,OH,OW]. */
+size_t hific_conv_transpose2d_ws_bytes(int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad,
+                                       int outpad, int dtype);
+int hific_conv_transpose2d_fwd(const void* x, const float* w, const float* bias, void* y, int N, int Ci, int H,
+                               int W, int Co, int R, int S, int stride, int pad, int outpad, int act, int dtype,
+                               int flags, void* ws, size_t ws_bytes, hipStream_t stream);
+int hific_conv_transpose2d_bwd_data(const void* dy, const float* w, void* dx, int N, int Ci, int H, int W, int Co,
+                                    int R, int S, int stride, int pad, int outpad, int dtype, int flags, void* ws,
+                                    size_t ws_bytes, hipStream_t stream);
+int hific_conv_transpose2d_bwd_weight(const void* x, const void* dy, float* dw, int N, int Ci, int H, int W,
+                                      int Co, int R, int S, int stride, int pad, int outpad, int accumulate,
+                                      int dtype, int flags, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* ---- ChannelNorm2D (csrc/norm.hip) — src/normalisation/channel.py:48-59 (+ the ReLU after it) ------------- */
+int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                          int N, int C, int HW, float eps, int relu, int dtype, hipStream_t stream);
+size_t hific_channelnorm_bwd_ws_bytes(int N, int C, int HW);
+int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* mean,
+                          const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int C, int HW, int relu,
+                          int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* ---- elementwise / reductions (csrc/elementwise.hip) -------------------------------------------------------- */
+/* dx = y>0 ? dy : slope*dy — backward of F.relu (src/network/hyper.py:59-60,91-92) / LeakyReLU */
+int hific_act_bwd(const void* dy, const void* y, void* dx, long long n, float slope, int dtype, hipStream_t stream);
+/* residual adds: src/network/generator.py:44,161; also gradient fan-in sums */
+int hific_add(const void* a, const void* b, void* o, long long n, int dtype, hipStream_t stream);
+int hific_cast(const void* a, int src_dtype, void* o, int dst_dtype, long long n, hipStream_t stream);
+int hific_axpby_f32(const float* a, const float* b, float* o, float alpha, float beta, long long n,
+                    hipStream_t stream);
+/* out[c] = sum_{n,hw} x[n,c,hw] (bias gradients) */
+int hific_channel_sum(const void* x, float* out, int N, int C, int HW, int accumulate, int dtype, void* ws,
+                      size_t ws_bytes, hipStream_t stream);
+/* nn.MaxPool2d(3, 2) of torchvision AlexNet (pretrained_networks.py:59) */
+int hific_maxpool3s2_fwd(const void* x, void* y, long long planes, int H, int W, int dtype, hipStream_t stream);
+int hific_maxpool3s2_bwd(const void* x, const void* dy, void* dx, long long planes, int H, int W, int dtype,
+                         hipStream_t stream);
+/* distortion loss mean((255 a - 255 b)^2): src/model.py:190-194 */
+int hific_mse_fwd(const void* a, const float* b, float* out, long long n, float scale, int dtype, void* ws,
+                  size_t ws_bytes, hipStream_t stream);
+int hific_mse_bwd(const void* a, const float* b, const float* g, void* da, long long n, float scale, int dtype,
+                  hipStream_t stream);
+/* F.binary_cross_entropy_with_logits vs ones/zeros: src/loss/losses.py:30-41 */
+int hific_bce_fwd(const float* z, float target, float* out, long long n, void* ws, size_t ws_bytes,
+                  hipStream_t stream);
+int hific_bce_bwd(const float* z, float target, const float* g, float* dz, long long n, int accumulate,
+                  hipStream_t stream);
+int hific_sigmoid_f32(const float* z, float* o, long long n, hipStream_t stream);   /* discriminator.py:84 */
+/* torch.cat((x, nn.Upsample(16,'nearest')(y)), 1): src/network/discriminator.py:36,75-77 */
+int hific_upcat_fwd(const void* img, const void* ctx, void* out, int N, int Ci, int Cc, int H, int W, int f,
+                    int dtype, hipStream_t stream);
+int hific_upcat_bwd(const void* dout, void* dimg, int n0, int nimg, void* dctx, int N, int Ci, int Cc, int H, int W,
+                    int f, int dtype, hipStream_t stream);
+/* torch.nn.utils.spectral_norm power iteration + sigma (discriminator.py:46-62); sigma_out = {sigma, 1/sigma} */
+int hific_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma_out, int K, int M, int do_iter,
+                            float eps, void* ws, size_t ws_bytes, hipStream_t stream);
+int hific_spectral_norm_bwd(const float* dW, const float* Worig, const float* u, const float* v,
+                            const float* sigma, float* dWorig, int K, int M, int accumulate, void* ws,
+                            size_t ws_bytes, hipStream_t stream);
+/* torch.optim.Adam step over a flat arena (train.py:287-301: lr 1e-4, betas (.9,.999), eps 1e-8, no decay) */
+int hific_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                    float eps, int step, float grad_scale, hipStream_t stream);
+
+/* ---- entropy model (csrc/entropy.hip), all float32 ----------------------------------------------------------- */
+/* floor(x - mean + .5) + mean: src/hyperprior.py:68-74,108-122 (mean may be NULL) */
+int hific_round_f32(const float* x, const float* mean, float* o, long long n, hipStream_t stream);
+/* LowerBoundToward: src/helpers/maths.py:87-100 */
+int hific_lower_bound_fwd(const float* x, float bound, float* o, long long n, hipStream_t stream);
+int hific_lower_bound_bwd(const float* x, const float* dy, float bound, float* dx, long long n, hipStream_t stream);
+/* mul * sum(log(p + eps)): src/hyperprior.py:80-93 */
+int hific_logsum_fwd(const float* p, float* out, long long n, float eps, float mul, void* ws, size_t ws_bytes,
+                     hipStream_t stream);
+int hific_logsum_bwd(const float* p, const float* g, float* dp, long long n, float eps, float mul, int accumulate,
+                     hipStream_t stream);
+/* latent_likelihood: src/hyperprior.py:124-139 with maths.py:102-109 CDFs (logistic=1 selects sigmoid) */
+int hific_gauss_lik_fwd(const float* x, const float* mean, const float* scale, float* lik, long long n,
+                        float min_lik, int logistic, hipStream_t stream);
+int hific_gauss_lik_bwd(const float* x, const float* mean, const float* scale, const float* dlik, float* dx,
+                        float* dmean, float* dscale, long long n, float min_lik, int logistic, int acc_mean,
+                        int acc_scale, hipStream_t stream);
+/* HyperpriorDensity.likelihood: src/compression/hyperprior_model.py:305-326,349-384.
+ * params / dparams: 12 device pointers H_0..H_3, a_0..a_3, b_0..b_3 (reference parameter shapes) */
+int hific_factorized_lik_fwd(const float* x, const float* const* params, float* lik, int N, int C, int HW,
+                             float min_lik, hipStream_t stream);
+int hific_factorized_lik_bwd(const float* x, const float* const* params, const float* dlik, float* dx,
+                             float* const* dparams, int N, int C, int HW, float min_lik, int accumulate, void* ws,
+                             size_t ws_bytes, hipStream_t stream);
+
+/* ---- LPIPS taps (csrc/lpips.hip) — perceptual_loss.py:36-46, networks_basic.py:61-108 ------------------------- */
+int hific_lpips_prep(const void* src0, int s0_f32, const void* src1, int s1_f32, void* out, int B, int HW,
+                     int normalize, int dtype, hipStream_t stream);
+int hific_lpips_prep_bwd(const void* dout, void* dsrc1, int B, int HW, int normalize, int dtype, int out_f32,
+                         hipStream_t stream);
+int hific_lpips_tap_fwd(const void* f, const float* w, float* val, int B, int C, int HW, int accumulate, int dtype,
+                        void* ws, size_t ws_bytes, hipStream_t stream);
+int hific_lpips_tap_bwd(const void* f, const float* w, const float* gval, void* df1, int B, int C, int HW,
+                        int accumulate, int dtype, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
