@@ -444,6 +444,47 @@ __global__ void wgrad_finalize_kernel(const WgParams p, float* __restrict__ dw, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Optional in-library profiler: HIP event pairs around every GEMM-class launch (on the launch stream), keyed by
+// kernel kind, with the algorithmic FLOPs of each launch.  Used by bench.py for the live roofline figure.
+// ---------------------------------------------------------------------------------------------------
+#define PROF_MAX 16384
+enum { PK_GCONV128 = 0, PK_GCONV64 = 1, PK_GCONV32 = 2, PK_WGRAD = 3, PK_NKIND = 4 };
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_ev[PROF_MAX][2];
+static bool g_prof_ev_made[PROF_MAX];
+static int g_prof_kind[PROF_MAX];
+static double g_prof_flops[PROF_MAX];
+
+static int prof_open(int kind, double flops, hipStream_t st) {
+    if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
+    const int i = g_prof_n++;
+    if (!g_prof_ev_made[i]) {
+        hipEventCreate(&g_prof_ev[i][0]); hipEventCreate(&g_prof_ev[i][1]); g_prof_ev_made[i] = true;
+    }
+    g_prof_kind[i] = kind; g_prof_flops[i] = flops;
+    hipEventRecord(g_prof_ev[i][0], st);
+    return i;
+}
+static void prof_close(int i, hipStream_t st) { if (i >= 0) hipEventRecord(g_prof_ev[i][1], st); }
+
+extern "C" int hific_prof_begin(void) { g_prof_on = true; g_prof_n = 0; return HIFIC_OK; }
+// Synchronises the recorded events; out arrays have PK_NKIND entries: total ms, total FLOPs, launch count.
+extern "C" int hific_prof_end(double* ms, double* flops, int* count) {
+    g_prof_on = false;
+    for (int k = 0; k < PK_NKIND; ++k) { ms[k] = 0; flops[k] = 0; count[k] = 0; }
+    for (int i = 0; i < g_prof_n; ++i) {
+        if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) return HIFIC_ERR_LAUNCH;
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_prof_ev[i][0], g_prof_ev[i][1]);
+        ms[g_prof_kind[i]] += t; flops[g_prof_kind[i]] += g_prof_flops[i]; count[g_prof_kind[i]]++;
+    }
+    g_prof_n = 0;
+    return HIFIC_OK;
+}
+
 // ===================================================================================================
 // Host-side planning
 // ===================================================================================================
@@ -554,6 +595,10 @@ static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, lon
         }
     }
     dim3 grid(max_tiles, p.Kpad / bm, p.nphase);
+    double aflops = 0;
+    for (int i = 0; i < p.nphase; ++i)
+        aflops += 2.0 * p.K * p.C * p.ph[i].ntaps * (double)p.N * p.ph[i].OHt * p.ph[i].OWt;
+    const int pslot = prof_open(bm == 128 ? PK_GCONV128 : (bm == 64 ? PK_GCONV64 : PK_GCONV32), aflops, st);
 #define GC_LAUNCH(WGM, WGN, WM, WN)                                                                      \
     do {                                                                                                 \
         auto kfn = gconv_kernel<T, WGM, WGN, WM, WN>;                                                    \
@@ -565,6 +610,7 @@ static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, lon
     else if (bm == 64) GC_LAUNCH(2, 2, 1, 2);
     else GC_LAUNCH(1, 4, 1, 1);
 #undef GC_LAUNCH
+    prof_close(pslot, st);
     return hific_launch_status();
 }
 
@@ -764,7 +810,9 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
     auto kfn = wgrad_kernel<T>;
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int pslot = prof_open(PK_WGRAD, 2.0 * p.M * p.C * p.ntaps * (double)p.N * p.AH * p.AW, st);
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+    prof_close(pslot, st);
     int rc = hific_launch_status();
     if (rc != HIFIC_OK) return rc;
     long long total = (long long)p.M * p.C * p.ntaps;

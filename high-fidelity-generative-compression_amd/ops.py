@@ -41,6 +41,25 @@ def _ws(t):
     return w.data_ptr(), w.numel()
 
 
+def _slot(t):
+    """Gradient slot bound by optim.ParamArena (None -> gradients are returned to autograd as tensors)."""
+    return getattr(t, "_hific_slot", None) if t is not None else None
+
+
+def _grad_target(slot, like):
+    """(tensor to write, accumulate flag, value to return to autograd)."""
+    if slot is None:
+        t = torch.empty_like(like)
+        return t, 0, t
+    return slot.grad, slot.take(), None
+
+
+def _written(*slots):
+    for sl in slots:
+        if sl is not None:
+            sl.written()
+
+
 def _act_code(act):
     return {None: lib.ACT_NONE, "none": lib.ACT_NONE, "relu": lib.ACT_RELU, "leaky_relu": lib.ACT_LEAKY}[act]
 
@@ -71,6 +90,7 @@ class Conv2dFn(Function):
         ctx.act = act
         ctx.cd = cd
         ctx.has_bias = bias is not None
+        ctx.w_slot, ctx.b_slot = _slot(weight), _slot(bias)
         ctx.save_for_backward(x, weight, w_scale, y if act not in (None, "none") else None)
         return y
 
@@ -96,15 +116,16 @@ class Conv2dFn(Function):
             call("hific_conv2d_bwd_data", ptr(dy), ptr(weight), ptr(w_scale), ptr(dx), N, C, H, W, K, R, S, stride,
                  pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
+            dwt, acc, dw = _grad_target(ctx.w_slot, weight)
             flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
-            call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dw), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
-                 pad_mode, 0, cd, flags, wsp, wsb, stream())
-            # NOTE: with w_scale (spectral norm) dw is the gradient w.r.t. the *scaled* weight; see SpectralNormFn
+            call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dwt), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                 pad_mode, acc, cd, flags, wsp, wsb, stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(K, dtype=torch.float32, device=x.device)
-            call("hific_channel_sum", ptr(dy), ptr(db), N, K, dy.shape[2] * dy.shape[3], 0, lib.dtype_code(dy),
+            dbt, acc, db = _grad_target(ctx.b_slot, weight.new_empty(K))
+            call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
                  wsp, wsb, stream())
+        _written(ctx.w_slot if ctx.needs_input_grad[1] else None,
+                 ctx.b_slot if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
         return dx, dw, db, None, None, None, None
 
 
@@ -137,6 +158,7 @@ class ConvTranspose2dFn(Function):
         call("hific_conv_transpose2d_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), N, Ci, H, W, Co, R, S, stride, pad,
              outpad, _act_code(act), cd, flags, wsp, wsb, stream())
         ctx.geom, ctx.act, ctx.cd, ctx.has_bias = geom, act, cd, bias is not None
+        ctx.w_slot, ctx.b_slot = _slot(weight), _slot(bias)
         ctx.save_for_backward(x, weight, y if act not in (None, "none") else None)
         return y
 
@@ -162,14 +184,16 @@ class ConvTranspose2dFn(Function):
             call("hific_conv_transpose2d_bwd_data", ptr(dy), ptr(weight), ptr(dx), N, Ci, H, W, Co, R, S, stride, pad,
                  outpad, cd, flags, wsp, wsb, stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
+            dwt, acc, dw = _grad_target(ctx.w_slot, weight)
             flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
-            call("hific_conv_transpose2d_bwd_weight", ptr(x), ptr(dy), ptr(dw), N, Ci, H, W, Co, R, S, stride, pad,
-                 outpad, 0, cd, flags, wsp, wsb, stream())
+            call("hific_conv_transpose2d_bwd_weight", ptr(x), ptr(dy), ptr(dwt), N, Ci, H, W, Co, R, S, stride, pad,
+                 outpad, acc, cd, flags, wsp, wsb, stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(Co, dtype=torch.float32, device=x.device)
-            call("hific_channel_sum", ptr(dy), ptr(db), N, Co, dy.shape[2] * dy.shape[3], 0, lib.dtype_code(dy),
+            dbt, acc, db = _grad_target(ctx.b_slot, weight.new_empty(Co))
+            call("hific_channel_sum", ptr(dy), ptr(dbt), N, Co, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
                  wsp, wsb, stream())
+        _written(ctx.w_slot if ctx.needs_input_grad[1] else None,
+                 ctx.b_slot if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
         return dx, dw, db, None, None, None
 
 
@@ -189,6 +213,7 @@ class ChannelNormFn(Function):
         call("hific_channelnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), N, C, H * W,
              float(eps), int(relu), lib.dtype_code(x), stream())
         ctx.relu = int(relu)
+        ctx.g_slot, ctx.b_slot = _slot(gamma), _slot(beta)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         return y
 
@@ -200,11 +225,13 @@ class ChannelNormFn(Function):
         if dy.dtype != x.dtype:
             raise lib.HificError("ChannelNorm backward: grad dtype mismatch")
         dx = torch.empty_like(x)
-        dg = torch.empty_like(gamma)
-        db = torch.empty_like(beta)
+        dgt, acc_g, dg = _grad_target(ctx.g_slot, gamma)
+        dbt, acc_b, db = _grad_target(ctx.b_slot, beta)
+        assert acc_g == acc_b
         wsp, wsb = _ws(x)
-        call("hific_channelnorm_bwd", ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dg),
-             ptr(db), N, C, H * W, ctx.relu, 0, lib.dtype_code(x), wsp, wsb, stream())
+        call("hific_channelnorm_bwd", ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dgt),
+             ptr(dbt), N, C, H * W, ctx.relu, acc_g, lib.dtype_code(x), wsp, wsb, stream())
+        _written(ctx.g_slot, ctx.b_slot)
         return dx, dg, db, None, None
 
 
@@ -397,6 +424,7 @@ class FactorizedLikFn(Function):
         lik = torch.empty_like(x)
         call("hific_factorized_lik_fwd", ptr(x), _ptr_array(params), ptr(lik), N, C, H * W, float(min_lik), stream())
         ctx.min_lik = float(min_lik)
+        ctx.p_slots = [_slot(p) for p in params]
         ctx.save_for_backward(x, *params)
         return lik
 
@@ -406,11 +434,14 @@ class FactorizedLikFn(Function):
         N, C, H, W = x.shape
         g = g.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dparams = [torch.empty_like(p) for p in params]
+        targets = [_grad_target(sl, p) for sl, p in zip(ctx.p_slots, params)]
+        accs = {t[1] for t in targets}
+        assert len(accs) == 1, "factorised-prior parameters must share one gradient state"
         wsp, wsb = _ws(x)
-        call("hific_factorized_lik_bwd", ptr(x), _ptr_array(params), ptr(g), ptr(dx), _ptr_array(dparams), N, C, H * W,
-             ctx.min_lik, 0, wsp, wsb, stream())
-        return (dx, None, *dparams)
+        call("hific_factorized_lik_bwd", ptr(x), _ptr_array(params), ptr(g), ptr(dx),
+             _ptr_array([t[0] for t in targets]), N, C, H * W, ctx.min_lik, accs.pop(), wsp, wsb, stream())
+        _written(*ctx.p_slots)
+        return (dx, None, *[t[2] for t in targets])
 
 
 class LogSumFn(Function):
@@ -551,6 +582,7 @@ class SNConv2dFn(Function):
         call("hific_conv2d_fwd", ptr(x), ptr(weight_orig), ptr(inv_sigma), ptr(bias), None, ptr(y),
              N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, stream())
         ctx.geom, ctx.act, ctx.cd = geom, act, cd
+        ctx.w_slot, ctx.b_slot = _slot(weight_orig), _slot(bias)
         ctx.save_for_backward(x, weight_orig, u.clone(), v.clone(), sig, y if act not in (None, "none") else None)
         return y
 
@@ -581,14 +613,15 @@ class SNConv2dFn(Function):
             flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
             call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dws), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
                  pad_mode, 0, cd, flags, wsp, wsb, stream())
-            dw = torch.empty_like(weight_orig)
+            dwt, acc, dw = _grad_target(ctx.w_slot, weight_orig)
             M = weight_orig.numel() // K
-            call("hific_spectral_norm_bwd", ptr(dws), ptr(weight_orig), ptr(u), ptr(v), ptr(sig), ptr(dw), K, M, 0,
+            call("hific_spectral_norm_bwd", ptr(dws), ptr(weight_orig), ptr(u), ptr(v), ptr(sig), ptr(dwt), K, M, acc,
                  wsp, wsb, stream())
         if ctx.needs_input_grad[2]:
-            db = torch.empty(K, dtype=torch.float32, device=x.device)
-            call("hific_channel_sum", ptr(dy), ptr(db), N, K, dy.shape[2] * dy.shape[3], 0, lib.dtype_code(dy),
+            dbt, acc, db = _grad_target(ctx.b_slot, weight_orig.new_empty(K))
+            call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
                  wsp, wsb, stream())
+        _written(ctx.w_slot if ctx.needs_input_grad[1] else None, ctx.b_slot if ctx.needs_input_grad[2] else None)
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -159,6 +159,13 @@ int hific_lpips_tap_fwd(const void* f, const float* w, float* val, int B, int C,
 int hific_lpips_tap_bwd(const void* f, const float* w, const float* gval, void* df1, int B, int C, int HW,
                         int accumulate, int dtype, hipStream_t stream);
 
+/* ---- in-library profiler (bench.py roofline) ------------------------------------------------------------------
+ * HIP event pairs around every GEMM-class kernel launch on its launch stream.  Kinds: 0/1/2 = gconv_kernel with
+ * 128/64/32-row tiles, 3 = wgrad_kernel.  hific_prof_end synchronises and returns per kind: total ms, total
+ * algorithmic FLOPs (2*K*C*taps*N*OH*OW), launch count (arrays of 4). */
+int hific_prof_begin(void);
+int hific_prof_end(double* ms, double* flops, int* count);
+
 #ifdef __cplusplus
 }
 #endif
