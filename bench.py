@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-timeout", type=int, default=150)
     return ap.parse_args()
 
 
@@ -97,24 +98,22 @@ def make_step(args, model, opts, reducers, dev):
     return step
 
 
-def cpu_baseline(args):
-    """Reference arithmetic (oracle restatement, torch CPU float32) on the host cores: same training step, bounded
-    sample (B=cpu_batch, 1 warm-up + cpu_steps timed steps)."""
+def _cpu_baseline_worker(size, B, steps, threads):
+    """Runs in a child process (no GPU context): reference arithmetic (oracle restatement, torch CPU float32)."""
+    import numpy as np
     from oracle import hific_oracle as O
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    torch.set_num_threads(threads)
     sd = {k: torch.nn.Parameter(v) for k, v in O.make_state_dict(seed=0, gan=False).items()}
     bb = O.make_alex_backbone()
-    lpips_w = __import__("numpy").load(os.path.join(ROOT, "high-fidelity-generative-compression_amd", "loss", "weights",
-                                                     "lpips_alex_lin_v0.1.npz"))
+    lpips_w = np.load(os.path.join(ROOT, "high-fidelity-generative-compression_amd", "loss", "weights",
+                                   "lpips_alex_lin_v0.1.npz"))
     lins = [torch.from_numpy(lpips_w[f"lin{i}"].copy()) for i in range(5)]
     hyper_keys = [k for k in sd if "hyperlatent_likelihood" in k]
     amort = torch.optim.Adam([v for k, v in sd.items() if k not in hyper_keys], lr=1e-4)
     hyper = torch.optim.Adam([sd[k] for k in hyper_keys], lr=1e-4)
-    B = args.cpu_batch
     times = []
-    for it in range(args.cpu_steps + 1):
-        x = O.make_image(100 + it, B, args.size, args.size)
+    for it in range(steps + 1):
+        x = O.make_image(100 + it, B, size, size)
         t0 = time.time()
         out = O.model_forward(sd, bb, lins, x, step_counter=it + 1, training=True, gan=False)
         out["compression"].backward()
@@ -122,9 +121,32 @@ def cpu_baseline(args):
         amort.zero_grad(); hyper.zero_grad()
         times.append(time.time() - t0)
     t = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": B / t, "unit": "images/s", "cores": ncores, "kind": "port",
-            "sample": f"oracle (torch-CPU restatement of the reference) compression train step, batch {B}, "
-                      f"{args.size}x{args.size}, fp32, 1 warm-up + {args.cpu_steps} timed steps (median)"}
+    print(json.dumps({"images_per_s": B / t, "step_s": t}), flush=True)
+
+
+def cpu_baseline(args):
+    """The oracle ("port" of the reference's CPU path) timed on this box's host cores on a bounded sample of the
+    same workload: compression training step (fwd + bwd + 2x Adam), batch `cpu_batch`, 1 warm-up + `cpu_steps`
+    timed steps, in a child process with a hard time limit so the GPU line can never be lost to it."""
+    import subprocess
+    ncores = os.cpu_count() or 1
+    threads = min(ncores, int(os.environ.get("HIFIC_CPU_THREADS", "32")))
+    cmd = [sys.executable, "-c",
+           f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
+           f"bench._cpu_baseline_worker({args.size}, {args.cpu_batch}, {args.cpu_steps}, {threads})"]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+    sample = (f"oracle (torch-CPU float32 restatement of the reference) compression train step, batch "
+              f"{args.cpu_batch}, {args.size}x{args.size}, 1 warm-up + {args.cpu_steps} timed steps (median), "
+              f"{threads} threads of {ncores} logical cores")
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_timeout)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+        return {"value": round(r["images_per_s"], 4), "unit": "images/s", "cores": threads, "kind": "port",
+                "sample": sample}
+    except Exception as e:
+        return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
+                "sample": sample + f" -- FAILED: {type(e).__name__}"}
 
 
 def main():
@@ -197,11 +219,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args)
-            except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
-                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {e!r}"}
+            out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
