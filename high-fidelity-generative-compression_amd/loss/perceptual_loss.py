@@ -139,6 +139,9 @@ class LpipsFn(Function):
 
 
 class PerceptualLoss(nn.Module):
+    """Like the reference (whose DistModel is not an nn.Module, base_model.py:5), the LPIPS tensors are *not*
+    registered: they never appear in a HiFIC state_dict, but they follow `.to()/.cuda()` of the owning model."""
+
     def __init__(self, model='net-lin', net='alex', colorspace='rgb', spatial=False, use_gpu=True, gpu_ids=[0],
                  version='0.1', backbone_seed=1234):
         super().__init__()
@@ -146,22 +149,32 @@ class PerceptualLoss(nn.Module):
             raise NotImplementedError("hific_amd PerceptualLoss implements the configuration HiFIC uses: "
                                       "model='net-lin', net='alex', colorspace='rgb', spatial=False, version='0.1'")
         self.use_gpu, self.gpu_ids, self.spatial = use_gpu, gpu_ids, spatial
-        # backbone parameters in torchvision's `features` indexing; frozen like the reference (requires_grad=False)
+        # backbone tensors in torchvision's `features.N.{weight,bias}` naming; frozen (requires_grad=False)
         gen = torch.Generator().manual_seed(backbone_seed)
-        feats = {}
+        t = {}
         for idx, (ci, co, k, s, p, _) in zip(ALEX_FEATURE_IDX, ALEX_CFG):
-            conv = nn.Conv2d(ci, co, k, stride=s, padding=p)
-            with torch.no_grad():
-                bound = 1.0 / np.sqrt(ci * k * k)
-                conv.weight.copy_((torch.rand(conv.weight.shape, generator=gen) * 2 - 1) * bound)
-                conv.bias.copy_((torch.rand(conv.bias.shape, generator=gen) * 2 - 1) * bound)
-            feats[str(idx)] = conv
-        self.features = nn.ModuleDict(feats)
+            bound = 1.0 / np.sqrt(ci * k * k)
+            t[f"features.{idx}.weight"] = (torch.rand((co, ci, k, k), generator=gen) * 2 - 1) * bound
+            t[f"features.{idx}.bias"] = (torch.rand((co,), generator=gen) * 2 - 1) * bound
         lin = np.load(os.path.join(_HERE, "weights", "lpips_alex_lin_v0.1.npz"))
         for i in range(5):
-            self.register_buffer(f"lin{i}", torch.from_numpy(lin[f"lin{i}"].copy()), persistent=False)
-        for prm in self.parameters():
-            prm.requires_grad = False
+            t[f"lin{i}"] = torch.from_numpy(lin[f"lin{i}"].copy())
+        object.__setattr__(self, "_t", t)          # plain dict: invisible to state_dict()/parameters()
+        if use_gpu and torch.cuda.is_available():
+            dev = torch.device("cuda", gpu_ids[0] if gpu_ids else 0)
+            for k in t:
+                t[k] = t[k].to(dev)
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        for key in self._t:
+            self._t[key] = fn(self._t[key])
+        return self
+
+    def __getattr__(self, name):
+        if name.startswith("lin") and name[3:].isdigit():
+            return self._t[name]
+        return super().__getattr__(name)
 
     def load_backbone_state_dict(self, sd):
         """Accepts torchvision alexnet keys (`features.N.weight`) or bare `N.weight`."""
@@ -169,13 +182,14 @@ class PerceptualLoss(nn.Module):
             for idx in ALEX_FEATURE_IDX:
                 for nm in ("weight", "bias"):
                     key = f"features.{idx}.{nm}" if f"features.{idx}.{nm}" in sd else f"{idx}.{nm}"
-                    getattr(self.features[str(idx)], nm).copy_(sd[key])
+                    dst = self._t[f"features.{idx}.{nm}"]
+                    dst.copy_(sd[key].to(dst.device))
 
     def forward(self, pred, target, normalize=False):
         if target.requires_grad:
             raise NotImplementedError("gradient w.r.t. the LPIPS target image is not implemented (not on the HiFIC path)")
-        lins = tuple(getattr(self, f"lin{i}") for i in range(5))
+        lins = tuple(self._t[f"lin{i}"] for i in range(5))
         wb = []
         for idx in ALEX_FEATURE_IDX:
-            wb += [self.features[str(idx)].weight, self.features[str(idx)].bias]
+            wb += [self._t[f"features.{idx}.weight"], self._t[f"features.{idx}.bias"]]
         return LpipsFn.apply(pred.contiguous(), target.contiguous(), normalize, lins, *wb)

@@ -70,13 +70,8 @@ class Model(nn.Module):
         else:
             self.discriminator_steps = 0
             self.Discriminator = None
-        # like the reference's DistModel, LPIPS is not part of the state_dict: keep it out of the module tree
-        object.__setattr__(self, 'perceptual_loss', ps.PerceptualLoss(model='net-lin', net='alex'))
-
-    def _apply(self, fn, *a, **k):
-        super()._apply(fn, *a, **k)
-        self.perceptual_loss._apply(fn, *a, **k)   # the reference moves LPIPS via use_gpu (dist_model.py:94-95)
-        return self
+        # LPIPS tensors are unregistered (not in the state_dict, like the reference's DistModel) but follow .to()
+        self.perceptual_loss = ps.PerceptualLoss(model='net-lin', net='alex', use_gpu=False)
 
     def store_loss(self, key, loss):
         assert type(loss) == float, 'Call .item() on loss before storage'

@@ -1,0 +1,122 @@
+"""Host-side logic that needs no GPU: module construction / state_dict contract, config, schedules, parameter
+arenas, gradient-bucket planning."""
+import pytest
+import torch
+
+from oracle import hific_oracle as O
+
+
+def test_state_dict_schema_matches_reference_layout(hific):
+    from hific_amd.default_config import make_args, hific_args, ModelTypes
+    m = hific.Model(make_args(hific_args), model_type=ModelTypes.COMPRESSION_GAN)
+    sd = m.state_dict()
+    want = {k: tuple(s) for k, s, _ in O._shapes(gan=True)}
+    assert set(sd) == set(want) and len(sd) == 168
+    for k, v in sd.items():
+        assert tuple(v.shape) == want[k], k
+    n_amort = sum(p.numel() for mod in m.amortization_models for p in mod.parameters())
+    n_hyper = sum(p.numel() for p in m.Hyperprior.hyperlatent_likelihood.parameters())
+    n_disc = sum(p.numel() for p in m.Discriminator.parameters())
+    assert (n_amort, n_hyper, n_disc) == (181461583, 14080, 2793117)
+    # the oracle's fixture state_dict loads unchanged (same keys/shapes as a reference checkpoint)
+    m.load_state_dict(O.make_state_dict(seed=1, gan=True), strict=True)
+    assert "perceptual_loss" not in "".join(sd)                            # LPIPS is not part of the checkpoint
+
+
+def test_same_seed_gives_reference_initialisation(hific):
+    """Parameters are created by the same torch constructors in the same order as the reference modules, so a
+    seed reproduces the reference's initial weights (checked against the reference where it is importable)."""
+    from oracle import ref_loader
+    from hific_amd.network.encoder import Encoder
+    from hific_amd.network.discriminator import Discriminator
+    torch.manual_seed(7)
+    e1 = Encoder((3, 64, 64), 2, C=8)
+    torch.manual_seed(7)
+    d1 = Discriminator((3, 64, 64), (8, 4, 4), C=8)
+    if not ref_loader.available():
+        pytest.skip("reference not present")
+    ns = ref_loader.load()
+    torch.manual_seed(7)
+    e2 = ns.encoder.Encoder((3, 64, 64), 2, C=8)
+    torch.manual_seed(7)
+    d2 = ns.discriminator.Discriminator((3, 64, 64), (8, 4, 4), C=8)
+    for (k1, v1), (k2, v2) in zip(e1.state_dict().items(), e2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    s1, s2 = d1.state_dict(), d2.state_dict()
+    assert set(s1) == set(s2)
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+
+
+def test_schedules_and_config(hific):
+    from hific_amd.helpers.utils import get_scheduled_params
+    from hific_amd.default_config import make_args, mse_lpips_args
+    sch = dict(vals=[2., 1.], steps=[50000])
+    for s in (0, 1, 49999, 50000, 123456):
+        assert get_scheduled_params(2.0, sch, s) == O.get_scheduled_params(2.0, sch, s)
+    assert get_scheduled_params(2.0, sch, 5, ignore_schedule=True) == 2.0
+    a = make_args(mse_lpips_args, regime="high")
+    assert a.target_rate == 0.45 and a.lambda_A == 0.5 and a.latent_channels == 220 and a.n_residual_blocks == 9
+
+
+def test_param_arena_and_adam_bookkeeping(hific):
+    from hific_amd import optim
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(70)), torch.nn.Parameter(torch.randn(1))]
+    before = [p.detach().clone() for p in ps]
+    arena = optim.ParamArena(ps)
+    for p, b in zip(ps, before):
+        assert torch.equal(p.detach(), b)
+        assert p.data.data_ptr() >= arena.flat.data_ptr()
+        assert p.grad is not None and p._hific_slot.grad.data_ptr() == p.grad.data_ptr()
+    assert all(o % 64 == 0 for o in arena.offsets)
+    s = ps[0]._hific_slot
+    assert s.take() == 0 and s.take() == 1          # first write overwrites, second accumulates
+    arena.zero_grad()
+    assert s.take() == 0
+    arena.flat[arena.offsets[1]] = 42.0
+    assert ps[1].detach()[0] == 42.0                 # parameters are views of the arena
+
+
+def test_bucket_planning_reverse_order(hific):
+    from hific_amd import optim, parallel
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (1000, 300000, 50, 9000000, 64, 64)]
+    arena = optim.ParamArena(ps)
+    red = parallel.BucketedGradReducer(arena, bucket_mbytes=1)
+    assert red.world == 1
+    covered = sorted((lo, hi) for lo, hi, _ in red.buckets)
+    assert covered[0][0] == 0 and covered[-1][1] == arena.numel
+    for (a, b), (c, d) in zip(covered, covered[1:]):
+        assert b == c
+    assert red.buckets[0][1] == arena.numel          # first bucket = tail of the arena (produced first by backward)
+    assert sum(n for _, _, n in red.buckets) == len(ps)
+    assert red.finish() == 1.0
+
+
+def test_injection_into_reference_model(hific):
+    """The reference's own Model builds the MI355X modules after inject.patch_reference() and accepts a
+    reference-layout state_dict."""
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip("reference not present")
+    import importlib
+    import sys
+    ns = ref_loader.load()
+    import hific_amd.inject as inject
+    saved = {}
+    names = inject.patch_reference()
+    try:
+        assert "src.network.encoder.Encoder" in names
+        m = ref_loader.build_reference_model(ns, gan=True)
+        assert type(m.Encoder).__module__.startswith("hific_amd")
+        assert type(m.Generator.resblock_0).__module__.startswith("hific_amd")
+        assert type(m.Hyperprior.hyperlatent_likelihood).__module__.startswith("hific_amd")
+        assert type(m.Discriminator).__module__.startswith("hific_amd")
+        m.load_state_dict(O.make_state_dict(seed=2, gan=True), strict=True)
+        assert len(m.state_dict()) == 168
+    finally:
+        for modname in ("src.network.encoder", "src.network.generator", "src.network.discriminator",
+                        "src.network.hyper", "src.normalisation.channel", "src.hyperprior",
+                        "src.compression.hyperprior_model", "src.loss.perceptual_similarity.perceptual_loss",
+                        "src.model"):
+            if modname in sys.modules:
+                importlib.reload(sys.modules[modname])

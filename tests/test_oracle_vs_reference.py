@@ -1,0 +1,100 @@
+"""Pins every oracle function against the imported reference modules (only where /root/reference exists — the
+build container; skipped on the GPU box).  Same weights (state_dict), same inputs, forward and gradients."""
+import pytest
+import torch
+
+from oracle import ref_loader, hific_oracle as O
+
+pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def ns():
+    return ref_loader.load()
+
+
+def _sub(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def test_encoder_generator(ns):
+    sd = O.make_state_dict(seed=3, gan=False, n_res=2)
+    enc = ns.encoder.Encoder((3, 64, 64), 2, C=220)
+    enc.load_state_dict(_sub(sd, "Encoder."))
+    x = O.make_image(5, 2, 64, 64).requires_grad_(True)
+    y_ref = enc(x)
+    x2 = x.detach().clone().requires_grad_(True)
+    y_or = O.encoder_forward(sd, x2)
+    assert torch.allclose(y_ref, y_or, rtol=1e-5, atol=1e-5)
+    g = O.make_noise(6, tuple(y_ref.shape))
+    y_ref.backward(g); y_or.backward(g)
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=1e-6)
+    gen = ns.generator.Generator((3, 64, 64), 2, C=220, n_residual_blocks=2)
+    gen.load_state_dict(_sub(sd, "Generator."))
+    lat = O.make_noise(7, (2, 220, 4, 4)) * 4
+    assert torch.allclose(gen(lat), O.generator_forward(sd, lat, 2), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("ltype", ["gaussian", "logistic"])
+def test_hyperprior(ns, training, ltype):
+    sd = O.make_state_dict(seed=4, gan=False, n_res=0)
+    hp = ns.hyperprior.Hyperprior(bottleneck_capacity=220, likelihood_type=ltype)
+    hp.load_state_dict(_sub(sd, "Hyperprior."))
+    hp.train(training)
+    y = (O.make_noise(8, (2, 220, 8, 8)) * 6).requires_grad_(True)
+    nh, nl = O.make_noise(9, (2, 320, 2, 2)), O.make_noise(10, (2, 220, 8, 8))
+    noises = [nh, nl]
+    orig = ns.hyperprior.CodingModel._quantize
+
+    def patched(self, x_, mode='noise', means=None):
+        if mode == 'noise':
+            return x_ + noises.pop(0)
+        return orig(self, x_, mode=mode, means=means)
+
+    ns.hyperprior.CodingModel._quantize = patched
+    try:
+        h_ref = hp(y, (128, 128))
+    finally:
+        ns.hyperprior.CodingModel._quantize = orig
+    y2 = y.detach().clone().requires_grad_(True)
+    h_or = O.hyperprior_forward(sd, y2, (128, 128), training, nh, nl, ltype)
+    for f in ("latent_nbpp", "hyperlatent_nbpp", "total_nbpp", "latent_qbpp", "hyperlatent_qbpp", "total_qbpp"):
+        assert torch.allclose(getattr(h_ref, f), getattr(h_or, f), rtol=1e-5), f
+    assert torch.equal(h_ref.decoded, h_or.decoded)
+    (h_ref.total_nbpp + 0.3 * h_ref.total_qbpp).backward()
+    (h_or.total_nbpp + 0.3 * h_or.total_qbpp).backward()
+    assert torch.allclose(y.grad, y2.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_discriminator_and_lpips(ns):
+    sd = O.make_state_dict(seed=5, gan=True, n_res=0)
+    D = ns.discriminator.Discriminator((3, 64, 64), (220, 4, 4), C=220)
+    D.load_state_dict(_sub(sd, "Discriminator."))
+    D.train()
+    x = O.make_image(11, 4, 64, 64)
+    y = O.make_noise(12, (4, 220, 4, 4)) * 3
+    out_ref, logit_ref = D(x, y)
+    out_or, logit_or, new_uv = O.discriminator_forward(sd, x, y, training=True)
+    assert torch.allclose(logit_ref, logit_or, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(D.conv1.weight_u, new_uv["Discriminator.conv1.weight_u"], atol=1e-6)
+    m = ref_loader.build_reference_model(ns, gan=False)
+    bb = O.make_alex_backbone()
+    ref_loader.set_lpips_backbone(m, bb)
+    lins = ref_loader.reference_lins(m)
+    a, b = O.make_image(13, 2, 64, 64), O.make_image(14, 2, 64, 64)
+    v_ref = m.perceptual_loss.forward(a, b, normalize=True)
+    v_or = O.lpips_forward(bb, lins, a, b, normalize=True)
+    assert torch.allclose(v_ref, v_or, rtol=1e-5, atol=1e-7)
+
+
+def test_packaged_lin_weights_equal_reference(ns):
+    import os
+    import numpy as np
+    m = ref_loader.build_reference_model(ns, gan=False)
+    lins = ref_loader.reference_lins(m)
+    p = os.path.join(os.path.dirname(os.path.dirname(__file__)), "high-fidelity-generative-compression_amd", "loss",
+                     "weights", "lpips_alex_lin_v0.1.npz")
+    w = np.load(p)
+    for i in range(5):
+        assert torch.equal(torch.from_numpy(w[f"lin{i}"]), lins[i])
