@@ -13,9 +13,10 @@
 #include <string.h>
 #include <stdlib.h>
 
+// K-slice of one MFMA and LDS row padding per element type; BC (channels per chunk) is a kernel template parameter
 template <typename T> struct GcCfg;
-template <> struct GcCfg<bf16_t> { static constexpr int BC = 32, KS = 16, PITCH = 80; };
-template <> struct GcCfg<float>  { static constexpr int BC = 16, KS = 2,  PITCH = 68; };
+template <> struct GcCfg<bf16_t> { static constexpr int KS = 16, PAD = 16; };
+template <> struct GcCfg<float>  { static constexpr int KS = 2,  PAD = 4; };
 
 // ---------------------------------------------------------------------------------------------------
 // Transposing stage: NCHW global -> LDS image [NI*PH*PW rows][DWR dwords], row pitch PITCH bytes.
@@ -27,58 +28,96 @@ __device__ __forceinline__ void stage_T(unsigned char* lds, const void* src, int
                                         int N, int C, int H, int W, int bmode,
                                         int n0, int NI, int y0, int x0, int ystep_unused, int PH, int PW,
                                         int c0, int tid, int nthreads) {
+    // Thread (lane, wave) handles patch pixels q = lane + 64*j and dwords dw = wave + 4*i: the pixel is decoded once
+    // and all DWR/4 channel loads of it are issued back-to-back (memory-level parallelism instead of one dependent
+    // 2-byte load at a time); lanes run along W so every channel row is a coalesced run.
+    static_assert(DWR % 4 == 0, "DWR");
+    constexpr int NDW = DWR / 4;
     const int npp = PH * PW;
     const int npatch = NI * npp;
-    const int nitems = npatch * DWR;
     const size_t plane = (size_t)H * W;
-    for (int it = tid; it < nitems; it += nthreads) {
-        const int dw = it / npatch;
-        const int q = it - dw * npatch;
-        const int img = q / npp;
+    const int lane = tid & 63, wv = tid >> 6;
+    const float inv_npp = 1.0f / (float)npp, inv_pw = 1.0f / (float)PW;
+    for (int q = lane; q < npatch; q += 64) {
+        // exact for q < 2^22: (q + 0.5)/d never rounds across an integer
+        const int img = (int)(((float)q + 0.5f) * inv_npp);
         const int r = q - img * npp;
-        const int py = r / PW;
+        const int py = (int)(((float)r + 0.5f) * inv_pw);
         const int px = r - py * PW;
         int iy = y0 + py, ix = x0 + px;
         const int n = n0 + img;
         if (bmode == PAD_REFLECT) { iy = reflect_idx(iy, H); ix = reflect_idx(ix, W); }
         const bool ok = (n < N) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-        unsigned val = 0;
-        if (ok) {
-            const size_t base = (size_t)n * C * plane + (size_t)iy * W + ix;
-            if constexpr (std::is_same<T, float>::value) {
-                const int c = c0 + dw;
-                if (c < C) val = __float_as_uint(((const float*)src)[base + (size_t)c * plane]);
-            } else {
-                const int c = c0 + 2 * dw;
-                unsigned lo = 0, hi = 0;
-                if (src_f32) {
-                    const float* s = (const float*)src;
-                    if (c < C) lo = f2bf(s[base + (size_t)c * plane]);
-                    if (c + 1 < C) hi = f2bf(s[base + (size_t)(c + 1) * plane]);
-                } else {
-                    const bf16_t* s = (const bf16_t*)src;
-                    if (c < C) lo = s[base + (size_t)c * plane];
-                    if (c + 1 < C) hi = s[base + (size_t)(c + 1) * plane];
-                }
-                val = lo | (hi << 16);
+        const size_t base = ok ? ((size_t)n * C * plane + (size_t)iy * W + ix) : 0;
+        // all loads are unconditional (invalid elements read element 0 and are zeroed by a select) so that the
+        // compiler can issue them back-to-back with a single wait
+        unsigned vals[NDW];
+        if constexpr (std::is_same<T, float>::value) {
+            const float* sp = (const float*)src;
+            float v[NDW];
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) {
+                const int c = c0 + wv + 4 * i;
+                const bool okc = ok && c < C;
+                v[i] = sp[okc ? base + (size_t)c * plane : 0];
+                vals[i] = okc ? __float_as_uint(v[i]) : 0u;
+            }
+        } else if (src_f32) {
+            const float* sp = (const float*)src;
+            float lo[NDW], hi[NDW];
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) {
+                const int c = c0 + 2 * (wv + 4 * i);
+                lo[i] = sp[(ok && c < C) ? base + (size_t)c * plane : 0];
+                hi[i] = sp[(ok && c + 1 < C) ? base + (size_t)(c + 1) * plane : 0];
+            }
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) {
+                const int c = c0 + 2 * (wv + 4 * i);
+                const unsigned l = (ok && c < C) ? (unsigned)f2bf(lo[i]) : 0u;
+                const unsigned h = (ok && c + 1 < C) ? (unsigned)f2bf(hi[i]) : 0u;
+                vals[i] = l | (h << 16);
+            }
+        } else {
+            const bf16_t* sp = (const bf16_t*)src;
+            unsigned lo[NDW], hi[NDW];
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) {
+                const int c = c0 + 2 * (wv + 4 * i);
+                lo[i] = sp[(ok && c < C) ? base + (size_t)c * plane : 0];
+                hi[i] = sp[(ok && c + 1 < C) ? base + (size_t)(c + 1) * plane : 0];
+            }
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) {
+                const int c = c0 + 2 * (wv + 4 * i);
+                const unsigned l = (ok && c < C) ? lo[i] : 0u;
+                const unsigned h = (ok && c + 1 < C) ? hi[i] : 0u;
+                vals[i] = l | (h << 16);
             }
         }
-        *(unsigned*)(lds + (size_t)q * PITCH + dw * 4) = val;
+        unsigned char* row = lds + (size_t)q * PITCH + wv * 4;
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) *(unsigned*)(row + i * 16) = vals[i];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Forward-type kernel
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int WGM, int WGN, int WM, int WN>
+template <typename T, int BC, int WGM, int WGN, int WM, int WN>
 __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
     using Cfg = GcCfg<T>;
-    constexpr int BC = Cfg::BC, KS = Cfg::KS, PITCH = Cfg::PITCH;
+    constexpr int KS = Cfg::KS;
+    constexpr int ROWB = BC * (int)sizeof(T);          // bytes of one LDS row (BC channels)
+    constexpr int PITCH = ROWB + Cfg::PAD;
+    constexpr int DWR = ROWB / 4;
+    constexpr int PPR = ROWB / 16;                     // 16-byte pieces per weight row
     constexpr int BM = WGM * WM * 32;
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(WGN * WN * 32 == GC_NPIX, "128 pixels per tile");
+    static_assert(ROWB % 16 == 0, "row bytes");
     constexpr int WBYTES = BM * PITCH;
-    constexpr int NWP = (BM * 4 + 255) / 256;   // 16-byte weight pieces per thread per step
+    constexpr int NWP = (BM * PPR + 255) / 256;   // 16-byte weight pieces per thread per step
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -102,8 +141,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
     const int npatch = p.NI * npp;
     const int iy0 = u0 * p.ist + ph.dy_min, ix0 = v0 * p.ist + ph.dx_min;
 
-    unsigned char* wbuf = smem;                       // 2 x WBYTES
-    unsigned char* patch = smem + 2 * WBYTES;         // npatch x PITCH
+    int* toffs = (int*)smem;                          // [GC_MAXTAPS] tap -> patch row offset
+    unsigned char* wbuf = smem + 512;                 // 2 x WBYTES
+    unsigned char* patch = wbuf + 2 * WBYTES;         // npatch x PITCH
+    if (tid < ph.ntaps)
+        toffs[tid] = ((int)p.tap_dy[ph.tap0 + tid] - ph.dy_min) * PW + ((int)p.tap_dx[ph.tap0 + tid] - ph.dx_min);
 
     // per-lane pixel decode for the B (pixel) operand and the epilogue
     int qb[WN], pu[WN], pv[WN], pn[WN];
@@ -136,52 +178,55 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
     const unsigned char* wp_ph = (const unsigned char*)p.wp + (size_t)ph.wp_off * sizeof(T);
     const size_t wrow_bytes = (size_t)nt * p.Cpad * sizeof(T);   // one m-row of this phase
 
-    uint4 wreg[NWP];
-    auto load_w = [&](int chunk, int t) {
+    // weight-tile prefetch registers: loaded right after the barrier of step s for step s+1, written to the other
+    // LDS buffer after the MFMAs of step s (single call site each, so they stay in VGPRs)
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t wreg[NWP];
+    int wrow[NWP], wpart[NWP];
 #pragma unroll
-        for (int i = 0; i < NWP; ++i) {
-            const int piece = tid + i * 256;
-            if (piece < BM * 4) {
-                const int row = piece >> 2, part = piece & 3;
-                const unsigned char* g = wp_ph + (size_t)(m0 + row) * wrow_bytes +
-                                         ((size_t)t * p.Cpad + (size_t)chunk * BC) * sizeof(T) + part * 16;
-                wreg[i] = *(const uint4*)g;
-            }
-        }
-    };
-    auto store_w = [&](unsigned char* wb) {
+    for (int i = 0; i < NWP; ++i) {
+        int piece = tid + i * 256;
+        if (piece >= BM * PPR) piece = BM * PPR - 1;          // clamp (duplicate load) instead of a divergent branch
+        wrow[i] = piece / PPR; wpart[i] = piece % PPR;
+    }
+    const unsigned char* wsrc[NWP];
 #pragma unroll
-        for (int i = 0; i < NWP; ++i) {
-            const int piece = tid + i * 256;
-            if (piece < BM * 4) {
-                const int row = piece >> 2, part = piece & 3;
-                unsigned char* d = wb + row * PITCH + part * 16;
-                if constexpr (PITCH % 16 == 0) {
-                    *(uint4*)d = wreg[i];
-                } else {
-                    ((unsigned*)d)[0] = wreg[i].x; ((unsigned*)d)[1] = wreg[i].y;
-                    ((unsigned*)d)[2] = wreg[i].z; ((unsigned*)d)[3] = wreg[i].w;
-                }
-            }
-        }
-    };
+    for (int i = 0; i < NWP; ++i) wsrc[i] = wp_ph + (size_t)(m0 + wrow[i]) * wrow_bytes + wpart[i] * 16;
 
-    if (nsteps > 0) load_w(0, 0);
+    if (nsteps > 0) {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) wreg[i] = *(const u32x4_t*)(wsrc[i]);     // step 0: (tap 0, chunk 0)
+    }
+    int step = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads();
-        stage_T<T, 16, PITCH>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode,
+        stage_T<T, DWR, PITCH>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode,
                               n0, p.NI, iy0, ix0, 0, PH, PW, chunk * BC, tid, 256);
-        for (int t = 0; t < nt; ++t) {
-            const int step = chunk * nt + t;
+        for (int t = 0; t < nt; ++t, ++step) {
             unsigned char* wb = wbuf + (step & 1) * WBYTES;
-            store_w(wb);
-            __syncthreads();
-            if (step + 1 < nsteps) {
-                if (t + 1 < nt) load_w(chunk, t + 1); else load_w(chunk + 1, 0);
+#pragma unroll
+            for (int i = 0; i < NWP; ++i) {
+                if (tid + i * 256 < BM * PPR) {
+                    unsigned char* d = wb + wrow[i] * PITCH + wpart[i] * 16;
+                    if constexpr (PITCH % 16 == 0) {
+                        *(u32x4_t*)d = wreg[i];
+                    } else {
+                        ((unsigned*)d)[0] = wreg[i].x; ((unsigned*)d)[1] = wreg[i].y;
+                        ((unsigned*)d)[2] = wreg[i].z; ((unsigned*)d)[3] = wreg[i].w;
+                    }
+                }
             }
-            const int tdy = (int)p.tap_dy[ph.tap0 + t] - ph.dy_min;
-            const int tdx = (int)p.tap_dx[ph.tap0 + t] - ph.dx_min;
-            const int toff = tdy * PW + tdx;
+            __syncthreads();
+            {
+                // next step's (tap, chunk); the last step re-loads itself (valid address, value unused)
+                int tn = t + 1, cn = chunk;
+                if (tn == nt) { tn = 0; cn = chunk + 1; }
+                if (cn == nchunks) { tn = t; cn = chunk; }
+                const size_t off = ((size_t)tn * p.Cpad + (size_t)cn * BC) * sizeof(T);
+#pragma unroll
+                for (int i = 0; i < NWP; ++i) wreg[i] = *(const u32x4_t*)(wsrc[i] + off);
+            }
+            const int toff = toffs[t];
             const unsigned char* arow = wb + (wm * WM * 32 + l31) * PITCH;
 #pragma unroll
             for (int kk = 0; kk < BC / KS; ++kk) {
@@ -488,33 +533,41 @@ extern "C" int hific_prof_end(double* ms, double* flops, int* count) {
 // ===================================================================================================
 // Host-side planning
 // ===================================================================================================
-static int p2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s ? atoi(s) : dflt; }
 
 static const int kLdsBudget = 150 * 1024;
 
-// choose (TH, TW, NI) for a (u,v) domain; patch extent depends on tap span and input stride
+// choose (TH, TW, NI) for a (u,v) domain: exhaustive search over tile shapes (not only powers of two, so padded
+// data-gradient domains such as 18x18 tile as 7x18 instead of 8x16) minimising a cost model
+//   tiles * (128 pixels * ntaps MFMA work + staging of the halo patch)
+// subject to the LDS budget.  need16: pixels per tile must be a multiple of 16 (weight-gradient K-slice).
 static bool choose_tile(int N, int OHt, int OWt, int ist, int span_y, int span_x, int pitch, int fixed_bytes,
-                        int pref_budget, int& TH, int& TW, int& NI) {
-    TW = p2ceil(OWt); if (TW > 16) TW = 16; if (TW < 1) TW = 1;
-    TH = p2ceil(OHt); if (TH > GC_NPIX / TW) TH = GC_NPIX / TW;
-    NI = GC_NPIX / (TH * TW); { int n2 = p2ceil(N); if (NI > n2) NI = n2; }
-    auto bytes = [&](int th, int tw, int ni) {
-        long long ph = (long long)(th - 1) * ist + span_y, pw = (long long)(tw - 1) * ist + span_x;
-        return (long long)ni * ph * pw * pitch + fixed_bytes;
-    };
-    int budget = pref_budget;
+                        int pref_budget, int& TH, int& TW, int& NI, int ntaps = 9, bool need16 = false) {
     for (int pass = 0; pass < 2; ++pass) {
-        int th = TH, tw = TW, ni = NI;
-        while (bytes(th, tw, ni) > budget) {
-            if (ni > 1) ni >>= 1;
-            else if (th > 1 && th >= tw) th >>= 1;
-            else if (tw > 4) tw >>= 1;
-            else if (th > 1) th >>= 1;
-            else break;
+        const long long budget = pass == 0 ? pref_budget : kLdsBudget;
+        double best = 1e300;
+        bool found = false;
+        const int twmax = OWt < 32 ? OWt : 32;
+        for (int tw = twmax; tw >= 1; --tw) {
+            if (tw < 4 && tw != twmax) break;
+            int thmax = GC_NPIX / tw; if (thmax > OHt) thmax = OHt;
+            for (int th = thmax; th >= 1; --th) {
+                const bool whole = (th >= OHt && tw >= OWt);
+                int nimax = whole ? GC_NPIX / (th * tw) : 1;       // several images per tile only for whole planes
+                if (nimax > N) nimax = N;
+                for (int ni = nimax; ni >= 1; --ni) {
+                    if (need16 && (ni * th * tw) % 16 != 0) continue;
+                    const long long ph = (long long)(th - 1) * ist + span_y, pw = (long long)(tw - 1) * ist + span_x;
+                    const long long bytes = (long long)ni * ph * pw * pitch + fixed_bytes;
+                    if (bytes > budget) continue;
+                    const double tiles = (double)cdiv(OHt, th) * cdiv(OWt, tw) * cdiv(N, ni);
+                    const double cost = tiles * (128.0 * ntaps + 3.0 * (double)(ni * ph * pw));
+                    // prefer wider tiles on ties (longer coalesced runs)
+                    if (cost < best * (1.0 - 1e-9)) { best = cost; TH = th; TW = tw; NI = ni; found = true; }
+                }
+            }
         }
-        if (bytes(th, tw, ni) <= budget) { TH = th; TW = tw; NI = ni; return true; }
-        budget = kLdsBudget;
+        if (found) return true;
     }
     return false;
 }
@@ -533,22 +586,23 @@ static void finish_phase(GcPhase& ph, const GcParams& p) {
     ph.PH = dymax - dymin + 1; ph.PW = dxmax - dxmin + 1;   // spans; converted to patch extents later
 }
 
-template <typename T>
-static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
-                          long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+template <typename T, int BC>
+static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
+                           long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
     using Cfg = GcCfg<T>;
+    constexpr int PITCH = BC * (int)sizeof(T) + Cfg::PAD;
     // M tile
     int bm;
     {
         long long w128 = cdivl(p.K, 128) * 128, w64 = cdivl(p.K, 64) * 64;
         if (p.K <= 32) bm = 32;
-        else if (w128 * 100 > w64 * 105) bm = 64;
+        else if (w128 * 100 > w64 * 110) bm = 64;
         else bm = 128;
         int e = env_int("HIFIC_BM", 0);
-        if (e == 32 || e == 64 || e == 128) bm = e;
+        if ((e == 64 || e == 128) && p.K > 32) bm = e;
     }
     p.Kpad = cdiv(p.K, bm) * bm;
-    p.Cpad = cdiv(p.C, Cfg::BC) * Cfg::BC;
+    p.Cpad = cdiv(p.C, BC) * BC;
     // tile shape: common to all phases (largest span decides)
     int span_y = 1, span_x = 1, OHt = 1, OWt = 1;
     for (int i = 0; i < p.nphase; ++i) {
@@ -557,8 +611,10 @@ static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, lon
         if (p.ph[i].OHt > OHt) OHt = p.ph[i].OHt;
         if (p.ph[i].OWt > OWt) OWt = p.ph[i].OWt;
     }
-    const int wbytes = 2 * bm * Cfg::PITCH;
-    if (!choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, Cfg::PITCH, wbytes, 64 * 1024, p.TH, p.TW, p.NI))
+    const int wbytes = 512 + 2 * bm * PITCH;
+    int maxtaps = 1;
+    for (int i = 0; i < p.nphase; ++i) if (p.ph[i].ntaps > maxtaps) maxtaps = p.ph[i].ntaps;
+    if (!choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, 72 * 1024, p.TH, p.TW, p.NI, maxtaps))
         return HIFIC_ERR_UNSUPPORTED;
     p.tiles_n = cdiv(p.N, p.NI);
     long long wp_elems = 0;
@@ -575,7 +631,7 @@ static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, lon
         wp_elems += (long long)p.Kpad * ph.ntaps * p.Cpad;
         int nt = p.tiles_n * ph.tiles_y * ph.tiles_x;
         if (nt > max_tiles) max_tiles = nt;
-        size_t b = (size_t)wbytes + (size_t)p.NI * ph.PH * ph.PW * Cfg::PITCH;
+        size_t b = (size_t)wbytes + (size_t)p.NI * ph.PH * ph.PW * PITCH;
         if (b > lds) lds = b;
     }
     if (lds > (size_t)kLdsBudget) return HIFIC_ERR_UNSUPPORTED;
@@ -601,7 +657,7 @@ static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, lon
     const int pslot = prof_open(bm == 128 ? PK_GCONV128 : (bm == 64 ? PK_GCONV64 : PK_GCONV32), aflops, st);
 #define GC_LAUNCH(WGM, WGN, WM, WN)                                                                      \
     do {                                                                                                 \
-        auto kfn = gconv_kernel<T, WGM, WGN, WM, WN>;                                                    \
+        auto kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN>;                                                \
         if (lds > 48 * 1024)                                                                             \
             hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);                                            \
@@ -612,6 +668,17 @@ static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, lon
 #undef GC_LAUNCH
     prof_close(pslot, st);
     return hific_launch_status();
+}
+
+template <typename T>
+static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
+                          long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+    if constexpr (std::is_same<T, float>::value) {
+        return launch_gconv_tb<float, 16>(p, w, w_scale, sm, sc, sr, ss, ws, st);
+    } else {
+        if (p.C <= 16) return launch_gconv_tb<bf16_t, 16>(p, w, w_scale, sm, sc, sr, ss, ws, st);
+        return launch_gconv_tb<bf16_t, 64>(p, w, w_scale, sm, sc, sr, ss, ws, st);
+    }
 }
 
 static int launch_gconv(GcParams& p, int dtype, const float* w, const float* w_scale, long long sm, long long sc,
@@ -780,11 +847,11 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
         if (gp.PW > span_x) span_x = gp.PW;
     }
     const int fixed = 512 + GC_NPIX * Cfg::PITCH;
-    if (!choose_tile(p.N, p.AH, p.AW, p.ist, span_y, span_x, Cfg::PITCH, fixed, 72 * 1024, p.TH, p.TW, p.NI))
-        return HIFIC_ERR_UNSUPPORTED;
-    if ((p.NI * p.TH * p.TW) % 16 != 0) {   // reduction granule of the bf16 MFMA
-        // tiny planes with tiny batch: widen the (masked) tile instead
-        while ((p.NI * p.TH * p.TW) % 16 != 0) { if (p.TW < 16) p.TW <<= 1; else p.TH <<= 1; }
+    if (!choose_tile(p.N, p.AH, p.AW, p.ist, span_y, span_x, Cfg::PITCH, fixed, 72 * 1024, p.TH, p.TW, p.NI,
+                     p.ntaps < GC_TG ? p.ntaps : GC_TG, true)) {
+        // tiny odd planes: fall back to a (masked) 16-pixel-multiple tile wider than the plane
+        p.TW = 16; p.TH = p.AH < 8 ? p.AH : 8; p.NI = 1;
+        while ((p.TH * p.TW) % 16 != 0) ++p.TH;
     }
     size_t lds = 0;
     for (int gi = 0; gi < p.ngroups; ++gi) {
