@@ -43,6 +43,9 @@ struct WgParams {
     const void* a;       // [N, M, AH, AW]   output-side operand (dY, or x for conv-transpose)
     const void* b;       // [N, C, BH, BW]   input-side operand, sampled at (u*ist+dy, v*ist+dx)
     float* ws;           // partials [nsplit][Mpad][ntaps][Cpad]
+    float* dw;           // final gradient (direct epilogue when nsplit == 1)
+    long long sm, sc, sr, ss;
+    int accumulate, direct;
     int N, M, C, AH, AW, BH, BW, Mpad, Cpad;
     int ist, bmode, a_f32, b_f32;
     int TH, TW, NI, tiles_y, tiles_x, tiles_n, ntiles, tiles_per_split, nsplit;

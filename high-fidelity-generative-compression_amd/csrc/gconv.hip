@@ -457,15 +457,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
         }
     }
 
-    // partials: ws[split][m][tap][c]
+    // single split: scatter straight into the PyTorch weight-gradient layout; else partials ws[split][m][tap][c]
 #pragma unroll
     for (int t = 0; t < GC_TG; ++t) {
         if (t < gp.ntaps) {
+            const int tg = gp.tap0 + t;
+            const long long toff_w = p.direct ? (long long)p.tap_r[tg] * p.sr + (long long)p.tap_s[tg] * p.ss : 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const int c = c0 + wn * 32 + l31;
-                p.ws[(((size_t)split * p.Mpad + m) * p.ntaps + (gp.tap0 + t)) * p.Cpad + c] = acc[t][r];
+                if (p.direct) {
+                    if (m < p.M && c < p.C) {
+                        float* d = p.dw + m * p.sm + c * p.sc + toff_w;
+                        if (p.accumulate) *d += acc[t][r]; else *d = acc[t][r];
+                    }
+                } else {
+                    p.ws[(((size_t)split * p.Mpad + m) * p.ntaps + tg) * p.Cpad + c] = acc[t][r];
+                }
             }
         }
     }
@@ -865,14 +874,19 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
     p.tiles_y = cdiv(p.AH, p.TH); p.tiles_x = cdiv(p.AW, p.TW); p.tiles_n = cdiv(p.N, p.NI);
     p.ntiles = p.tiles_n * p.tiles_y * p.tiles_x;
     const int base_blocks = (p.Mpad / 64) * (p.Cpad / 64) * p.ngroups;
-    int nsplit = cdiv(768, base_blocks);
+    // enough (m,c,tap-group) tiles to fill the chip: no pixel split, epilogue writes the final layout directly
+    int nsplit = base_blocks >= env_int("HIFIC_WG_NOSPLIT", 160) ? 1 : cdiv(768, base_blocks);
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     if (nsplit < 1) nsplit = 1;
     p.tiles_per_split = cdiv(p.ntiles, nsplit);
     p.nsplit = cdiv(p.ntiles, p.tiles_per_split);
-    const size_t wsb = (size_t)p.nsplit * p.Mpad * p.ntaps * p.Cpad * sizeof(float);
-    p.ws = (float*)ws.take(wsb);
-    if (!p.ws) return HIFIC_ERR_WS;
+    p.direct = p.nsplit == 1;
+    p.dw = dw; p.sm = sm; p.sc = sc; p.sr = sr; p.ss = ss; p.accumulate = accumulate;
+    if (!p.direct) {
+        const size_t wsb = (size_t)p.nsplit * p.Mpad * p.ntaps * p.Cpad * sizeof(float);
+        p.ws = (float*)ws.take(wsb);
+        if (!p.ws) return HIFIC_ERR_WS;
+    }
     dim3 grid((p.Mpad / 64) * (p.Cpad / 64), p.ngroups, p.nsplit);
     auto kfn = wgrad_kernel<T>;
     if (lds > 48 * 1024)
@@ -881,7 +895,7 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
     prof_close(pslot, st);
     int rc = hific_launch_status();
-    if (rc != HIFIC_OK) return rc;
+    if (rc != HIFIC_OK || p.direct) return rc;
     long long total = (long long)p.M * p.C * p.ntaps;
     int gx = (int)((total + 255) / 256); if (gx > 8192) gx = 8192;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(gx), dim3(256), 0, st, p, dw, sm, sc, sr, ss, accumulate);

@@ -5,72 +5,128 @@
 // 128 B (bf16) / 256 B (f32) coalesced run; the three channel passes after the first hit L2.
 #include "common.h"
 
-template <typename T>
-__global__ __launch_bounds__(256) void cn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, T* __restrict__ y,
-                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     int C, int HW, float eps, int relu) {
-    __shared__ float red[4][64];
+// Workgroup = 64 consecutive pixels x all C channels, NW waves: wave w owns channels w, w+NW, ...  Loads are issued
+// 8 at a time per thread (clamped index + select instead of branches) so that the three channel passes are
+// bandwidth- rather than latency-bound; NW is chosen from C so small planes (16x16 x 960 ch) still fill the chip.
+#define CN_U 8
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void cn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         int C, int HW, float eps, int relu) {
+    __shared__ float red[NW][64];
     const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int n = blockIdx.y;
-    const int hw = blockIdx.x * 64 + px;
-    const bool ok = hw < HW;
+    const int hw0 = blockIdx.x * 64 + px;
+    const bool ok = hw0 < HW;
+    const int hw = ok ? hw0 : HW - 1;
     const T* xp = x + (size_t)n * C * HW + hw;
     float s = 0.f;
-    if (ok) for (int c = cg; c < C; c += 4) s += DT<T>::ld(xp + (size_t)c * HW);
+    for (int c = cg; c < C; c += NW * CN_U) {
+        float v[CN_U];
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) { const int cc = c + k * NW; v[k] = DT<T>::ld(xp + (size_t)(cc < C ? cc : C - 1) * HW); }
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) s += (c + k * NW < C) ? v[k] : 0.f;
+    }
     red[cg][px] = s;
     __syncthreads();
-    const float mu = (red[0][px] + red[1][px] + red[2][px] + red[3][px]) / (float)C;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w][px];
+    const float mu = tot / (float)C;
     __syncthreads();
-    float v = 0.f;
-    if (ok) for (int c = cg; c < C; c += 4) { float d = DT<T>::ld(xp + (size_t)c * HW) - mu; v += d * d; }
-    red[cg][px] = v;
+    float q = 0.f;
+    for (int c = cg; c < C; c += NW * CN_U) {
+        float v[CN_U];
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) { const int cc = c + k * NW; v[k] = DT<T>::ld(xp + (size_t)(cc < C ? cc : C - 1) * HW); }
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) { const float d = v[k] - mu; q += (c + k * NW < C) ? d * d : 0.f; }
+    }
+    red[cg][px] = q;
     __syncthreads();
-    const float var = (red[0][px] + red[1][px] + red[2][px] + red[3][px]) / (float)(C - 1);
+    float tq = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tq += red[w][px];
+    const float var = tq / (float)(C - 1);
     const float r = rsqrtf(var + eps);
-    if (ok) {
-        if (cg == 0) { mean_out[(size_t)n * HW + hw] = mu; rstd_out[(size_t)n * HW + hw] = r; }
-        T* yp = y + (size_t)n * C * HW + hw;
-        for (int c = cg; c < C; c += 4) {
-            float o = gamma[c] * ((DT<T>::ld(xp + (size_t)c * HW) - mu) * r) + beta[c];
-            if (relu) o = o > 0.f ? o : 0.f;
-            DT<T>::st(yp + (size_t)c * HW, o);
+    if (ok && cg == 0) { mean_out[(size_t)n * HW + hw] = mu; rstd_out[(size_t)n * HW + hw] = r; }
+    T* yp = y + (size_t)n * C * HW + hw;
+    for (int c = cg; c < C; c += NW * CN_U) {
+        float v[CN_U];
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) { const int cc = c + k * NW; v[k] = DT<T>::ld(xp + (size_t)(cc < C ? cc : C - 1) * HW); }
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) {
+            const int cc = c + k * NW;
+            if (ok && cc < C) {
+                float o = gamma[cc] * ((v[k] - mu) * r) + beta[cc];
+                if (relu) o = o > 0.f ? o : 0.f;
+                DT<T>::st(yp + (size_t)cc * HW, o);
+            }
         }
     }
 }
 
 // dx = r*(g - mean_c g) - d * (sum_c g*d) * r^3/(C-1),  g = dy*gamma (dy masked by the fused ReLU)
-template <typename T>
-__global__ __launch_bounds__(256) void cn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        T* __restrict__ dx, int C, int HW, int relu) {
-    __shared__ float red1[4][64], red2[4][64];
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void cn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            T* __restrict__ dx, int C, int HW, int relu) {
+    __shared__ float red1[NW][64], red2[NW][64];
     const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int n = blockIdx.y;
-    const int hw = blockIdx.x * 64 + px;
-    const bool ok = hw < HW;
+    const int hw0 = blockIdx.x * 64 + px;
+    const bool ok = hw0 < HW;
+    const int hw = ok ? hw0 : HW - 1;
     const size_t off = (size_t)n * C * HW + hw;
-    const float mu = ok ? mean[(size_t)n * HW + hw] : 0.f;
-    const float r = ok ? rstd[(size_t)n * HW + hw] : 0.f;
+    const float mu = mean[(size_t)n * HW + hw];
+    const float r = rstd[(size_t)n * HW + hw];
     float s1 = 0.f, s2 = 0.f;
-    if (ok) for (int c = cg; c < C; c += 4) {
-        const float d = DT<T>::ld(x + off + (size_t)c * HW) - mu;
-        float g = DT<T>::ld(dy + off + (size_t)c * HW);
-        if (relu && !(gamma[c] * (d * r) + beta[c] > 0.f)) g = 0.f;
-        g *= gamma[c];
-        s1 += g; s2 += g * d;
+    for (int c = cg; c < C; c += NW * CN_U) {
+        float xv[CN_U], gv[CN_U];
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) {
+            const int cc = c + k * NW; const size_t o = off + (size_t)(cc < C ? cc : C - 1) * HW;
+            xv[k] = DT<T>::ld(x + o); gv[k] = DT<T>::ld(dy + o);
+        }
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) {
+            const int cc = c + k * NW; const int ci = cc < C ? cc : C - 1;
+            const float d = xv[k] - mu;
+            float g = gv[k];
+            if (relu && !(gamma[ci] * (d * r) + beta[ci] > 0.f)) g = 0.f;
+            g *= gamma[ci];
+            if (cc < C) { s1 += g; s2 += g * d; }
+        }
     }
     red1[cg][px] = s1; red2[cg][px] = s2;
     __syncthreads();
-    const float S1 = (red1[0][px] + red1[1][px] + red1[2][px] + red1[3][px]) / (float)C;
-    const float S2 = (red2[0][px] + red2[1][px] + red2[2][px] + red2[3][px]) * r * r * r / (float)(C - 1);
-    if (ok) for (int c = cg; c < C; c += 4) {
-        const float d = DT<T>::ld(x + off + (size_t)c * HW) - mu;
-        float g = DT<T>::ld(dy + off + (size_t)c * HW);
-        if (relu && !(gamma[c] * (d * r) + beta[c] > 0.f)) g = 0.f;
-        g *= gamma[c];
-        DT<T>::st(dx + off + (size_t)c * HW, r * (g - S1) - d * S2);
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { t1 += red1[w][px]; t2 += red2[w][px]; }
+    const float S1 = t1 / (float)C;
+    const float S2 = t2 * r * r * r / (float)(C - 1);
+    for (int c = cg; c < C; c += NW * CN_U) {
+        float xv[CN_U], gv[CN_U];
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) {
+            const int cc = c + k * NW; const size_t o = off + (size_t)(cc < C ? cc : C - 1) * HW;
+            xv[k] = DT<T>::ld(x + o); gv[k] = DT<T>::ld(dy + o);
+        }
+#pragma unroll
+        for (int k = 0; k < CN_U; ++k) {
+            const int cc = c + k * NW;
+            if (ok && cc < C) {
+                const float d = xv[k] - mu;
+                float g = gv[k];
+                if (relu && !(gamma[cc] * (d * r) + beta[cc] > 0.f)) g = 0.f;
+                g *= gamma[cc];
+                DT<T>::st(dx + off + (size_t)cc * HW, r * (g - S1) - d * S2);
+            }
+        }
     }
 }
 
@@ -125,13 +181,13 @@ int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, 
                           int N, int C, int HW, float eps, int relu, int dtype, hipStream_t st) {
     if (C < 2 || N <= 0 || HW <= 0) return HIFIC_ERR_ARG;
     dim3 grid(cdiv(HW, 64), N);
-    if (dtype == HIFIC_F32)
-        hipLaunchKernelGGL(cn_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y,
-                           mean, rstd, C, HW, eps, relu);
-    else if (dtype == HIFIC_BF16)
-        hipLaunchKernelGGL(cn_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y,
-                           mean, rstd, C, HW, eps, relu);
+    const int nw = C >= 480 ? 16 : (C >= 200 ? 8 : 4);
+#define CN_FWD(TT, NWV) hipLaunchKernelGGL((cn_fwd_kernel<TT, NWV>), grid, dim3(NWV * 64), 0, st, (const TT*)x, gamma, \
+                                           beta, (TT*)y, mean, rstd, C, HW, eps, relu)
+    if (dtype == HIFIC_F32) { if (nw == 16) CN_FWD(float, 16); else if (nw == 8) CN_FWD(float, 8); else CN_FWD(float, 4); }
+    else if (dtype == HIFIC_BF16) { if (nw == 16) CN_FWD(bf16_t, 16); else if (nw == 8) CN_FWD(bf16_t, 8); else CN_FWD(bf16_t, 4); }
     else return HIFIC_ERR_ARG;
+#undef CN_FWD
     return hific_launch_status();
 }
 
@@ -153,17 +209,19 @@ int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, con
     if ((size_t)nsplit * 2 * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
     float* part = (float*)ws;
     dim3 grid(cdiv(HW, 64), N), pgrid(C, nsplit);
+    const int nw = C >= 480 ? 16 : (C >= 200 ? 8 : 4);
+#define CN_BWD(TT, NWV) hipLaunchKernelGGL((cn_bwd_dx_kernel<TT, NWV>), grid, dim3(NWV * 64), 0, st, (const TT*)x, \
+                                           (const TT*)dy, gamma, beta, mean, rstd, (TT*)dx, C, HW, relu)
     if (dtype == HIFIC_F32) {
-        hipLaunchKernelGGL(cn_bwd_dx_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, gamma,
-                           beta, mean, rstd, (float*)dx, C, HW, relu);
+        if (nw == 16) CN_BWD(float, 16); else if (nw == 8) CN_BWD(float, 8); else CN_BWD(float, 4);
         hipLaunchKernelGGL(cn_bwd_param_kernel<float>, pgrid, dim3(256), 0, st, (const float*)x, (const float*)dy,
                            gamma, beta, mean, rstd, part, N, C, HW, relu, nsplit);
     } else if (dtype == HIFIC_BF16) {
-        hipLaunchKernelGGL(cn_bwd_dx_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, gamma,
-                           beta, mean, rstd, (bf16_t*)dx, C, HW, relu);
+        if (nw == 16) CN_BWD(bf16_t, 16); else if (nw == 8) CN_BWD(bf16_t, 8); else CN_BWD(bf16_t, 4);
         hipLaunchKernelGGL(cn_bwd_param_kernel<bf16_t>, pgrid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
                            gamma, beta, mean, rstd, part, N, C, HW, relu, nsplit);
     } else return HIFIC_ERR_ARG;
+#undef CN_BWD
     hipLaunchKernelGGL(cn_bwd_param_reduce_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, part, dgamma, dbeta, C,
                        nsplit, accumulate);
     return hific_launch_status();

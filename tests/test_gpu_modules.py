@@ -139,8 +139,17 @@ def test_model_losses_and_grads_fp32(hific, dev, sd, gan):
     model.perceptual_loss.load_backbone_state_dict(bb)
     model = model.to(dev).train()
     lins = [getattr(model.perceptual_loss, f"lin{i}").cpu() for i in range(5)]
-    x = O.make_image(1, 2, 128, 128)
     nh, nl = O.make_noise(6, (2, 320, 2, 2)), O.make_noise(7, (2, 220, 8, 8))
+    # pick an input whose latents are not within f32 noise of a rounding tie (so index equality is well-posed)
+    for img_seed in range(1, 12):
+        x = O.make_image(img_seed, 2, 128, 128)
+        with torch.no_grad():
+            y0 = O.encoder_forward(sd, x)
+            h0 = O.hyperprior_forward(sd, y0, (128, 128), True, nh, nl)
+            fr = y0 - h0.latent_means + 0.5
+            fr = fr - torch.floor(fr)
+        if float(torch.minimum(fr, 1 - fr).min()) > 2e-5:
+            break
     noises = [nh.to(dev), nl.to(dev)]
     model.Hyperprior._draw_noise = lambda t: noises.pop(0)
     losses, inter = model(x.to(dev), train_generator=True, return_intermediates=True, writeout=False)
@@ -158,7 +167,21 @@ def test_model_losses_and_grads_fp32(hific, dev, sd, gan):
     assert abs(a - b) < 1e-3 * abs(b), (a, b)
     if gan:
         assert abs(float(losses["disc"]) - float(out["disc"])) < 1e-3 * abs(float(out["disc"]))
-    assert _relerr(inter.reconstruction.detach().float().cpu(), out["reconstruction"].detach()) < 1e-3
+    # quantised latents: integer-exact, except where the oracle's own value sits on a rounding tie (|frac-.5|<1e-4:
+    # f32 summation-order noise decides those on either side); the reconstruction is then checked against the
+    # oracle Generator run on the HIP path's latents
+    hi = out["hyperinfo"]
+    dec_h, dec_o = inter.latents_quantized.detach().cpu(), hi.decoded.detach()
+    flips = (dec_h - dec_o).abs() > 1e-3
+    rec_ref = out["reconstruction"].detach()
+    if flips.any():
+        frac = (out["y"].detach() - hi.latent_means.detach() + 0.5)
+        frac = frac - torch.floor(frac)
+        tie = torch.minimum(frac, 1 - frac)
+        print(f"rounding flips: {int(flips.sum())} of {flips.numel()}, max tie distance {float(tie[flips].max()):.2e}")
+        assert int(flips.sum()) <= 4 and float(tie[flips].max()) < 1e-4
+        rec_ref = O.generator_forward(sd, dec_h, N_RES)
+    assert _relerr(inter.reconstruction.detach().float().cpu(), rec_ref) < 1e-3
     params = dict(model.named_parameters())
     for k in watch:
         assert _relerr(params[k].grad.cpu(), sdr[k].grad) < 1e-2, k
