@@ -34,6 +34,7 @@ struct GcParams {
     int ist, ost, bmode, act, in_f32, out_f32;
     int TH, TW, NI, tiles_n;
     int nphase;
+    int dbg;             // ablation flags for micro-benchmarks (HIFIC_DBG; 0 in production)
     GcPhase ph[GC_MAXPH];
     short tap_dy[GC_MAXTAPS], tap_dx[GC_MAXTAPS];
     short tap_r[GC_MAXTAPS], tap_s[GC_MAXTAPS];
@@ -50,6 +51,7 @@ struct WgParams {
     int ist, bmode, a_f32, b_f32;
     int TH, TW, NI, tiles_y, tiles_x, tiles_n, ntiles, tiles_per_split, nsplit;
     int ntaps, ngroups;
+    int dbg;
     GcPhase grp[GC_MAXPH];
     short tap_dy[GC_MAXTAPS], tap_dx[GC_MAXTAPS];
     short tap_r[GC_MAXTAPS], tap_s[GC_MAXTAPS];

@@ -23,82 +23,116 @@ template <> struct GcCfg<float>  { static constexpr int KS = 2,  PAD = 4; };
 // bf16: one dword = channels (c0+2*dw, c0+2*dw+1); f32: one dword = channel c0+dw.
 // Consecutive threads take consecutive patch pixels => coalesced global reads along W.
 // ---------------------------------------------------------------------------------------------------
+// Element loads with 32-bit element offsets from a wave-uniform base (tensors on this path are < 2^31 elements):
+// one v_add per load instead of 64-bit address arithmetic + selects.
+template <bool F32SRC> struct SrcT;
+template <> struct SrcT<true>  { typedef float type; };
+template <> struct SrcT<false> { typedef bf16_t type; };
+
+// Loads the NDW dwords (channel pairs for bf16, single channels for f32) of one patch pixel into raw registers.
+//   full: the whole chunk [c0, c0+BC) is inside [0, C) -> no per-channel predicate
+template <typename T, int NDW, bool SF32>
+__device__ __forceinline__ void px_load(unsigned (&lo)[NDW], unsigned (&hi)[NDW], const void* src, unsigned qoff,
+                                        unsigned plane, int C, int c0, int wv, bool full) {
+    if constexpr (std::is_same<T, float>::value) {
+        const float* sp = (const float*)src;
+        unsigned off = qoff + (unsigned)(c0 + wv) * plane;
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) {
+            const bool okc = full || (c0 + wv + 4 * i < C);
+            lo[i] = __float_as_uint(sp[okc ? off : 0u]);
+            hi[i] = okc ? 1u : 0u;
+            off += 4u * plane;
+        }
+    } else {
+        typedef typename SrcT<SF32>::type S;
+        const S* sp = (const S*)src;
+        unsigned off = qoff + (unsigned)(c0 + 2 * wv) * plane;
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) {
+                if constexpr (SF32) { lo[i] = __float_as_uint(sp[off]); hi[i] = __float_as_uint(sp[off + plane]); }
+                else { lo[i] = sp[off]; hi[i] = sp[off + plane]; }
+                off += 8u * plane;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) {
+                const int c = c0 + 2 * (wv + 4 * i);
+                const unsigned o0 = c < C ? off : 0u, o1 = c + 1 < C ? off + plane : 0u;
+                unsigned l, h;
+                if constexpr (SF32) { l = __float_as_uint(sp[o0]); h = __float_as_uint(sp[o1]); }
+                else { l = sp[o0]; h = sp[o1]; }
+                // zero out-of-range channels now (bf16 zero == f32 zero bit pattern)
+                lo[i] = c < C ? l : 0u; hi[i] = c + 1 < C ? h : 0u;
+                off += 8u * plane;
+            }
+        }
+    }
+}
+// Packs and writes one pixel row; ok=false writes zeros (padding / masked pixels)
+template <typename T, int NDW, bool SF32>
+__device__ __forceinline__ void px_store(unsigned char* row, const unsigned (&lo)[NDW], const unsigned (&hi)[NDW],
+                                         bool ok) {
+#pragma unroll
+    for (int i = 0; i < NDW; ++i) {
+        unsigned v;
+        if constexpr (std::is_same<T, float>::value) {
+            v = (ok && hi[i]) ? lo[i] : 0u;
+        } else {
+            unsigned l = lo[i], h = hi[i];
+            if constexpr (SF32) { l = f2bf(__uint_as_float(l)); h = f2bf(__uint_as_float(h)); }
+            v = ok ? (l | (h << 16)) : 0u;
+        }
+        *(unsigned*)(row + i * 16) = v;
+    }
+}
+// Decode patch pixel q -> element offset of channel 0 (0 when outside) and validity
+__device__ __forceinline__ void px_decode(int q, int npatch, int npp, int PW, float inv_npp, float inv_pw, int n0, int y0,
+                                          int x0, int N, int C, int H, int W, int bmode, unsigned& qoff, bool& ok) {
+    const int img = (int)(((float)q + 0.5f) * inv_npp);          // exact for q < 2^22
+    const int r = q - img * npp;
+    const int py = (int)(((float)r + 0.5f) * inv_pw);
+    const int px = r - py * PW;
+    int iy = y0 + py, ix = x0 + px;
+    const int n = n0 + img;
+    if (bmode == PAD_REFLECT) { iy = reflect_idx(iy, H); ix = reflect_idx(ix, W); }
+    ok = (q < npatch) && (n < N) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+    qoff = ok ? ((unsigned)n * (unsigned)C * (unsigned)(H * W) + (unsigned)iy * (unsigned)W + (unsigned)ix) : 0u;
+}
+
+template <typename T, int DWR, int PITCH, bool SF32>
+__device__ __forceinline__ void stage_T_impl(unsigned char* lds, const void* src, int N, int C, int H, int W, int bmode,
+                                             int n0, int NI, int y0, int x0, int PH, int PW, int c0, int tid) {
+    // Thread (lane, wave) handles patch pixels q = lane + 64*j and dwords dw = wave + 4*i: the pixel is decoded once
+    // and all DWR/4 channel loads of it are issued back-to-back; lanes run along W so every channel row is a
+    // coalesced run.
+    static_assert(DWR % 4 == 0, "DWR");
+    constexpr int NDW = DWR / 4;
+    constexpr int BCH = std::is_same<T, float>::value ? DWR : DWR * 2;
+    const int npp = PH * PW;
+    const int npatch = NI * npp;
+    const unsigned plane = (unsigned)(H * W);
+    const int lane = tid & 63, wv = tid >> 6;
+    const float inv_npp = 1.0f / (float)npp, inv_pw = 1.0f / (float)PW;
+    const bool full = c0 + BCH <= C;
+    for (int q = lane; q < npatch; q += 64) {
+        unsigned qoff; bool ok;
+        px_decode(q, npatch, npp, PW, inv_npp, inv_pw, n0, y0, x0, N, C, H, W, bmode, qoff, ok);
+        unsigned lo[NDW], hi[NDW];
+        px_load<T, NDW, SF32>(lo, hi, src, qoff, plane, C, c0, wv, full);
+        px_store<T, NDW, SF32>(lds + (size_t)q * PITCH + wv * 4, lo, hi, ok);
+    }
+}
 template <typename T, int DWR, int PITCH>
 __device__ __forceinline__ void stage_T(unsigned char* lds, const void* src, int src_f32,
                                         int N, int C, int H, int W, int bmode,
                                         int n0, int NI, int y0, int x0, int ystep_unused, int PH, int PW,
                                         int c0, int tid, int nthreads) {
-    // Thread (lane, wave) handles patch pixels q = lane + 64*j and dwords dw = wave + 4*i: the pixel is decoded once
-    // and all DWR/4 channel loads of it are issued back-to-back (memory-level parallelism instead of one dependent
-    // 2-byte load at a time); lanes run along W so every channel row is a coalesced run.
-    static_assert(DWR % 4 == 0, "DWR");
-    constexpr int NDW = DWR / 4;
-    const int npp = PH * PW;
-    const int npatch = NI * npp;
-    const size_t plane = (size_t)H * W;
-    const int lane = tid & 63, wv = tid >> 6;
-    const float inv_npp = 1.0f / (float)npp, inv_pw = 1.0f / (float)PW;
-    for (int q = lane; q < npatch; q += 64) {
-        // exact for q < 2^22: (q + 0.5)/d never rounds across an integer
-        const int img = (int)(((float)q + 0.5f) * inv_npp);
-        const int r = q - img * npp;
-        const int py = (int)(((float)r + 0.5f) * inv_pw);
-        const int px = r - py * PW;
-        int iy = y0 + py, ix = x0 + px;
-        const int n = n0 + img;
-        if (bmode == PAD_REFLECT) { iy = reflect_idx(iy, H); ix = reflect_idx(ix, W); }
-        const bool ok = (n < N) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-        const size_t base = ok ? ((size_t)n * C * plane + (size_t)iy * W + ix) : 0;
-        // all loads are unconditional (invalid elements read element 0 and are zeroed by a select) so that the
-        // compiler can issue them back-to-back with a single wait
-        unsigned vals[NDW];
-        if constexpr (std::is_same<T, float>::value) {
-            const float* sp = (const float*)src;
-            float v[NDW];
-#pragma unroll
-            for (int i = 0; i < NDW; ++i) {
-                const int c = c0 + wv + 4 * i;
-                const bool okc = ok && c < C;
-                v[i] = sp[okc ? base + (size_t)c * plane : 0];
-                vals[i] = okc ? __float_as_uint(v[i]) : 0u;
-            }
-        } else if (src_f32) {
-            const float* sp = (const float*)src;
-            float lo[NDW], hi[NDW];
-#pragma unroll
-            for (int i = 0; i < NDW; ++i) {
-                const int c = c0 + 2 * (wv + 4 * i);
-                lo[i] = sp[(ok && c < C) ? base + (size_t)c * plane : 0];
-                hi[i] = sp[(ok && c + 1 < C) ? base + (size_t)(c + 1) * plane : 0];
-            }
-#pragma unroll
-            for (int i = 0; i < NDW; ++i) {
-                const int c = c0 + 2 * (wv + 4 * i);
-                const unsigned l = (ok && c < C) ? (unsigned)f2bf(lo[i]) : 0u;
-                const unsigned h = (ok && c + 1 < C) ? (unsigned)f2bf(hi[i]) : 0u;
-                vals[i] = l | (h << 16);
-            }
-        } else {
-            const bf16_t* sp = (const bf16_t*)src;
-            unsigned lo[NDW], hi[NDW];
-#pragma unroll
-            for (int i = 0; i < NDW; ++i) {
-                const int c = c0 + 2 * (wv + 4 * i);
-                lo[i] = sp[(ok && c < C) ? base + (size_t)c * plane : 0];
-                hi[i] = sp[(ok && c + 1 < C) ? base + (size_t)(c + 1) * plane : 0];
-            }
-#pragma unroll
-            for (int i = 0; i < NDW; ++i) {
-                const int c = c0 + 2 * (wv + 4 * i);
-                const unsigned l = (ok && c < C) ? lo[i] : 0u;
-                const unsigned h = (ok && c + 1 < C) ? hi[i] : 0u;
-                vals[i] = l | (h << 16);
-            }
-        }
-        unsigned char* row = lds + (size_t)q * PITCH + wv * 4;
-#pragma unroll
-        for (int i = 0; i < NDW; ++i) *(unsigned*)(row + i * 16) = vals[i];
-    }
+    if (std::is_same<T, float>::value || src_f32)
+        stage_T_impl<T, DWR, PITCH, true>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid);
+    else
+        stage_T_impl<T, DWR, PITCH, false>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -178,88 +212,99 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
     const unsigned char* wp_ph = (const unsigned char*)p.wp + (size_t)ph.wp_off * sizeof(T);
     const size_t wrow_bytes = (size_t)nt * p.Cpad * sizeof(T);   // one m-row of this phase
 
-    // weight-tile prefetch registers: loaded right after the barrier of step s for step s+1, written to the other
-    // LDS buffer after the MFMAs of step s (single call site each, so they stay in VGPRs)
+    // Weight tiles stream through a 2-deep LDS ring with a distance-2 register prefetch: at step s the loads of tile
+    // s+2 are issued right after the barrier and tile s+1 (loaded during step s-1) is written to the other LDS
+    // buffer after the MFMAs of step s, so every weight load has two full steps (~1000 MFMA cycles) to land.
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t wreg[NWP];
+    u32x4_t wA[NWP], wB[NWP];
     int wrow[NWP], wpart[NWP];
+    const unsigned char* wsrc[NWP];
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
         int piece = tid + i * 256;
         if (piece >= BM * PPR) piece = BM * PPR - 1;          // clamp (duplicate load) instead of a divergent branch
         wrow[i] = piece / PPR; wpart[i] = piece % PPR;
+        wsrc[i] = wp_ph + (size_t)(m0 + wrow[i]) * wrow_bytes + wpart[i] * 16;
     }
-    const unsigned char* wsrc[NWP];
-#pragma unroll
-    for (int i = 0; i < NWP; ++i) wsrc[i] = wp_ph + (size_t)(m0 + wrow[i]) * wrow_bytes + wpart[i] * 16;
+    // byte offset of tile s = (tap s % nt, chunk s / nt); s clamped to the last tile
+    auto tile_off = [&](int s_) -> size_t {
+        if (s_ >= nsteps) s_ = nsteps - 1;
+        const int c_ = s_ / nt, t_ = s_ - c_ * nt;
+        return ((size_t)t_ * p.Cpad + (size_t)c_ * BC) * sizeof(T);
+    };
+#define GC_WLOAD(R, S_)                                                                     \
+    do {                                                                                    \
+        const size_t off_ = tile_off(S_);                                                   \
+        _Pragma("unroll") for (int i = 0; i < NWP; ++i) R[i] = *(const u32x4_t*)(wsrc[i] + off_); \
+    } while (0)
+#define GC_WSTORE(R, BUF)                                                                   \
+    do {                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NWP; ++i) {                                   \
+            if (tid + i * 256 < BM * PPR) {                                                 \
+                unsigned char* d = (BUF) + wrow[i] * PITCH + wpart[i] * 16;                 \
+                if constexpr (PITCH % 16 == 0) { *(u32x4_t*)d = R[i]; }                     \
+                else { ((unsigned*)d)[0] = R[i].x; ((unsigned*)d)[1] = R[i].y;              \
+                       ((unsigned*)d)[2] = R[i].z; ((unsigned*)d)[3] = R[i].w; }            \
+            }                                                                               \
+        }                                                                                   \
+    } while (0)
+    // one GEMM step on the tile in `wb` with tap `t`
+#define GC_COMPUTE(wb, t)                                                                                       \
+    do {                                                                                                        \
+        const int toff = toffs[t];                                                                              \
+        const unsigned char* arow = (wb) + (wm * WM * 32 + l31) * PITCH;                                        \
+        _Pragma("unroll") for (int kk = 0; kk < BC / KS; ++kk) {                                                \
+            if constexpr (std::is_same<T, float>::value) {                                                      \
+                float a[WM], b[WN];                                                                             \
+                _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                               \
+                    a[mi] = *(const float*)(arow + mi * 32 * PITCH + (kk * 2 + lhi) * 4);                       \
+                _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                               \
+                    b[ni] = *(const float*)(patch + (size_t)(qb[ni] + toff) * PITCH + (kk * 2 + lhi) * 4);      \
+                _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                               \
+                    _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                           \
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0); \
+            } else {                                                                                            \
+                bf16x8_t a[WM], b[WN];                                                                          \
+                _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                               \
+                    a[mi] = *(const bf16x8_t*)(arow + mi * 32 * PITCH + kk * 32 + lhi * 16);                    \
+                _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                               \
+                    b[ni] = *(const bf16x8_t*)(patch + (size_t)(qb[ni] + toff) * PITCH + kk * 32 + lhi * 16);   \
+                _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                               \
+                    _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                           \
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0); \
+            }                                                                                                   \
+        }                                                                                                       \
+    } while (0)
+    // step s: RL = register set that receives tile s+2, RS = register set holding tile s+1
+#define GC_STEP(s, RL, RS)                                                                  \
+    do {                                                                                    \
+        if (t == 0 && !((p.dbg & 1) && chunk > 0)) {                                        \
+            __syncthreads();                                                                \
+            stage_T<T, DWR, PITCH>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode,    \
+                                   n0, p.NI, iy0, ix0, 0, PH, PW, chunk * BC, tid, 256);    \
+        }                                                                                   \
+        __syncthreads();                                                                    \
+        if (!(p.dbg & 4)) GC_WLOAD(RL, (s) + 2);                                            \
+        if (!(p.dbg & 2)) GC_COMPUTE(wbuf + ((s) & 1) * WBYTES, t);                         \
+        if (!(p.dbg & 4)) GC_WSTORE(RS, wbuf + (((s) + 1) & 1) * WBYTES);                   \
+        if (++t == nt) { t = 0; ++chunk; }                                                  \
+    } while (0)
 
     if (nsteps > 0) {
-#pragma unroll
-        for (int i = 0; i < NWP; ++i) wreg[i] = *(const u32x4_t*)(wsrc[i]);     // step 0: (tap 0, chunk 0)
-    }
-    int step = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();
-        stage_T<T, DWR, PITCH>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode,
-                              n0, p.NI, iy0, ix0, 0, PH, PW, chunk * BC, tid, 256);
-        for (int t = 0; t < nt; ++t, ++step) {
-            unsigned char* wb = wbuf + (step & 1) * WBYTES;
-#pragma unroll
-            for (int i = 0; i < NWP; ++i) {
-                if (tid + i * 256 < BM * PPR) {
-                    unsigned char* d = wb + wrow[i] * PITCH + wpart[i] * 16;
-                    if constexpr (PITCH % 16 == 0) {
-                        *(u32x4_t*)d = wreg[i];
-                    } else {
-                        ((unsigned*)d)[0] = wreg[i].x; ((unsigned*)d)[1] = wreg[i].y;
-                        ((unsigned*)d)[2] = wreg[i].z; ((unsigned*)d)[3] = wreg[i].w;
-                    }
-                }
-            }
-            __syncthreads();
-            {
-                // next step's (tap, chunk); the last step re-loads itself (valid address, value unused)
-                int tn = t + 1, cn = chunk;
-                if (tn == nt) { tn = 0; cn = chunk + 1; }
-                if (cn == nchunks) { tn = t; cn = chunk; }
-                const size_t off = ((size_t)tn * p.Cpad + (size_t)cn * BC) * sizeof(T);
-#pragma unroll
-                for (int i = 0; i < NWP; ++i) wreg[i] = *(const u32x4_t*)(wsrc[i] + off);
-            }
-            const int toff = toffs[t];
-            const unsigned char* arow = wb + (wm * WM * 32 + l31) * PITCH;
-#pragma unroll
-            for (int kk = 0; kk < BC / KS; ++kk) {
-                if constexpr (std::is_same<T, float>::value) {
-                    float a[WM], b[WN];
-#pragma unroll
-                    for (int mi = 0; mi < WM; ++mi)
-                        a[mi] = *(const float*)(arow + mi * 32 * PITCH + (kk * 2 + lhi) * 4);
-#pragma unroll
-                    for (int ni = 0; ni < WN; ++ni)
-                        b[ni] = *(const float*)(patch + (size_t)(qb[ni] + toff) * PITCH + (kk * 2 + lhi) * 4);
-#pragma unroll
-                    for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < WN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-                } else {
-                    bf16x8_t a[WM], b[WN];
-#pragma unroll
-                    for (int mi = 0; mi < WM; ++mi)
-                        a[mi] = *(const bf16x8_t*)(arow + mi * 32 * PITCH + kk * 32 + lhi * 16);
-#pragma unroll
-                    for (int ni = 0; ni < WN; ++ni)
-                        b[ni] = *(const bf16x8_t*)(patch + (size_t)(qb[ni] + toff) * PITCH + kk * 32 + lhi * 16);
-#pragma unroll
-                    for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < WN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-                }
-            }
+        GC_WLOAD(wA, 0);
+        GC_WLOAD(wB, 1);
+        GC_WSTORE(wA, wbuf);
+        int chunk = 0, t = 0, s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            GC_STEP(s, wA, wB);
+            GC_STEP(s + 1, wB, wA);
         }
+        if (s < nsteps) GC_STEP(s, wA, wB);
     }
+#undef GC_STEP
+#undef GC_COMPUTE
+#undef GC_WSTORE
+#undef GC_WLOAD
 
     // epilogue: bias + residual + activation, NCHW store (32 consecutive pixels per store instruction)
     const bool out_f32 = std::is_same<T, float>::value || p.out_f32;
@@ -480,6 +525,238 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Pipelined bf16 weight-gradient kernel (3x3 stride-1 class layers: TW % 8 == 0, AW % 8 == 0, patch <= 192 pixels).
+//   * dY operand in its natural NCHW order: [64 m][128 tile pixels] LDS image filled by 16-byte global loads
+//     (4 per thread per tile instead of 32 two-byte loads); its MFMA fragment is a plain ds_read_b128
+//   * x operand: transposed halo patch + ds_read_b64_tr_b16 as in wgrad_kernel
+//   * both LDS images are double-buffered; the next tile's data is prefetched into registers while the current
+//     tile's 72 MFMAs per wave run (patch in two halves to keep the prefetch at 24+16 VGPRs); one barrier per tile
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
+    constexpr int PITCH = 144, NDW = 8, QI = 3, HALF = 4;
+    constexpr int APITCH = GC_NPIX * 2 + 16;                       // 272 B per m row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int pwv = tid >> 6;
+
+    const GcPhase& gp = p.grp[blockIdx.y];
+    const int ctiles = p.Cpad / 64;
+    const int m0 = (blockIdx.x / ctiles) * 64;
+    const int c0 = (blockIdx.x % ctiles) * 64;
+    const int split = blockIdx.z;
+    const int PH = gp.PH, PW = gp.PW, npp = PH * PW;
+    const int npatch = p.NI * npp;
+    const size_t patch_bytes = ((size_t)npatch * PITCH + 15) & ~(size_t)15;
+    constexpr int ABYTES = 64 * APITCH;
+
+    int* qtab = (int*)smem;                                         // [128]
+    unsigned char* abuf = smem + 512;                               // 2 x ABYTES
+    unsigned char* pbuf = abuf + 2 * ABYTES;                        // 2 x patch_bytes
+
+    const int thw = p.TH * p.TW;
+    if (tid < GC_NPIX) {
+        const int img = tid / thw;
+        const int rem = tid - img * thw;
+        const int ty_ = rem / p.TW, tx_ = rem - ty_ * p.TW;
+        qtab[tid] = img * npp + ty_ * p.ist * PW + tx_ * p.ist;
+    }
+    int toffs[GC_TG];
+#pragma unroll
+    for (int t = 0; t < GC_TG; ++t) {
+        const int tt = t < gp.ntaps ? t : 0;
+        toffs[t] = ((int)p.tap_dy[gp.tap0 + tt] - gp.dy_min) * PW + ((int)p.tap_dx[gp.tap0 + tt] - gp.dx_min);
+    }
+    int toffb[GC_TG];
+#pragma unroll
+    for (int t = 0; t < GC_TG; ++t) toffb[t] = toffs[t] * PITCH;
+    // A pieces of this thread: piece = tid + 256*i -> (row m, 8-pixel segment); tile-independent part of the address
+    int a_img[4], a_ty[4], a_tx[4], a_row[4], a_seg[4];
+    unsigned a_rel[4];
+    const unsigned aplane = (unsigned)(p.AH * p.AW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = tid + 256 * i;
+        a_row[i] = piece >> 4; a_seg[i] = piece & 15;
+        const int r0 = a_seg[i] * 8;
+        a_img[i] = r0 / thw;
+        const int rem = r0 - a_img[i] * thw;
+        a_ty[i] = rem / p.TW; a_tx[i] = rem - a_ty[i] * p.TW;
+        a_rel[i] = (unsigned)(a_img[i] * p.M + m0 + a_row[i]) * aplane + (unsigned)(a_ty[i] * p.AW + a_tx[i]);
+    }
+    const bf16_t* asrc = (const bf16_t*)p.a;
+    const float inv_npp = 1.0f / (float)npp, inv_pw = 1.0f / (float)PW;
+    const unsigned bplane = (unsigned)(p.BH * p.BW);
+    const bool cfull = c0 + 64 <= p.C;
+
+    f32x16_t acc[GC_TG];
+#pragma unroll
+    for (int t = 0; t < GC_TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int tile_lo = split * p.tiles_per_split;
+    int tile_hi = tile_lo + p.tiles_per_split;
+    if (tile_hi > p.ntiles) tile_hi = p.ntiles;
+
+    u32x4_t areg[4]; unsigned aokm = 0;
+    unsigned plo[QI][NDW], phi[QI][NDW];
+    unsigned qoff[QI]; unsigned qokm = 0;
+
+#define WG_TILE_ORIGIN(tile_, n0_, u0_, v0_)                        \
+    const int tx_t = (tile_) % p.tiles_x;                           \
+    const int ty_t = ((tile_) / p.tiles_x) % p.tiles_y;             \
+    const int tn_t = (tile_) / (p.tiles_x * p.tiles_y);             \
+    const int u0_ = ty_t * p.TH, v0_ = tx_t * p.TW, n0_ = tn_t * p.NI;
+#define WG_LOAD_A(n0_, u0_, v0_)                                                                            \
+    do {                                                                                                    \
+        const unsigned tbase = (unsigned)(n0_ * p.M) * aplane + (unsigned)(u0_ * p.AW + v0_);               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+            const bool ok_ = (n0_ + a_img[i] < p.N) && (u0_ + a_ty[i] < p.AH) && (v0_ + a_tx[i] < p.AW) &&   \
+                     (m0 + a_row[i] < p.M) && (a_img[i] < p.NI);                                            \
+            aokm = (aokm & ~(1u << i)) | ((ok_ ? 1u : 0u) << i);                                            \
+            areg[i] = *(const u32x4_t*)(asrc + (ok_ ? tbase + a_rel[i] : 0u));                              \
+        }                                                                                                   \
+    } while (0)
+#define WG_STORE_A(buf_)                                                                                    \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+            u32x4_t v = areg[i];                                                                            \
+            if (!((aokm >> i) & 1u)) { v.x = 0; v.y = 0; v.z = 0; v.w = 0; }                                            \
+            *(u32x4_t*)((buf_) + a_row[i] * APITCH + a_seg[i] * 16) = v;                                    \
+        }                                                                                                   \
+    } while (0)
+#define WG_DECODE_P(n0_, u0_, v0_)                                                                          \
+    do {                                                                                                    \
+        qokm = 0;                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < QI; ++j) {                                                    \
+            bool ok_;                                                                                       \
+            px_decode(lane + 64 * j, npatch, npp, PW, inv_npp, inv_pw, n0_, u0_ * p.ist + gp.dy_min,        \
+                      v0_ * p.ist + gp.dx_min, p.N, p.C, p.BH, p.BW, p.bmode, qoff[j], ok_);                \
+            qokm |= (ok_ ? 1u : 0u) << j;                                                                   \
+        }                                                                                                   \
+    } while (0)
+    // half h of the patch dwords: i in [h*HALF, h*HALF+HALF)
+#define WG_LOAD_P(h)                                                                                        \
+    do {                                                                                                    \
+        const bf16_t* sp = (const bf16_t*)p.b;                                                              \
+        _Pragma("unroll") for (int j = 0; j < QI; ++j) {                                                    \
+            _Pragma("unroll") for (int ii = 0; ii < HALF; ++ii) {                                           \
+                const int i = (h) * HALF + ii;                                                              \
+                const int c = c0 + 2 * (pwv + 4 * i);                                                       \
+                const unsigned off = qoff[j] + (unsigned)c * bplane;                                        \
+                const bool k0 = cfull || c < p.C, k1 = cfull || c + 1 < p.C;                                \
+                plo[j][i] = sp[k0 ? off : 0u];                                                              \
+                phi[j][i] = sp[k1 ? off + bplane : 0u];                                                     \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+#define WG_STORE_P(buf_, h)                                                                                 \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < QI; ++j) {                                                    \
+            const int q = lane + 64 * j;                                                                    \
+            if (q < npatch) {                                                                               \
+                unsigned char* row = (buf_) + (size_t)q * PITCH + pwv * 4;                                  \
+                _Pragma("unroll") for (int ii = 0; ii < HALF; ++ii) {                                       \
+                    const int i = (h) * HALF + ii;                                                          \
+                    const int c = c0 + 2 * (pwv + 4 * i);                                                   \
+                    const unsigned l = (((qokm >> j) & 1u) && (cfull || c < p.C)) ? plo[j][i] : 0u;                     \
+                    const unsigned hh = (((qokm >> j) & 1u) && (cfull || c + 1 < p.C)) ? phi[j][i] : 0u;                \
+                    *(unsigned*)(row + i * 16) = l | (hh << 16);                                            \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+#define WG_COMPUTE(ab_, pb_, ks_lo, ks_hi)                                                                  \
+    do {                                                                                                    \
+        const int g = lane >> 4, i16 = lane & 15;                                                           \
+        const int colb = ((g & 1) * 16 + (i16 & 3) * 4) * 2;                                                \
+        typedef __attribute__((address_space(3))) short4_t* lds_s4;                                         \
+        typedef __attribute__((ext_vector_type(8))) short short8_t;                                         \
+        for (int ks = (ks_lo); ks < (ks_hi); ++ks) {                                                        \
+            const bf16x8_t a = *(const bf16x8_t*)((ab_) + (wm * 32 + l31) * APITCH + (ks * 16 + lhi * 8) * 2); \
+            const int rb = ks * 16 + (g >> 1) * 8 + (i16 >> 2);                                             \
+            const unsigned char* b0row = (pb_) + (size_t)qtab[rb] * PITCH + wn * 64 + colb;                 \
+            const unsigned char* b1row = (pb_) + (size_t)qtab[rb + 4] * PITCH + wn * 64 + colb;             \
+            /* all GC_TG taps unconditionally (taps beyond ntaps alias tap 0, their accumulators are dropped): */ \
+            /* straight-line code lets the compiler issue the 18 LDS reads ahead of the 9 independent MFMAs */   \
+            short4_t b0[GC_TG], b1[GC_TG];                                                                  \
+            _Pragma("unroll") for (int t = 0; t < GC_TG; ++t) {                                             \
+                b0[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b0row + toffb[t]));                \
+                b1[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b1row + toffb[t]));                \
+            }                                                                                               \
+            _Pragma("unroll") for (int t = 0; t < GC_TG; ++t) {                                             \
+                short8_t bv = {b0[t][0], b0[t][1], b0[t][2], b0[t][3], b1[t][0], b1[t][1], b1[t][2], b1[t][3]}; \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, bv), acc[t], 0, 0, 0); \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+
+    if (tile_lo < tile_hi) {
+        {
+            WG_TILE_ORIGIN(tile_lo, n0, u0, v0)
+            WG_LOAD_A(n0, u0, v0);
+            WG_DECODE_P(n0, u0, v0);
+            WG_LOAD_P(0); WG_LOAD_P(1);
+            WG_STORE_A(abuf);
+            WG_STORE_P(pbuf, 0); WG_STORE_P(pbuf, 1);
+        }
+        for (int tile = tile_lo; tile < tile_hi; ++tile) {
+            const int cur = (tile - tile_lo) & 1;
+            unsigned char* ab = abuf + cur * ABYTES;
+            unsigned char* pb = pbuf + cur * patch_bytes;
+            unsigned char* abn = abuf + (cur ^ 1) * ABYTES;
+            unsigned char* pbn = pbuf + (cur ^ 1) * patch_bytes;
+            const bool more = (tile + 1 < tile_hi) && !(p.dbg & 1);
+            __syncthreads();
+            if (more) {
+                WG_TILE_ORIGIN(tile + 1, n0, u0, v0)
+                WG_LOAD_A(n0, u0, v0);
+                WG_DECODE_P(n0, u0, v0);
+                WG_LOAD_P(0);
+            }
+            if (!(p.dbg & 2)) WG_COMPUTE(ab, pb, 0, GC_NPIX / 32);
+            if (more) { WG_STORE_P(pbn, 0); WG_LOAD_P(1); }
+            if (!(p.dbg & 2)) WG_COMPUTE(ab, pb, GC_NPIX / 32, GC_NPIX / 16);
+            if (more) { WG_STORE_A(abn); WG_STORE_P(pbn, 1); }
+        }
+    }
+#undef WG_COMPUTE
+#undef WG_STORE_P
+#undef WG_LOAD_P
+#undef WG_DECODE_P
+#undef WG_STORE_A
+#undef WG_LOAD_A
+#undef WG_TILE_ORIGIN
+
+#pragma unroll
+    for (int t = 0; t < GC_TG; ++t) {
+        if (t < gp.ntaps) {
+            const int tg = gp.tap0 + t;
+            const long long toff_w = p.direct ? (long long)p.tap_r[tg] * p.sr + (long long)p.tap_s[tg] * p.ss : 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int c = c0 + wn * 32 + l31;
+                if (p.direct) {
+                    if (m < p.M && c < p.C) {
+                        float* d = p.dw + m * p.sm + c * p.sc + toff_w;
+                        if (p.accumulate) *d += acc[t][r]; else *d = acc[t][r];
+                    }
+                } else {
+                    p.ws[(((size_t)split * p.Mpad + m) * p.ntaps + tg) * p.Cpad + c] = acc[t][r];
+                }
+            }
+        }
+    }
+}
+
 // dw[m*sm + c*sc + r*sr + s*ss] (=|+=) sum_split ws[split][m][t][c]
 __global__ void wgrad_finalize_kernel(const WgParams p, float* __restrict__ dw, long long sm, long long sc,
                                       long long sr, long long ss, int accumulate) {
@@ -612,6 +889,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     }
     p.Kpad = cdiv(p.K, bm) * bm;
     p.Cpad = cdiv(p.C, BC) * BC;
+    p.dbg = env_int("HIFIC_DBG", 0);
     // tile shape: common to all phases (largest span decides)
     int span_y = 1, span_x = 1, OHt = 1, OWt = 1;
     for (int i = 0; i < p.nphase; ++i) {
@@ -835,6 +1113,7 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
                           int accumulate, WsAlloc& ws, hipStream_t st) {
     using Cfg = WgCfg<T>;
     p.Mpad = cdiv(p.M, 64) * 64; p.Cpad = cdiv(p.C, 64) * 64;
+    p.dbg = env_int("HIFIC_DBG", 0);
     // tap groups of <= GC_TG consecutive taps
     p.ngroups = cdiv(p.ntaps, GC_TG);
     if (p.ngroups > GC_MAXPH) return HIFIC_ERR_UNSUPPORTED;
@@ -888,11 +1167,28 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
         if (!p.ws) return HIFIC_ERR_WS;
     }
     dim3 grid((p.Mpad / 64) * (p.Cpad / 64), p.ngroups, p.nsplit);
-    auto kfn = wgrad_kernel<T>;
-    if (lds > 48 * 1024)
-        hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int pslot = prof_open(PK_WGRAD, 2.0 * p.M * p.C * p.ntaps * (double)p.N * p.AH * p.AW, st);
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+    bool pipe = false;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        int npatch_max = 0;
+        for (int gi = 0; gi < p.ngroups; ++gi) {
+            int np_ = p.NI * p.grp[gi].PH * p.grp[gi].PW;
+            if (np_ > npatch_max) npatch_max = np_;
+        }
+        const size_t lds_pipe = 512 + 2 * (size_t)64 * (GC_NPIX * 2 + 16) + 2 * (((size_t)npatch_max * 144 + 15) & ~(size_t)15);
+        pipe = !p.a_f32 && !p.b_f32 && p.NI * p.TH * p.TW == GC_NPIX && p.TW % 8 == 0 && p.AW % 8 == 0 &&
+               npatch_max <= 192 && lds_pipe <= (size_t)kLdsBudget && !env_int("HIFIC_NO_WGPIPE", 0);
+        if (pipe) {
+            hipFuncSetAttribute((const void*)wgrad_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
+            hipLaunchKernelGGL(wgrad_pipe_kernel, grid, dim3(256), lds_pipe, st, p);
+        }
+    }
+    if (!pipe) {
+        auto kfn = wgrad_kernel<T>;
+        if (lds > 48 * 1024)
+            hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+    }
     prof_close(pslot, st);
     int rc = hific_launch_status();
     if (rc != HIFIC_OK || p.direct) return rc;
