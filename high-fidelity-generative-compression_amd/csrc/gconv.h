@@ -52,6 +52,8 @@ struct WgParams {
     int TH, TW, NI, tiles_y, tiles_x, tiles_n, ntiles, tiles_per_split, nsplit;
     int ntaps, ngroups;
     int dbg;
+    // small-channel (im2col) mode: virtual columns j = tap*4 + c; see wgrad_im2col_kernel
+    int im2col, creal, ntaps_real, tsign, swap_out, a_bmode, a_y0, a_x0, a_h, a_w, b_y0, b_x0;
     GcPhase grp[GC_MAXPH];
     short tap_dy[GC_MAXTAPS], tap_dx[GC_MAXTAPS];
     short tap_r[GC_MAXTAPS], tap_s[GC_MAXTAPS];

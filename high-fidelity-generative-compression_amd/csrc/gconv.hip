@@ -460,13 +460,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
                 const int r = ks * 2 + lhi;
                 const float a = *(const float*)(at + (size_t)r * PITCH + (wm * 32 + l31) * 4);
                 const unsigned char* brow = patch + (size_t)qtab[r] * PITCH + (wn * 32 + l31) * 4;
+                // all GC_TG taps unconditionally (taps beyond ntaps alias tap 0 and are dropped in the epilogue)
+                float bb[GC_TG];
 #pragma unroll
-                for (int t = 0; t < GC_TG; ++t) {
-                    if (t < gp.ntaps) {
-                        const float b = *(const float*)(brow + (size_t)toffs[t] * PITCH);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                    }
-                }
+                for (int t = 0; t < GC_TG; ++t) bb[t] = *(const float*)(brow + (size_t)toffs[t] * PITCH);
+#pragma unroll
+                for (int t = 0; t < GC_TG; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[t], acc[t], 0, 0, 0);
             } else {
                 // ds_read_b64_tr_b16: each 16-lane group reads a [4 rows][16 cols] bf16 block; lane i supplies the
                 // address of row (i>>2), col chunk (i&3)*4 and receives column i of the 4 rows.
@@ -487,16 +486,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
                 const int q0 = qtab[rb], q1 = qtab[rb + 4];
                 const unsigned char* b0row = patch + (size_t)q0 * PITCH + wn * 64 + colb;
                 const unsigned char* b1row = patch + (size_t)q1 * PITCH + wn * 64 + colb;
+                typedef __attribute__((ext_vector_type(8))) short short8_t;
+                short4_t b0[GC_TG], b1[GC_TG];
 #pragma unroll
                 for (int t = 0; t < GC_TG; ++t) {
-                    if (t < gp.ntaps) {
-                        short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b0row + (size_t)toffs[t] * PITCH));
-                        short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b1row + (size_t)toffs[t] * PITCH));
-                        typedef __attribute__((ext_vector_type(8))) short short8_t;
-                        short8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                        bf16x8_t b = __builtin_bit_cast(bf16x8_t, bv);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-                    }
+                    b0[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b0row + (size_t)toffs[t] * PITCH));
+                    b1[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b1row + (size_t)toffs[t] * PITCH));
+                }
+#pragma unroll
+                for (int t = 0; t < GC_TG; ++t) {
+                    short8_t bv = {b0[t][0], b0[t][1], b0[t][2], b0[t][3], b1[t][0], b1[t][1], b1[t][2], b1[t][3]};
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, bv), acc[t], 0, 0, 0);
                 }
             }
         }
@@ -754,6 +754,142 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Small-channel weight gradient (one operand has <= 4 channels: the first Encoder conv 3->60 and the last Generator
+// conv 60->3, both 7x7).  Padding 3 channels to a 64-wide MFMA tile wastes 95% of the work, so the taps are folded
+// into the GEMM column dimension instead: column j = tap*4 + c, B image [tile pixel][64 columns] is an im2col slice
+// gathered straight from global memory (the small operand is L2 resident), one accumulator tile per wave.
+//   normal  : D[m][(t,c)]  = sum_pix A[m][pix] * B[c][pix + tap_t]         (A = dY, B = x with reflect/zero pad)
+//   swapped : D[c][(t,m)]  = sum_pix' A'[c][pix'] * B'[m][pix' - tap_t]    (A' = padded x over the padded domain,
+//             B' = dY zero outside) -- used when dY is the small operand
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
+    using Cfg = WgCfg<T>;
+    constexpr int PITCH = Cfg::PITCH, KS = Cfg::KS, DWR = Cfg::DWR, NDW = DWR / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wv = tid >> 6;
+    const int ctiles = p.Cpad / 64;
+    const int m0 = (blockIdx.x / ctiles) * 64;
+    const int c0 = (blockIdx.x % ctiles) * 64;       // first virtual column of this block
+    const int split = blockIdx.z;
+    const int npix = p.NI * p.TH * p.TW;
+    unsigned char* at = smem;                                  // [128][PITCH]  A^T image
+    unsigned char* bt = smem + (size_t)GC_NPIX * PITCH;        // [128][PITCH]  im2col image
+    const int thw = p.TH * p.TW;
+    const float inv_thw = 1.0f / (float)thw, inv_tw = 1.0f / (float)p.TW;
+    const unsigned bplane = (unsigned)(p.BH * p.BW);
+
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int tile_lo = split * p.tiles_per_split;
+    int tile_hi = tile_lo + p.tiles_per_split;
+    if (tile_hi > p.ntiles) tile_hi = p.ntiles;
+
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        const int tx = tile % p.tiles_x;
+        const int ty = (tile / p.tiles_x) % p.tiles_y;
+        const int tn = tile / (p.tiles_x * p.tiles_y);
+        const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
+        __syncthreads();
+        // A^T: the tile itself, sampled at (u + a_y0, v + a_x0) of the source tensor [N, M, a_h, a_w].  Pixels of
+        // the tile that lie outside the (padded) domain must contribute nothing: they are zeroed via the B image.
+        stage_T<T, DWR, PITCH>(at, p.a, p.a_f32, p.N, p.M, p.a_h, p.a_w, p.a_bmode, n0, p.NI, u0 + p.a_y0,
+                               v0 + p.a_x0, 0, p.TH, p.TW, m0, tid, 256);
+        // im2col slice: rows = tile pixels, dword dw = wv + 4*i covers columns (c0 + 2*dw, c0 + 2*dw + 1)
+        for (int q = lane; q < npix; q += 64) {
+            const int img = (int)(((float)q + 0.5f) * inv_thw);
+            const int rem = q - img * thw;
+            const int tyy = (int)(((float)rem + 0.5f) * inv_tw);
+            const int txx = rem - tyy * p.TW;
+            const int n = n0 + img, ud = u0 + tyy, vd = v0 + txx;
+            const bool pix_ok = (n < p.N) && (ud < p.AH) && (vd < p.AW);
+            float vals[NDW][2];
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int col = c0 + (std::is_same<T, float>::value ? (wv + 4 * i) : 2 * (wv + 4 * i) + e);
+                    const int t = col >> 2, cc = col & 3;
+                    const int tt = t < p.ntaps_real ? t : 0;
+                    int yb = ud + p.b_y0 + p.tsign * (int)p.tap_dy[tt];
+                    int xb = vd + p.b_x0 + p.tsign * (int)p.tap_dx[tt];
+                    if (p.bmode == PAD_REFLECT) { yb = reflect_idx(yb, p.BH); xb = reflect_idx(xb, p.BW); }
+                    const bool ok = pix_ok && t < p.ntaps_real && cc < p.creal && (unsigned)yb < (unsigned)p.BH &&
+                                    (unsigned)xb < (unsigned)p.BW;
+                    const unsigned off = ok ? ((unsigned)(n * p.creal + cc) * bplane + (unsigned)(yb * p.BW + xb)) : 0u;
+                    float v;
+                    if (std::is_same<T, float>::value || p.b_f32) v = ((const float*)p.b)[off];
+                    else v = bf2f(((const bf16_t*)p.b)[off]);
+                    vals[i][e] = ok ? v : 0.f;
+                    if (std::is_same<T, float>::value) break;
+                }
+            }
+            unsigned char* row = bt + (size_t)q * PITCH + wv * 4;
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) {
+                unsigned w;
+                if constexpr (std::is_same<T, float>::value) w = __float_as_uint(vals[i][0]);
+                else w = (unsigned)f2bf(vals[i][0]) | ((unsigned)f2bf(vals[i][1]) << 16);
+                *(unsigned*)(row + i * 16) = w;
+            }
+        }
+        __syncthreads();
+        for (int ks = 0; ks < npix / KS; ++ks) {
+            if constexpr (std::is_same<T, float>::value) {
+                const int r = ks * 2 + lhi;
+                const float a = *(const float*)(at + (size_t)r * PITCH + (wm * 32 + l31) * 4);
+                const float b = *(const float*)(bt + (size_t)r * PITCH + (wn * 32 + l31) * 4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            } else {
+                const int g = lane >> 4, i16 = lane & 15;
+                const int rb = ks * 16 + (g >> 1) * 8 + (i16 >> 2);
+                const int colb = ((g & 1) * 16 + (i16 & 3) * 4) * 2;
+                typedef __attribute__((address_space(3))) short4_t* lds_s4;
+                typedef __attribute__((ext_vector_type(8))) short short8_t;
+                short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(at + (size_t)rb * PITCH + wm * 64 + colb));
+                short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(at + (size_t)(rb + 4) * PITCH + wm * 64 + colb));
+                short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(bt + (size_t)rb * PITCH + wn * 64 + colb));
+                short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(bt + (size_t)(rb + 4) * PITCH + wn * 64 + colb));
+                short8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                short8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av),
+                                                              __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int c = c0 + wn * 32 + l31;
+        p.ws[((size_t)split * p.Mpad + m) * p.Cpad + c] = acc[r];
+    }
+}
+
+// im2col-mode finalize: dw[md*sm + cd*sc + r*sr + s*ss] (=|+=) sum_split ws[split][row][t*4 + col4]
+//   normal: row = md (dY channel), col4 = cd;  swapped: row = cd (x channel), col4 = md
+__global__ void wgrad_im2col_finalize_kernel(const WgParams p, int Md, int Cd) {
+    const long long total = (long long)Md * Cd * p.ntaps_real;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % p.ntaps_real);
+        const long long j = i / p.ntaps_real;
+        const int cd = (int)(j % Cd);
+        const int md = (int)(j / Cd);
+        const int row = p.swap_out ? cd : md, col4 = p.swap_out ? md : cd;
+        float s = 0.f;
+        for (int sp = 0; sp < p.nsplit; ++sp) s += p.ws[((size_t)sp * p.Mpad + row) * p.Cpad + t * 4 + col4];
+        const long long o = md * p.sm + cd * p.sc + p.tap_r[t] * p.sr + p.tap_s[t] * p.ss;
+        if (p.accumulate) p.dw[o] += s; else p.dw[o] = s;
     }
 }
 
@@ -1205,9 +1341,75 @@ static int launch_wgrad(WgParams& p, int dtype, float* dw, long long sm, long lo
     return HIFIC_ERR_ARG;
 }
 
+// small-channel path for nn.Conv2d weight gradients with stride 1 (see wgrad_im2col_kernel)
+template <typename T>
+static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* dy, float* dw, int accumulate,
+                                 int x_f32, int dy_f32, WsAlloc& ws, hipStream_t st) {
+    using Cfg = WgCfg<T>;
+    WgParams p; memset(&p, 0, sizeof(p));
+    const bool swap = g.K <= 4 && g.C > 4;          // dY is the small operand
+    int nt = 0;
+    for (int r = 0; r < g.R; ++r) for (int s = 0; s < g.S; ++s) {
+        p.tap_dy[nt] = (short)(r - g.pt); p.tap_dx[nt] = (short)(s - g.pl); p.tap_r[nt] = (short)r; p.tap_s[nt] = (short)s; ++nt;
+    }
+    p.im2col = 1; p.ntaps_real = nt; p.ntaps = 1; p.ngroups = 1; p.ist = 1; p.N = g.N;
+    p.swap_out = swap ? 1 : 0;
+    const int Hp = g.H + g.pt + g.pb, Wp = g.W + g.pl + g.pr;
+    if (!swap) {
+        // A = dY [N,K,OH,OW] over its own domain; B = x with the conv's padding rule
+        p.a = dy; p.a_f32 = dy_f32; p.M = g.K; p.a_h = g.OH(); p.a_w = g.OW(); p.a_bmode = PAD_ZERO; p.a_y0 = 0; p.a_x0 = 0;
+        p.AH = g.OH(); p.AW = g.OW();
+        p.b = x; p.b_f32 = x_f32; p.creal = g.C; p.BH = g.H; p.BW = g.W; p.bmode = g.pad_mode; p.b_y0 = 0; p.b_x0 = 0;
+        p.tsign = 1;
+    } else {
+        // A' = padded x over the padded domain (origin -pt,-pl, conv's padding rule); B' = dY, zero outside
+        p.a = x; p.a_f32 = x_f32; p.M = g.C; p.a_h = g.H; p.a_w = g.W; p.a_bmode = g.pad_mode; p.a_y0 = -g.pt; p.a_x0 = -g.pl;
+        p.AH = Hp; p.AW = Wp;
+        p.b = dy; p.b_f32 = dy_f32; p.creal = g.K; p.BH = g.OH(); p.BW = g.OW(); p.bmode = PAD_ZERO;
+        p.b_y0 = -g.pt; p.b_x0 = -g.pl; p.tsign = -1;
+    }
+    p.C = nt * 4;                                   // virtual columns
+    p.Mpad = cdiv(p.M, 64) * 64; p.Cpad = cdiv(p.C, 64) * 64;
+    p.dbg = 0;
+    // pixel tile: 8 x 16 (whole 128-pixel K extent; multiple of 16 for the bf16 MFMA)
+    p.TW = p.AW < 16 ? p.AW : 16; p.TH = GC_NPIX / p.TW; if (p.TH > p.AH) p.TH = p.AH; p.NI = 1;
+    while ((p.NI * p.TH * p.TW) % 16 != 0) ++p.TH;
+    p.tiles_y = cdiv(p.AH, p.TH); p.tiles_x = cdiv(p.AW, p.TW); p.tiles_n = cdiv(p.N, p.NI);
+    p.ntiles = p.tiles_n * p.tiles_y * p.tiles_x;
+    const int base_blocks = (p.Mpad / 64) * (p.Cpad / 64);
+    int nsplit = cdiv(768, base_blocks);
+    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    p.tiles_per_split = cdiv(p.ntiles, nsplit);
+    p.nsplit = cdiv(p.ntiles, p.tiles_per_split);
+    p.ws = (float*)ws.take((size_t)p.nsplit * p.Mpad * p.Cpad * sizeof(float));
+    if (!p.ws) return HIFIC_ERR_WS;
+    const long long RS = (long long)g.R * g.S;
+    p.dw = dw; p.sm = (long long)g.C * RS; p.sc = RS; p.sr = g.S; p.ss = 1; p.accumulate = accumulate;
+    const size_t lds = 2 * (size_t)GC_NPIX * Cfg::PITCH;
+    dim3 grid(base_blocks, 1, p.nsplit);
+    auto kfn = wgrad_im2col_kernel<T>;
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int pslot = prof_open(PK_WGRAD, 2.0 * g.K * g.C * nt * (double)g.N * g.OH() * g.OW(), st);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+    prof_close(pslot, st);
+    int rc = hific_launch_status();
+    if (rc != HIFIC_OK) return rc;
+    long long total = (long long)g.K * g.C * nt;
+    int gx = (int)((total + 255) / 256); if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(wgrad_im2col_finalize_kernel, dim3(gx), dim3(256), 0, st, p, g.K, g.C);
+    return hific_launch_status();
+}
+
 int gc_conv_bwd_weight(const ConvGeom& g, const void* x, const void* dy, float* dw, int accumulate,
                        int dtype, int x_f32, int dy_f32, WsAlloc& ws, hipStream_t st) {
     if (g.R * g.S > GC_MAXTAPS) return HIFIC_ERR_UNSUPPORTED;
+    if (g.stride == 1 && g.R * g.S >= 9 && g.R * g.S * 4 <= 256 && (g.C <= 4 || g.K <= 4) && (g.C > 4 || g.K > 4) &&
+        !env_int("HIFIC_NO_IM2COL", 0)) {
+        if (dtype == HIFIC_F32) return launch_wgrad_im2col_t<float>(g, x, dy, dw, accumulate, 1, 1, ws, st);
+        if (dtype == HIFIC_BF16) return launch_wgrad_im2col_t<bf16_t>(g, x, dy, dw, accumulate, x_f32, dy_f32, ws, st);
+        return HIFIC_ERR_ARG;
+    }
     WgParams p; memset(&p, 0, sizeof(p));
     p.a = dy; p.b = x; p.N = g.N; p.M = g.K; p.C = g.C; p.AH = g.OH(); p.AW = g.OW(); p.BH = g.H; p.BW = g.W;
     p.ist = g.stride; p.bmode = g.pad_mode; p.a_f32 = dy_f32; p.b_f32 = x_f32;
