@@ -34,6 +34,7 @@ struct GcParams {
     int ist, ost, bmode, act, in_f32, out_f32;
     int TH, TW, NI, tiles_n;
     int nphase;
+    int tap_sw;          // kernel width S (weight tap index = r*S + s)
     int dbg;             // ablation flags for micro-benchmarks (HIFIC_DBG; 0 in production)
     GcPhase ph[GC_MAXPH];
     short tap_dy[GC_MAXTAPS], tap_dx[GC_MAXTAPS];

@@ -359,6 +359,58 @@ __global__ void pack_w_kernel(const GcParams p, const float* __restrict__ w, con
     }
 }
 
+// Coalesced packing through LDS.  The source keeps the R*S taps of one (m, c) pair contiguous; which of m / c is the
+// neighbouring dimension (stride R*S) decides the tiling:
+//   MODE 0 (c adjacent: conv fwd, conv-transpose bwd-data): block = (one m, 64 c)   -> 64*RS contiguous floats
+//   MODE 1 (m adjacent: conv bwd-data, conv-transpose fwd): block = (MB m, 64 c)    -> 64 runs of MB*RS floats
+// Output rows wp[phase][m][t][c0..c0+63] are 128-byte (bf16) contiguous stores.  One launch covers all phases.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pack_w2_kernel(const GcParams p, const float* __restrict__ w,
+                                                      const float* scale, long long sm, long long sc, int RS, int MB) {
+    extern __shared__ float pk_lds[];
+    const float sc_ = scale ? *scale : 1.f;
+    const int c0 = blockIdx.x * 64;
+    const int mb = MODE == 0 ? 1 : MB;
+    const int m0 = blockIdx.y * mb;
+    const int run = mb * RS;                 // contiguous floats per (c row [MODE 1] | whole block [MODE 0])
+    const int pitch = (run | 1);             // odd pitch: conflict-free column reads
+    if (MODE == 0) {
+        // 64*RS contiguous floats starting at (m0, c0)
+        const int n = 64 * RS;
+        const float* src = w + (long long)m0 * sm + (long long)c0 * sc;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int c = i / RS, rs = i - c * RS;
+            float v = 0.f;
+            if (m0 < p.K && c0 + c < p.C) v = src[i] * sc_;
+            pk_lds[c * pitch + rs] = v;
+        }
+    } else {
+        const int n = 64 * run;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int c = i / run, j = i - c * run;
+            const int ml = j / RS;
+            float v = 0.f;
+            if (m0 + ml < p.K && c0 + c < p.C) v = w[(long long)(m0) * sm + (long long)(c0 + c) * sc + j] * sc_;
+            pk_lds[c * pitch + j] = v;
+        }
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    for (int phi = 0; phi < p.nphase; ++phi) {
+        const GcPhase& ph = p.ph[phi];
+        T* dst = (T*)p.wp + ph.wp_off;
+        for (int ml = 0; ml < mb; ++ml) {
+            const int m = m0 + ml;
+            if (m >= p.Kpad) break;
+            for (int t = tq; t < ph.ntaps; t += 4) {
+                const int rs = (int)p.tap_r[ph.tap0 + t] * p.tap_sw + (int)p.tap_s[ph.tap0 + t];
+                const float v = pk_lds[c * pitch + ml * RS + rs];
+                if (c0 + c < p.Cpad) DT<T>::st(dst + ((long long)m * ph.ntaps + t) * p.Cpad + c0 + c, v);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Reflect fold: dx[y,x] = sum over padded positions that the reflection pad maps onto (y,x)
 // (adjoint of ReflectionPad2d, torch reflection_pad2d_backward)
@@ -1026,6 +1078,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     p.Kpad = cdiv(p.K, bm) * bm;
     p.Cpad = cdiv(p.C, BC) * BC;
     p.dbg = env_int("HIFIC_DBG", 0);
+    p.tap_sw = (int)sr;
     // tile shape: common to all phases (largest span decides)
     int span_y = 1, span_x = 1, OHt = 1, OWt = 1;
     for (int i = 0; i < p.nphase; ++i) {
@@ -1061,16 +1114,32 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     void* wp = ws.take((size_t)(wp_elems > 0 ? wp_elems : 1) * sizeof(T));
     if (!wp) return HIFIC_ERR_WS;
     p.wp = wp;
-    // pack
+    // pack (coalesced LDS-transposing kernel when the taps of a (m,c) pair are contiguous and one of m/c is adjacent)
     {
-        long long mx = 0;
-        for (int i = 0; i < p.nphase; ++i) {
-            long long e = (long long)p.Kpad * p.ph[i].ntaps * p.Cpad;
-            if (e > mx) mx = e;
-        }
-        if (mx > 0) {
-            int gx = (int)((mx + 255) / 256); if (gx > 4096) gx = 4096;
-            hipLaunchKernelGGL(pack_w_kernel<T>, dim3(gx, p.nphase), dim3(256), 0, st, p, w, w_scale, sm, sc, sr, ss);
+        int RS = 0;
+        for (int i = 0; i < p.nphase; ++i) RS += p.ph[i].ntaps;       // phases partition the R*S taps
+        const bool contiguous = (sr == p.tap_sw && ss == 1 && RS > 0);
+        const bool full = (sr * 0 + RS) == RS;
+        (void)full;
+        if (contiguous && sc == RS && !env_int("HIFIC_OLD_PACK", 0)) {
+            dim3 pg(p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0), p.Kpad);
+            const size_t lb = (size_t)64 * (RS | 1) * sizeof(float);
+            hipLaunchKernelGGL((pack_w2_kernel<T, 0>), pg, dim3(256), lb, st, p, w, w_scale, sm, sc, RS, 1);
+        } else if (contiguous && sm == RS && !env_int("HIFIC_OLD_PACK", 0)) {
+            int MB = 192 / RS; if (MB > 16) MB = 16; if (MB < 1) MB = 1;
+            dim3 pg(p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0), cdiv(p.Kpad, MB));
+            const size_t lb = (size_t)64 * ((MB * RS) | 1) * sizeof(float);
+            hipLaunchKernelGGL((pack_w2_kernel<T, 1>), pg, dim3(256), lb, st, p, w, w_scale, sm, sc, RS, MB);
+        } else {
+            long long mx = 0;
+            for (int i = 0; i < p.nphase; ++i) {
+                long long e = (long long)p.Kpad * p.ph[i].ntaps * p.Cpad;
+                if (e > mx) mx = e;
+            }
+            if (mx > 0) {
+                int gx = (int)((mx + 255) / 256); if (gx > 4096) gx = 4096;
+                hipLaunchKernelGGL(pack_w_kernel<T>, dim3(gx, p.nphase), dim3(256), 0, st, p, w, w_scale, sm, sc, sr, ss);
+            }
         }
     }
     dim3 grid(max_tiles, p.Kpad / bm, p.nphase);
