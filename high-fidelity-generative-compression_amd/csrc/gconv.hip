@@ -372,40 +372,51 @@ __global__ __launch_bounds__(256) void pack_w2_kernel(const GcParams p, const fl
     const int c0 = blockIdx.x * 64;
     const int mb = MODE == 0 ? 1 : MB;
     const int m0 = blockIdx.y * mb;
-    const int run = mb * RS;                 // contiguous floats per (c row [MODE 1] | whole block [MODE 0])
+    const int run = mb * RS;                 // contiguous floats per c row
     const int pitch = (run | 1);             // odd pitch: conflict-free column reads
     if (MODE == 0) {
-        // 64*RS contiguous floats starting at (m0, c0)
+        // 64*RS contiguous floats starting at (m0, c0); LDS index c*pitch + rs
         const int n = 64 * RS;
+        const int nvalid = (m0 < p.K) ? ((p.C - c0 < 64 ? p.C - c0 : 64) * RS) : 0;
         const float* src = w + (long long)m0 * sm + (long long)c0 * sc;
         for (int i = threadIdx.x; i < n; i += 256) {
-            const int c = i / RS, rs = i - c * RS;
-            float v = 0.f;
-            if (m0 < p.K && c0 + c < p.C) v = src[i] * sc_;
-            pk_lds[c * pitch + rs] = v;
+            const float v = i < nvalid ? src[i] * sc_ : 0.f;
+            const int li = (pitch == RS) ? i : i + i / RS;
+            pk_lds[li] = v;
         }
     } else {
-        const int n = 64 * run;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int c = i / run, j = i - c * run;
-            const int ml = j / RS;
-            float v = 0.f;
-            if (m0 + ml < p.K && c0 + c < p.C) v = w[(long long)(m0) * sm + (long long)(c0 + c) * sc + j] * sc_;
-            pk_lds[c * pitch + j] = v;
+        // 64 rows (c) of `run` contiguous floats each: wave w takes rows w, w+4, ...
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        int jmax = (p.K - m0) * RS; if (jmax > run) jmax = run; if (jmax < 0) jmax = 0;
+        for (int c = wv; c < 64; c += 4) {
+            const bool cok = c0 + c < p.C;
+            const float* src = w + (long long)m0 * sm + (long long)(cok ? c0 + c : 0) * sc;
+            for (int j = lane; j < run; j += 64)
+                pk_lds[c * pitch + j] = (cok && j < jmax) ? src[j] * sc_ : 0.f;
         }
     }
     __syncthreads();
-    const int c = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    // write: thread = (4 consecutive c, row slot); rows enumerate (ml, t); 8-byte (bf16) / 16-byte (f32) stores
+    const int cq = (threadIdx.x & 15) * 4, rslot = threadIdx.x >> 4;
     for (int phi = 0; phi < p.nphase; ++phi) {
         const GcPhase& ph = p.ph[phi];
         T* dst = (T*)p.wp + ph.wp_off;
-        for (int ml = 0; ml < mb; ++ml) {
+        const int nrows = mb * ph.ntaps;
+        for (int r = rslot; r < nrows; r += 16) {
+            const int ml = r / ph.ntaps, t = r - ml * ph.ntaps;
             const int m = m0 + ml;
-            if (m >= p.Kpad) break;
-            for (int t = tq; t < ph.ntaps; t += 4) {
-                const int rs = (int)p.tap_r[ph.tap0 + t] * p.tap_sw + (int)p.tap_s[ph.tap0 + t];
-                const float v = pk_lds[c * pitch + ml * RS + rs];
-                if (c0 + c < p.Cpad) DT<T>::st(dst + ((long long)m * ph.ntaps + t) * p.Cpad + c0 + c, v);
+            if (m >= p.Kpad || c0 + cq >= p.Cpad) continue;
+            const int rs = (int)p.tap_r[ph.tap0 + t] * p.tap_sw + (int)p.tap_s[ph.tap0 + t];
+            const float* lp = pk_lds + ml * RS + rs;
+            const float v0 = lp[(cq + 0) * pitch], v1 = lp[(cq + 1) * pitch], v2 = lp[(cq + 2) * pitch], v3 = lp[(cq + 3) * pitch];
+            T* d = dst + ((long long)m * ph.ntaps + t) * p.Cpad + c0 + cq;
+            if constexpr (std::is_same<T, float>::value) {
+                *(float4*)d = make_float4(v0, v1, v2, v3);
+            } else {
+                uint2 o;
+                o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                *(uint2*)d = o;
             }
         }
     }

@@ -42,7 +42,8 @@ class BucketedGradReducer:
         self.works = []
         # eager=False: reduce everything in finish() (used for the Discriminator arena, whose slots are written by
         # two backward passes per optimizer step)
-        if self.world > 1 and eager:
+        self.active = self.world > 1 or (dist.is_initialized() and __import__('os').environ.get('HIFIC_FORCE_DIST') == '1')
+        if self.active and eager:
             arena.on_write = self._on_write
 
     def _launch(self, b):
@@ -60,7 +61,7 @@ class BucketedGradReducer:
     def finish(self):
         """Launch whatever is not sealed yet (parameters that received no gradient this turn), wait for all
         collectives on the current stream, reset for the next backward.  Returns the gradient scale 1/world."""
-        if self.world > 1:
+        if self.active:
             for b in range(len(self.buckets)):
                 if not self.launched[b]:
                     self._launch(b)
