@@ -32,7 +32,7 @@ struct GcParams {
     const void* resid;   // same shape as out, or null
     int N, C, IH, IW, K, OHf, OWf, Cpad, Kpad;
     int ist, ost, bmode, act, in_f32, out_f32;
-    int TH, TW, NI, tiles_n;
+    int TH, TW, NI, tiles_n, max_tiles;
     int nphase;
     int tap_sw;          // kernel width S (weight tap index = r*S + s)
     int dbg;             // ablation flags for micro-benchmarks (HIFIC_DBG; 0 in production)

@@ -163,13 +163,24 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
 
     const GcPhase& ph = p.ph[blockIdx.z];
     const int ntile_ph = p.tiles_n * ph.tiles_y * ph.tiles_x;
-    if ((int)blockIdx.x >= ntile_ph) return;
-    const int tile = blockIdx.x;
+    // XCD-aware mapping: the dispatcher places block b on XCD b % 8 (speed only, never correctness).  Blocks are
+    // renumbered so that each XCD works on a contiguous range of the m-major (m-tile, pixel-tile) list: an XCD then
+    // streams only ~1/8 of the packed weights through its private 4 MiB L2 instead of all of them.
+    int tile, mtile;
+    {
+        const int nwg = gridDim.x;                       // = max_tiles * mtiles (host)
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int q = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;   // bijective
+        mtile = q / p.max_tiles;
+        tile = q - mtile * p.max_tiles;
+    }
+    if (tile >= ntile_ph) return;
     const int tx = tile % ph.tiles_x;
     const int ty = (tile / ph.tiles_x) % ph.tiles_y;
     const int tn = tile / (ph.tiles_x * ph.tiles_y);
     const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
-    const int m0 = blockIdx.y * BM;
+    const int m0 = mtile * BM;
     const int PH = ph.PH, PW = ph.PW;
     const int npp = PH * PW;
     const int npatch = p.NI * npp;
@@ -798,6 +809,38 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
 #undef WG_LOAD_A
 #undef WG_TILE_ORIGIN
 
+    // Epilogue.  Direct mode with the whole kernel window in this group (3x3 layers): the per-lane scatter
+    // (4-byte stores at a 36-byte stride) costs 8x write amplification (rocprofv3 WRITE_SIZE 275 MB for a 33 MB
+    // gradient), so the tile is transposed through LDS and each m row leaves as one contiguous run of 64c x 9 taps.
+    if (p.direct && p.ngroups == 1 && p.sc == gp.ntaps && p.ss == 1 && gp.ntaps == GC_TG) {
+        constexpr int RP = 32 * GC_TG + 1;                      // floats per staged row (odd: conflict-free)
+        float* stg = (float*)smem + (size_t)wave * 16 * RP;     // per-wave region: 16 rows
+        __syncthreads();                                        // all waves done with the operand buffers
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int t = 0; t < GC_TG; ++t)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = h * 8 + rr;
+                    const int rowl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi;      // 0..15 within the half
+                    stg[rowl * RP + l31 * GC_TG + t] = acc[t][r];
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes landed (wave-private region)
+            for (int rowl = 0; rowl < 16; ++rowl) {
+                const int m = m0 + wm * 32 + h * 16 + rowl;
+                if (m >= p.M) break;
+                float* drow = p.dw + (long long)m * p.sm + (long long)(c0 + wn * 32) * p.sc;
+                int nvalid = (p.C - (c0 + wn * 32)) * GC_TG; if (nvalid > 32 * GC_TG) nvalid = 32 * GC_TG;
+                for (int j = lane; j < nvalid; j += 64) {
+                    const float v = stg[rowl * RP + j];
+                    if (p.accumulate) drow[j] += v; else drow[j] = v;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < GC_TG; ++t) {
         if (t < gp.ntaps) {
@@ -1153,7 +1196,8 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             }
         }
     }
-    dim3 grid(max_tiles, p.Kpad / bm, p.nphase);
+    p.max_tiles = max_tiles;
+    dim3 grid(max_tiles * (p.Kpad / bm), 1, p.nphase);
     double aflops = 0;
     for (int i = 0; i < p.nphase; ++i)
         aflops += 2.0 * p.K * p.C * p.ph[i].ntaps * (double)p.N * p.ph[i].OHt * p.ph[i].OWt;
