@@ -49,17 +49,16 @@ __global__ void axpby_kernel(const float* __restrict__ a, const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, float* __restrict__ part, int N, int C,
                                                        int HW, int nsplit) {
+    // block (c, split): the split owns a contiguous slice of the HW axis of every image (no per-element division)
     __shared__ float sh[4];
     const int c = blockIdx.x, split = blockIdx.y;
-    const long long total = (long long)N * HW;
-    const long long per = (total + nsplit - 1) / nsplit;
-    const long long lo = split * per;
-    long long hi = lo + per; if (hi > total) hi = total;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int lo = split * per;
+    int hi = lo + per; if (hi > HW) hi = HW;
     float s = 0.f;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const int n = (int)(i / HW);
-        const int hw = (int)(i - (long long)n * HW);
-        s += DT<T>::ld(x + ((size_t)n * C + c) * HW + hw);
+    for (int n = 0; n < N; ++n) {
+        const T* xp = x + ((size_t)n * C + c) * HW;
+        for (int i = lo + threadIdx.x; i < hi; i += 256) s += DT<T>::ld(xp + i);
     }
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) part[(size_t)split * C + c] = s;
@@ -332,9 +331,8 @@ int hific_axpby_f32(const float* a, const float* b, float* o, float alpha, float
 // out[c] (=|+=) sum_{n,hw} x[n,c,hw]; ws >= 64*C floats
 int hific_channel_sum(const void* x, float* out, int N, int C, int HW, int accumulate, int dtype, void* ws,
                       size_t ws_bytes, hipStream_t st) {
-    long long total = (long long)N * HW;
     int nsplit = cdiv(1024, C); if (nsplit > 64) nsplit = 64;
-    if ((long long)nsplit * 256 > total) nsplit = (int)((total + 255) / 256);
+    if (nsplit * 256 > HW) nsplit = cdiv(HW, 256);
     if (nsplit < 1) nsplit = 1;
     if ((size_t)nsplit * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
     float* part = (float*)ws;

@@ -19,7 +19,8 @@ struct GcPhase {
     int ooy, oox;        // output position = u*ost + ooy (masked to the full plane)
     int OHt, OWt;        // extent of the (u,v) tile domain
     int dy_min, dx_min;  // min tap offset (patch origin)
-    int PH, PW;          // LDS patch extent per image
+    int PH, PW;          // LDS patch extent per image (logical)
+    int PWs;             // storage row width of the LDS patch (>= PW; multiple of 16 avoids B-fragment bank conflicts)
     int tiles_x, tiles_y;
     long long wp_off;    // element offset of this phase's packed weights
 };

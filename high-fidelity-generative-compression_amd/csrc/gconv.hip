@@ -89,11 +89,13 @@ __device__ __forceinline__ void px_store(unsigned char* row, const unsigned (&lo
 }
 // Decode patch pixel q -> element offset of channel 0 (0 when outside) and validity
 __device__ __forceinline__ void px_decode(int q, int npatch, int npp, int PW, float inv_npp, float inv_pw, int n0, int y0,
-                                          int x0, int N, int C, int H, int W, int bmode, unsigned& qoff, bool& ok) {
+                                          int x0, int N, int C, int H, int W, int bmode, unsigned& qoff, bool& ok,
+                                          int PWs, int& qs) {
     const int img = (int)(((float)q + 0.5f) * inv_npp);          // exact for q < 2^22
     const int r = q - img * npp;
     const int py = (int)(((float)r + 0.5f) * inv_pw);
     const int px = r - py * PW;
+    qs = q + (img * (npp / PW) + py) * (PWs - PW);              // storage index: rows are PWs wide
     int iy = y0 + py, ix = x0 + px;
     const int n = n0 + img;
     if (bmode == PAD_REFLECT) { iy = reflect_idx(iy, H); ix = reflect_idx(ix, W); }
@@ -103,7 +105,7 @@ __device__ __forceinline__ void px_decode(int q, int npatch, int npp, int PW, fl
 
 template <typename T, int DWR, int PITCH, bool SF32>
 __device__ __forceinline__ void stage_T_impl(unsigned char* lds, const void* src, int N, int C, int H, int W, int bmode,
-                                             int n0, int NI, int y0, int x0, int PH, int PW, int c0, int tid) {
+                                             int n0, int NI, int y0, int x0, int PH, int PW, int c0, int tid, int PWs) {
     // Thread (lane, wave) handles patch pixels q = lane + 64*j and dwords dw = wave + 4*i: the pixel is decoded once
     // and all DWR/4 channel loads of it are issued back-to-back; lanes run along W so every channel row is a
     // coalesced run.
@@ -117,22 +119,23 @@ __device__ __forceinline__ void stage_T_impl(unsigned char* lds, const void* src
     const float inv_npp = 1.0f / (float)npp, inv_pw = 1.0f / (float)PW;
     const bool full = c0 + BCH <= C;
     for (int q = lane; q < npatch; q += 64) {
-        unsigned qoff; bool ok;
-        px_decode(q, npatch, npp, PW, inv_npp, inv_pw, n0, y0, x0, N, C, H, W, bmode, qoff, ok);
+        unsigned qoff; bool ok; int qs;
+        px_decode(q, npatch, npp, PW, inv_npp, inv_pw, n0, y0, x0, N, C, H, W, bmode, qoff, ok, PWs, qs);
         unsigned lo[NDW], hi[NDW];
         px_load<T, NDW, SF32>(lo, hi, src, qoff, plane, C, c0, wv, full);
-        px_store<T, NDW, SF32>(lds + (size_t)q * PITCH + wv * 4, lo, hi, ok);
+        px_store<T, NDW, SF32>(lds + (size_t)qs * PITCH + wv * 4, lo, hi, ok);
     }
 }
 template <typename T, int DWR, int PITCH>
 __device__ __forceinline__ void stage_T(unsigned char* lds, const void* src, int src_f32,
                                         int N, int C, int H, int W, int bmode,
-                                        int n0, int NI, int y0, int x0, int ystep_unused, int PH, int PW,
+                                        int n0, int NI, int y0, int x0, int PWs, int PH, int PW,
                                         int c0, int tid, int nthreads) {
+    if (PWs < PW) PWs = PW;
     if (std::is_same<T, float>::value || src_f32)
-        stage_T_impl<T, DWR, PITCH, true>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid);
+        stage_T_impl<T, DWR, PITCH, true>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
     else
-        stage_T_impl<T, DWR, PITCH, false>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid);
+        stage_T_impl<T, DWR, PITCH, false>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -181,8 +184,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
     const int tn = tile / (ph.tiles_x * ph.tiles_y);
     const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
     const int m0 = mtile * BM;
-    const int PH = ph.PH, PW = ph.PW;
+    const int PH = ph.PH, PW = ph.PW, PWs = ph.PWs;
     const int npp = PH * PW;
+    const int npps = PH * PWs;                    // storage pixels per image
     const int npatch = p.NI * npp;
     const int iy0 = u0 * p.ist + ph.dy_min, ix0 = v0 * p.ist + ph.dx_min;
 
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
     unsigned char* wbuf = smem + 512;                 // 2 x WBYTES
     unsigned char* patch = wbuf + 2 * WBYTES;         // npatch x PITCH
     if (tid < ph.ntaps)
-        toffs[tid] = ((int)p.tap_dy[ph.tap0 + tid] - ph.dy_min) * PW + ((int)p.tap_dx[ph.tap0 + tid] - ph.dx_min);
+        toffs[tid] = ((int)p.tap_dy[ph.tap0 + tid] - ph.dy_min) * PWs + ((int)p.tap_dx[ph.tap0 + tid] - ph.dx_min);
 
     // per-lane pixel decode for the B (pixel) operand and the epilogue
     int qb[WN], pu[WN], pv[WN], pn[WN];
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
         const int tx_ = rem - ty_ * p.TW;
         const bool v = img < p.NI;
         pvalid[ni] = v;
-        qb[ni] = v ? (img * npp + ty_ * p.ist * PW + tx_ * p.ist) : 0;
+        qb[ni] = v ? (img * npps + ty_ * p.ist * PWs + tx_ * p.ist) : 0;
         pu[ni] = u0 + ty_; pv[ni] = v0 + tx_; pn[ni] = n0 + img;
     }
 
@@ -276,10 +280,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0); \
             } else {                                                                                            \
                 bf16x8_t a[WM], b[WN];                                                                          \
+                if (!(p.dbg & 8)) {                                                                             \
                 _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                               \
                     a[mi] = *(const bf16x8_t*)(arow + mi * 32 * PITCH + kk * 32 + lhi * 16);                    \
                 _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                               \
                     b[ni] = *(const bf16x8_t*)(patch + (size_t)(qb[ni] + toff) * PITCH + kk * 32 + lhi * 16);   \
+                } else {                                                                                        \
+                _Pragma("unroll") for (int mi = 0; mi < WM; ++mi) a[mi] = __builtin_bit_cast(bf16x8_t, dbgv);   \
+                _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) b[ni] = __builtin_bit_cast(bf16x8_t, dbgv);   \
+                }                                                                                               \
                 _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                               \
                     _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                           \
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0); \
@@ -292,15 +301,16 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
         if (t == 0 && !((p.dbg & 1) && chunk > 0)) {                                        \
             __syncthreads();                                                                \
             stage_T<T, DWR, PITCH>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode,    \
-                                   n0, p.NI, iy0, ix0, 0, PH, PW, chunk * BC, tid, 256);    \
+                                   n0, p.NI, iy0, ix0, PWs, PH, PW, chunk * BC, tid, 256);    \
         }                                                                                   \
-        __syncthreads();                                                                    \
+        if (!(p.dbg & 16)) __syncthreads();                                                 \
         if (!(p.dbg & 4)) GC_WLOAD(RL, (s) + 2);                                            \
         if (!(p.dbg & 2)) GC_COMPUTE(wbuf + ((s) & 1) * WBYTES, t);                         \
         if (!(p.dbg & 4)) GC_WSTORE(RS, wbuf + (((s) + 1) & 1) * WBYTES);                   \
         if (++t == nt) { t = 0; ++chunk; }                                                  \
     } while (0)
 
+    const u32x4_t dbgv = {(unsigned)tid, 1u, 2u, 3u};
     if (nsteps > 0) {
         GC_WLOAD(wA, 0);
         GC_WLOAD(wB, 1);
@@ -440,13 +450,15 @@ __global__ __launch_bounds__(256) void pack_w2_kernel(const GcParams p, const fl
 template <typename TO>
 __global__ void reflect_fold_kernel(const float* __restrict__ src, TO* __restrict__ dst, long long planes,
                                     int H, int W, int pt, int pl, int pb, int pr) {
+    // one thread per output element, 32-bit index math (planes*H*W < 2^31 on this path)
     const int Hp = H + pt + pb, Wp = W + pl + pr;
-    const long long total = planes * H * W;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W);
-        const int y = (int)((i / W) % H);
-        const long long pc = i / ((long long)W * H);
+    const unsigned total = (unsigned)planes * (unsigned)(H * W);
+    const unsigned hw = (unsigned)(H * W);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned pc = i / hw;
+        const unsigned rem = i - pc * hw;
+        const int y = (int)(rem / (unsigned)W);
+        const int x = (int)(rem - (unsigned)y * (unsigned)W);
         int ys[3], xs[3], ny = 0, nx = 0;
         ys[ny++] = y + pt;
         if (y >= 1 && y <= pt) ys[ny++] = pt - y;
@@ -454,10 +466,10 @@ __global__ void reflect_fold_kernel(const float* __restrict__ src, TO* __restric
         xs[nx++] = x + pl;
         if (x >= 1 && x <= pl) xs[nx++] = pl - x;
         if (x <= W - 2 && x >= W - 1 - pr) xs[nx++] = pl + 2 * (W - 1) - x;
-        const float* s = src + pc * Hp * Wp;
+        const float* s = src + (size_t)pc * Hp * Wp;
         float acc = 0.f;
         for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) acc += s[(long long)ys[a] * Wp + xs[b]];
+            for (int b2 = 0; b2 < nx; ++b2) acc += s[ys[a] * Wp + xs[b2]];
         DT<TO>::st(dst + i, acc);
     }
 }
@@ -711,8 +723,9 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
         qokm = 0;                                                                                           \
         _Pragma("unroll") for (int j = 0; j < QI; ++j) {                                                    \
             bool ok_;                                                                                       \
+            int qs_;                                                                                        \
             px_decode(lane + 64 * j, npatch, npp, PW, inv_npp, inv_pw, n0_, u0_ * p.ist + gp.dy_min,        \
-                      v0_ * p.ist + gp.dx_min, p.N, p.C, p.BH, p.BW, p.bmode, qoff[j], ok_);                \
+                      v0_ * p.ist + gp.dx_min, p.N, p.C, p.BH, p.BW, p.bmode, qoff[j], ok_, PW, qs_);       \
             qokm |= (ok_ ? 1u : 0u) << j;                                                                   \
         }                                                                                                   \
     } while (0)
@@ -1002,21 +1015,19 @@ __global__ void wgrad_im2col_finalize_kernel(const WgParams p, int Md, int Cd) {
 // dw[m*sm + c*sc + r*sr + s*ss] (=|+=) sum_split ws[split][m][t][c]
 __global__ void wgrad_finalize_kernel(const WgParams p, float* __restrict__ dw, long long sm, long long sc,
                                       long long sr, long long ss, int accumulate) {
-    const long long total = (long long)p.M * p.C * p.ntaps;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int t = (int)(i % p.ntaps);
-        const long long j = i / p.ntaps;
-        const int c = (int)(j % p.C);
-        const int m = (int)(j / p.C);
+    // thread per (m, c, t), t fastest: contiguous writes; 32-bit index math
+    const unsigned nt = (unsigned)p.ntaps, C = (unsigned)p.C;
+    const unsigned total = (unsigned)p.M * C * nt;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned j = i / nt, t = i - j * nt;
+        const unsigned m = j / C, c = j - m * C;
         float s = 0.f;
         for (int sp = 0; sp < p.nsplit; ++sp)
-            s += p.ws[(((size_t)sp * p.Mpad + m) * p.ntaps + t) * p.Cpad + c];
+            s += p.ws[(((size_t)sp * p.Mpad + m) * nt + t) * p.Cpad + c];
         const long long o = m * sm + c * sc + p.tap_r[t] * sr + p.tap_s[t] * ss;
         if (accumulate) dw[o] += s; else dw[o] = s;
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------
 // Optional in-library profiler: HIP event pairs around every GEMM-class launch (on the launch stream), keyed by
@@ -1155,13 +1166,18 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         const int sy = ph.PH, sx = ph.PW;
         ph.PH = (p.TH - 1) * p.ist + sy;
         ph.PW = (p.TW - 1) * p.ist + sx;
+        ph.PWs = ph.PW;
+        if (std::is_same<T, bf16_t>::value && BC == 64 && (ph.PW % 16) != 0 && env_int("HIFIC_PWS", 0)) {   // measured: no gain
+            const int pws = (ph.PW + 15) / 16 * 16;
+            if ((size_t)wbytes + (size_t)p.NI * ph.PH * pws * PITCH <= (size_t)96 * 1024) ph.PWs = pws;
+        }
         ph.tiles_y = cdiv(ph.OHt, p.TH);
         ph.tiles_x = cdiv(ph.OWt, p.TW);
         ph.wp_off = wp_elems;
         wp_elems += (long long)p.Kpad * ph.ntaps * p.Cpad;
         int nt = p.tiles_n * ph.tiles_y * ph.tiles_x;
         if (nt > max_tiles) max_tiles = nt;
-        size_t b = (size_t)wbytes + (size_t)p.NI * ph.PH * ph.PW * PITCH;
+        size_t b = (size_t)wbytes + (size_t)p.NI * ph.PH * ph.PWs * PITCH;
         if (b > lds) lds = b;
     }
     if (lds > (size_t)kLdsBudget) return HIFIC_ERR_UNSUPPORTED;
@@ -1303,7 +1319,7 @@ int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const fl
     if (fold) {
         const long long planes = (long long)g.N * g.C;
         long long total = planes * g.H * g.W;
-        int gx = (int)((total + 255) / 256); if (gx > 8192) gx = 8192;
+        int gx = (int)((total + 255) / 256); if (gx > 16384) gx = 16384;
         const bool of32 = (dtype == HIFIC_F32) || out_f32;
         if (of32)
             hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(gx), dim3(256), 0, st, padbuf, (float*)dx, planes,
@@ -1453,7 +1469,7 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
     int rc = hific_launch_status();
     if (rc != HIFIC_OK || p.direct) return rc;
     long long total = (long long)p.M * p.C * p.ntaps;
-    int gx = (int)((total + 255) / 256); if (gx > 8192) gx = 8192;
+    int gx = (int)((total + 255) / 256); if (gx > 16384) gx = 16384;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(gx), dim3(256), 0, st, p, dw, sm, sc, sr, ss, accumulate);
     return hific_launch_status();
 }

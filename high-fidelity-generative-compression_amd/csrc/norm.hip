@@ -139,20 +139,21 @@ __global__ __launch_bounds__(256) void cn_bwd_param_kernel(const T* __restrict__
                                                            int nsplit) {
     __shared__ float r1[4], r2[4];
     const int c = blockIdx.x, split = blockIdx.y;
-    const long long total = (long long)N * HW;
-    const long long per = (total + nsplit - 1) / nsplit;
-    const long long lo = split * per;
-    long long hi = lo + per; if (hi > total) hi = total;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int lo = split * per;
+    int hi = lo + per; if (hi > HW) hi = HW;
     const float gm = gamma[c], bt = beta[c];
     float sg = 0.f, sb = 0.f;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const int n = (int)(i / HW);
-        const int hw = (int)(i - (long long)n * HW);
-        const size_t off = ((size_t)n * C + c) * HW + hw;
-        const float xh = (DT<T>::ld(x + off) - mean[i]) * rstd[i];
-        float g = DT<T>::ld(dy + off);
-        if (relu && !(gm * xh + bt > 0.f)) g = 0.f;
-        sg += g * xh; sb += g;
+    for (int n = 0; n < N; ++n) {
+        const size_t off = ((size_t)n * C + c) * HW;
+        const float* mp = mean + (size_t)n * HW;
+        const float* rp = rstd + (size_t)n * HW;
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            const float xh = (DT<T>::ld(x + off + i) - mp[i]) * rp[i];
+            float g = DT<T>::ld(dy + off + i);
+            if (relu && !(gm * xh + bt > 0.f)) g = 0.f;
+            sg += g * xh; sb += g;
+        }
     }
     sg = wave_sum(sg); sb = wave_sum(sb);
     if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = sg; r2[threadIdx.x >> 6] = sb; }
@@ -201,10 +202,9 @@ int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, con
                           const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int C, int HW, int relu,
                           int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
     if (C < 2 || N <= 0 || HW <= 0) return HIFIC_ERR_ARG;
-    long long total = (long long)N * HW;
     int nsplit = cdiv(1024, C);
     if (nsplit > 64) nsplit = 64;
-    if ((long long)nsplit * 256 > total) nsplit = (int)((total + 255) / 256);
+    if (nsplit * 256 > HW) nsplit = cdiv(HW, 256);
     if (nsplit < 1) nsplit = 1;
     if ((size_t)nsplit * 2 * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
     float* part = (float*)ws;
