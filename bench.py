@@ -194,10 +194,17 @@ def main():
     ms = (ctypes.c_double * 4)(); fl = (ctypes.c_double * 4)(); cnt = (ctypes.c_int * 4)()
     lib.call("hific_prof_end", ms, fl, cnt)
     kinds = ["gconv_kernel<128-row tile>", "gconv_kernel<64-row tile>", "gconv_kernel<32-row tile>", "wgrad_kernel"]
+    kinds_key = ["gconv128", "gconv64", "gconv32", "wgrad"]
     per_kind = {kinds[i]: {"launches": cnt[i], "ms": round(ms[i], 3),
                            "tflops": round(fl[i] / (ms[i] * 1e-3) / 1e12, 2) if ms[i] > 0 else 0.0}
                 for i in range(4) if cnt[i] > 0}
     dom = max(range(4), key=lambda i: ms[i])
+    traffic = None
+    try:   # HBM bytes per launch of the dominant kernel class: rocprofv3 FETCH_SIZE(x2 on gfx950)+WRITE_SIZE, see profiles/
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get(kinds_key[dom])
+    except Exception:
+        traffic = None
     achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
     imgs_per_step = args.batch * (2 if args.config == "gan" else 1)
     value = world * imgs_per_step * args.steps / elapsed
@@ -213,7 +220,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": kinds[dom], "achieved": round(achieved, 2),
                      "peak": MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                      "frac": round(achieved / (MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                     "avg_launch_us": round(ms[dom] * 1e3 / max(cnt[dom], 1), 2), "traffic": None,
+                     "avg_launch_us": round(ms[dom] * 1e3 / max(cnt[dom], 1), 2), "traffic": traffic,
                      "per_kernel": per_kind,
                      "step_model": {"algorithmic_tflop_per_step": round(FLOP_PER_IMAGE_COMPRESSION * args.batch / 1e12, 3),
                                     "whole_step_tflops": round(FLOP_PER_IMAGE_COMPRESSION * args.batch /

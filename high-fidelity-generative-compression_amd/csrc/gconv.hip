@@ -356,6 +356,229 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Software-pipelined kernel for the stride-1 3x3 layers (bf16, 9 taps in one phase, 64-channel chunks, halo patch of
+// <= 192 pixels).  Same tiling as gconv_kernel; the 9 GEMM steps of a channel chunk are ONE straight-line block in
+// which every wave also
+//   * loads weight tile s+3 (retired into a 3-deep LDS ring two steps later), and
+//   * in steps 0..3 loads 2 of the 8 dword columns of the NEXT chunk's halo patch (retired two steps later into the
+//     other patch buffer).
+// Everything about a thread's patch items is static: its pixels (lane + 64 j) are decoded once into registers, the
+// channel of an item is wave-uniform (scalar base pointer + 32-bit vector offset addressing), LDS offsets are
+// immediates.  The number of loads per step is a compile-time constant, so vmcnt accounting stays exact (conditional
+// or table-driven loads made the compiler drain with vmcnt(0): measured 1.3-2x slower) and the loads / ds_writes are
+// interleaved between the 16 MFMAs of a step.  One barrier per step, no separate staging phase.
+// ---------------------------------------------------------------------------------------------------
+template <int WM>
+__global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
+    typedef bf16_t T;
+    constexpr int BC = 64, KS = 16, PITCH = 144, PPR = 8, WGN = 2, WN = 2, NT = 9, QJ = 3;
+    constexpr int BM = 2 * WM * 32;
+    constexpr int WBYTES = BM * PITCH, NWP = BM * PPR / 256;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const GcPhase& ph = p.ph[0];
+    const int ntile_ph = p.tiles_n * ph.tiles_y * ph.tiles_x;
+    int tile, mtile;
+    {
+        const int nwg = gridDim.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int q = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        mtile = q / p.max_tiles;
+        tile = q - mtile * p.max_tiles;
+    }
+    if (tile >= ntile_ph) return;
+    const int tx = tile % ph.tiles_x;
+    const int ty = (tile / ph.tiles_x) % ph.tiles_y;
+    const int tn = tile / (ph.tiles_x * ph.tiles_y);
+    const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
+    const int m0 = mtile * BM;
+    const int PH = ph.PH, PW = ph.PW;
+    const int npp = PH * PW;
+    const int npatch = p.NI * npp;
+    const int iy0 = u0 * p.ist + ph.dy_min, ix0 = v0 * p.ist + ph.dx_min;
+    const unsigned patch_bytes = (unsigned)(((size_t)(npatch + 1) * PITCH + 15) & ~(size_t)15);   // + dump row
+
+    int* toffs = (int*)smem;                                   // [16] byte offset of each tap inside the patch
+    unsigned char* wbuf = smem + 64;                           // 3 x WBYTES
+    unsigned char* pbuf = wbuf + 3 * WBYTES;                   // 2 x patch_bytes
+    if (tid < NT)
+        toffs[tid] = (((int)p.tap_dy[tid] - ph.dy_min) * PW + ((int)p.tap_dx[tid] - ph.dx_min)) * PITCH;
+
+    // static patch pixels of this thread
+    unsigned qoff[QJ], pdst[QJ];
+    bool qok[QJ];
+    {
+        const float inv_npp = 1.0f / (float)npp, inv_pw = 1.0f / (float)PW;
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) {
+            const int q = lane + 64 * j;
+            int qs;
+            px_decode(q, npatch, npp, PW, inv_npp, inv_pw, n0, iy0, ix0, p.N, p.C, p.IH, p.IW, p.bmode, qoff[j], qok[j], PW, qs);
+            pdst[j] = (unsigned)((q < npatch ? q : npatch) * PITCH + wave * 4);
+        }
+    }
+
+    unsigned brow[WN];                                          // byte offset of this lane's B rows inside a patch buffer
+    int pu[WN], pv[WN], pn[WN];
+    bool pvalid[WN];
+    const int thw = p.TH * p.TW;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int pt = (wn * WN + ni) * 32 + l31;
+        const int img = pt / thw;
+        const int rem = pt - img * thw;
+        const int ty_ = rem / p.TW;
+        const int tx_ = rem - ty_ * p.TW;
+        const bool v = img < p.NI;
+        pvalid[ni] = v;
+        brow[ni] = (unsigned)((v ? (img * npp + ty_ * PW + tx_) : 0) * PITCH + lhi * 16);
+        pu[ni] = u0 + ty_; pv[ni] = v0 + tx_; pn[ni] = n0 + img;
+    }
+    const unsigned arow = (unsigned)((wm * WM * 32 + l31) * PITCH + lhi * 16);
+
+    f32x16_t acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nchunks = p.Cpad / BC;
+    const unsigned char* wp_ph = (const unsigned char*)p.wp + (size_t)ph.wp_off * sizeof(T);
+    const size_t wrow_bytes = (size_t)NT * p.Cpad * sizeof(T);
+    const unsigned plane = (unsigned)(p.IH * p.IW);
+    const bf16_t* inb = (const bf16_t*)p.in;
+
+    unsigned wdst[NWP];
+    const unsigned char* wsrc[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int piece = tid + i * 256;
+        wdst[i] = (unsigned)((piece / PPR) * PITCH + (piece % PPR) * 16);
+        wsrc[i] = wp_ph + (size_t)(m0 + piece / PPR) * wrow_bytes + (piece % PPR) * 16;
+    }
+
+    u32x4_t wS[3][NWP];
+    unsigned short rlo[3][2 * QJ], rhi[3][2 * QJ];
+
+    // prologue: patch of chunk 0 staged synchronously, weight tiles 0..2 requested, tile 0 in ring slot 0
+    stage_T<T, 32, PITCH>(pbuf, p.in, 0, p.N, p.C, p.IH, p.IW, p.bmode, n0, p.NI, iy0, ix0, 0, PH, PW, 0, tid, 256);
+
+    // weight tile (chunk cc, tap tt); tiles past the end re-read the last chunk (never consumed)
+#define SP_WISSUE(SET, cc, tt)                                                                     \
+    do { const int c_ = (cc) < nchunks ? (cc) : nchunks - 1;                                       \
+         const size_t off_ = ((size_t)(tt) * p.Cpad + (size_t)c_ * BC) * sizeof(T);                \
+         _Pragma("unroll") for (int i = 0; i < NWP; ++i) wS[SET][i] = *(const u32x4_t*)(wsrc[i] + off_); } while (0)
+#define SP_WRETIRE(SET, SLOT)                                                                      \
+    do { _Pragma("unroll") for (int i = 0; i < NWP; ++i)                                           \
+             *(u32x4_t*)(wbuf + (SLOT) * WBYTES + wdst[i]) = wS[SET][i]; } while (0)
+    // dword columns 2*tt, 2*tt+1 (of 8) of the next chunk's patch: channel c = c0n + 2*(wave + 4*col) is wave-uniform
+#define SP_PISSUE(SET, tt)                                                                                  \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                     \
+            const int c = c0n + 2 * (wave + 4 * (2 * (tt) + d));                                            \
+            const bf16_t* pl0 = inb + (size_t)(c < p.C ? c : 0) * plane;                                    \
+            const bf16_t* pl1 = inb + (size_t)(c + 1 < p.C ? c + 1 : 0) * plane;                            \
+            _Pragma("unroll") for (int j = 0; j < QJ; ++j) {                                                \
+                rlo[SET][d * QJ + j] = pl0[qoff[j]];                                                        \
+                rhi[SET][d * QJ + j] = pl1[qoff[j]];                                                        \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+#define SP_PRETIRE(SET, tt)                                                                                 \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                     \
+            const int c = c0n + 2 * (wave + 4 * (2 * (tt) + d));                                            \
+            const bool c0ok = c < p.C, c1ok = c + 1 < p.C;                                                  \
+            _Pragma("unroll") for (int j = 0; j < QJ; ++j) {                                                \
+                const unsigned lo_ = (qok[j] && c0ok) ? (unsigned)rlo[SET][d * QJ + j] : 0u;                \
+                const unsigned hi_ = (qok[j] && c1ok) ? (unsigned)rhi[SET][d * QJ + j] : 0u;                \
+                *(unsigned*)(pnext + pdst[j] + (2 * (tt) + d) * 16) = lo_ | (hi_ << 16);                    \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+#define SP_COMPUTE(SLOT, tt)                                                                                    \
+    do {                                                                                                        \
+        const unsigned toff = (unsigned)toffs[tt];                                                              \
+        const unsigned char* ab = wbuf + (SLOT) * WBYTES + arow;                                                \
+        _Pragma("unroll") for (int kk = 0; kk < BC / KS; ++kk) {                                                \
+            bf16x8_t a[WM], b[WN];                                                                              \
+            _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
+                a[mi] = *(const bf16x8_t*)(ab + mi * 32 * PITCH + kk * 32);                                     \
+            _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                                   \
+                b[ni] = *(const bf16x8_t*)(pcur + brow[ni] + toff + kk * 32);                                   \
+            _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
+                _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                               \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);  \
+        }                                                                                                       \
+    } while (0)
+    // step tt of the current chunk: tile (chunk, tt) sits in ring slot tt%3; issue into register set tt%3,
+    // retire the set issued two steps ago ((tt+1)%3) = tile tt+1 -> slot (tt+1)%3
+#define SP_STEP(tt)                                                                         \
+    do {                                                                                    \
+        __syncthreads();                                                                    \
+        if ((tt) + 3 < NT) SP_WISSUE((tt) % 3, chunk, (tt) + 3);                            \
+        else SP_WISSUE((tt) % 3, chunk + 1, (tt) + 3 - NT);                                 \
+        if ((tt) < 4) SP_PISSUE((tt) % 3, tt);                                              \
+        SP_COMPUTE((tt) % 3, tt);                                                           \
+        SP_WRETIRE(((tt) + 1) % 3, ((tt) + 1) % 3);                                         \
+        if ((tt) >= 2 && (tt) < 6) SP_PRETIRE(((tt) + 1) % 3, (tt) - 2);                    \
+    } while (0)
+
+    SP_WISSUE(0, 0, 0);
+    SP_WRETIRE(0, 0);
+    SP_WISSUE(1, 0, 1);
+    SP_WISSUE(2, 0, 2);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const unsigned char* pcur = pbuf + (chunk & 1) * patch_bytes;
+        unsigned char* pnext = pbuf + ((chunk + 1) & 1) * patch_bytes;
+        const int c0n = (chunk + 1 < nchunks ? chunk + 1 : chunk) * BC;     // last chunk: harmless re-load
+        SP_STEP(0); SP_STEP(1); SP_STEP(2); SP_STEP(3); SP_STEP(4); SP_STEP(5); SP_STEP(6); SP_STEP(7); SP_STEP(8);
+    }
+#undef SP_STEP
+#undef SP_COMPUTE
+#undef SP_PRETIRE
+#undef SP_PISSUE
+#undef SP_WRETIRE
+#undef SP_WISSUE
+
+    const bool out_f32 = p.out_f32;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int oy = pu[ni] * p.ost + ph.ooy, ox = pv[ni] * p.ost + ph.oox;
+        const bool okp = pvalid[ni] && pn[ni] < p.N && pu[ni] < ph.OHt && pv[ni] < ph.OWt &&
+                         (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
+        if (!okp) continue;
+        const size_t pbase = (size_t)pn[ni] * p.K * p.OHf * p.OWf + (size_t)oy * p.OWf + ox;
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < p.K) {
+                    float v = acc[mi][ni][r];
+                    if (p.bias) v += p.bias[m];
+                    const size_t idx = pbase + (size_t)m * p.OHf * p.OWf;
+                    if (p.resid) v += out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
+                    if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
+                    if (out_f32) ((float*)p.out)[idx] = v; else ((bf16_t*)p.out)[idx] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Weight packing: wp[phase][m][t][c] = w[m*sm + c*sc + r_t*sr + s_t*ss] * scale   (zero padded)
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1225,7 +1448,28 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);                                            \
     } while (0)
-    if (bm == 128) GC_LAUNCH(2, 2, 2, 2);
+    bool sp_done = false;
+    if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
+        // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, patch <= 192 pixels
+        bool ok = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 &&
+                  p.NI * p.ph[0].PH * p.ph[0].PW <= 192 && !env_int("HIFIC_NO_SP", 0);
+        if (ok) {
+            const int npatch = p.NI * p.ph[0].PH * p.ph[0].PW;
+            const size_t lds_sp = 64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(npatch + 1) * PITCH + 15) & ~(size_t)15);
+            if (lds_sp <= (size_t)kLdsBudget) {
+                if (bm == 128) {
+                    hipFuncSetAttribute((const void*)gconv_sp9_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
+                    hipLaunchKernelGGL((gconv_sp9_kernel<2>), grid, dim3(256), lds_sp, st, p);
+                } else {
+                    hipFuncSetAttribute((const void*)gconv_sp9_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
+                    hipLaunchKernelGGL((gconv_sp9_kernel<1>), grid, dim3(256), lds_sp, st, p);
+                }
+                sp_done = true;
+            }
+        }
+    }
+    if (sp_done) { /* launched */ }
+    else if (bm == 128) GC_LAUNCH(2, 2, 2, 2);
     else if (bm == 64) GC_LAUNCH(2, 2, 1, 2);
     else GC_LAUNCH(1, 4, 1, 1);
 #undef GC_LAUNCH
