@@ -11,6 +11,7 @@
 #include "gconv.h"
 #include <type_traits>
 #include <string.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 // K-slice of one MFMA and LDS row padding per element type; BC (channels per chunk) is a kernel template parameter
@@ -48,32 +49,23 @@ __device__ __forceinline__ void px_load(unsigned (&lo)[NDW], unsigned (&hi)[NDW]
         typedef typename SrcT<SF32>::type S;
         const S* sp = (const S*)src;
         unsigned off = qoff + (unsigned)(c0 + 2 * wv) * plane;
-        if (full) {
+        // Channels past C read element 0 instead (clamped address, unconditional load) and are zeroed at store
+        // time: a select on the loaded value right here made the compiler wait for every pair of loads
+        // (8 serial round trips per pixel on every partial chunk, i.e. on all of a 60-channel layer).
 #pragma unroll
-            for (int i = 0; i < NDW; ++i) {
-                if constexpr (SF32) { lo[i] = __float_as_uint(sp[off]); hi[i] = __float_as_uint(sp[off + plane]); }
-                else { lo[i] = sp[off]; hi[i] = sp[off + plane]; }
-                off += 8u * plane;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NDW; ++i) {
-                const int c = c0 + 2 * (wv + 4 * i);
-                const unsigned o0 = c < C ? off : 0u, o1 = c + 1 < C ? off + plane : 0u;
-                unsigned l, h;
-                if constexpr (SF32) { l = __float_as_uint(sp[o0]); h = __float_as_uint(sp[o1]); }
-                else { l = sp[o0]; h = sp[o1]; }
-                // zero out-of-range channels now (bf16 zero == f32 zero bit pattern)
-                lo[i] = c < C ? l : 0u; hi[i] = c + 1 < C ? h : 0u;
-                off += 8u * plane;
-            }
+        for (int i = 0; i < NDW; ++i) {
+            const int c = c0 + 2 * (wv + 4 * i);
+            const unsigned o0 = (full || c < C) ? off : 0u, o1 = (full || c + 1 < C) ? off + plane : 0u;
+            if constexpr (SF32) { lo[i] = __float_as_uint(sp[o0]); hi[i] = __float_as_uint(sp[o1]); }
+            else { lo[i] = sp[o0]; hi[i] = sp[o1]; }
+            off += 8u * plane;
         }
     }
 }
-// Packs and writes one pixel row; ok=false writes zeros (padding / masked pixels)
+// Packs and writes one pixel row; ok=false writes zeros (padding / masked pixels); channels >= C are zeroed
 template <typename T, int NDW, bool SF32>
 __device__ __forceinline__ void px_store(unsigned char* row, const unsigned (&lo)[NDW], const unsigned (&hi)[NDW],
-                                         bool ok) {
+                                         bool ok, int C, int c0, int wv, bool full) {
 #pragma unroll
     for (int i = 0; i < NDW; ++i) {
         unsigned v;
@@ -82,7 +74,9 @@ __device__ __forceinline__ void px_store(unsigned char* row, const unsigned (&lo
         } else {
             unsigned l = lo[i], h = hi[i];
             if constexpr (SF32) { l = f2bf(__uint_as_float(l)); h = f2bf(__uint_as_float(h)); }
-            v = ok ? (l | (h << 16)) : 0u;
+            const int c = c0 + 2 * (wv + 4 * i);
+            const bool okl = ok && (full || c < C), okh = ok && (full || c + 1 < C);
+            v = (okl ? l : 0u) | ((okh ? h : 0u) << 16);
         }
         *(unsigned*)(row + i * 16) = v;
     }
@@ -123,7 +117,7 @@ __device__ __forceinline__ void stage_T_impl(unsigned char* lds, const void* src
         px_decode(q, npatch, npp, PW, inv_npp, inv_pw, n0, y0, x0, N, C, H, W, bmode, qoff, ok, PWs, qs);
         unsigned lo[NDW], hi[NDW];
         px_load<T, NDW, SF32>(lo, hi, src, qoff, plane, C, c0, wv, full);
-        px_store<T, NDW, SF32>(lds + (size_t)qs * PITCH + wv * 4, lo, hi, ok);
+        px_store<T, NDW, SF32>(lds + (size_t)qs * PITCH + wv * 4, lo, hi, ok, C, c0, wv, full);
     }
 }
 template <typename T, int DWR, int PITCH>
@@ -759,12 +753,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
         const int tn = tile / (p.tiles_x * p.tiles_y);
         const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
         __syncthreads();
+        if (!(p.dbg & 1))
         stage_T<T, DWR, PITCH>(at, p.a, p.a_f32, p.N, p.M, p.AH, p.AW, PAD_ZERO,
                                n0, p.NI, u0, v0, 0, p.TH, p.TW, m0, tid, 256);
+        if (!(p.dbg & 2))
         stage_T<T, DWR, PITCH>(patch, p.b, p.b_f32, p.N, p.C, p.BH, p.BW, p.bmode,
                                n0, p.NI, u0 * p.ist + gp.dy_min, v0 * p.ist + gp.dx_min, 0, PH, PW, c0, tid, 256);
         __syncthreads();
-        for (int ks = 0; ks < npix / KS; ++ks) {
+        for (int ks = 0; ks < ((p.dbg & 4) ? 0 : npix / KS); ++ks) {
             if constexpr (std::is_same<T, float>::value) {
                 const int r = ks * 2 + lhi;
                 const float a = *(const float*)(at + (size_t)r * PITCH + (wm * 32 + l31) * 4);
@@ -1264,14 +1260,16 @@ static hipEvent_t g_prof_ev[PROF_MAX][2];
 static bool g_prof_ev_made[PROF_MAX];
 static int g_prof_kind[PROF_MAX];
 static double g_prof_flops[PROF_MAX];
+static char g_prof_tag[PROF_MAX][112];     // launch shape, printed per launch when HIFIC_PROF_DUMP=1
 
-static int prof_open(int kind, double flops, hipStream_t st) {
+static int prof_open(int kind, double flops, hipStream_t st, const char* tag = "") {
     if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
     const int i = g_prof_n++;
     if (!g_prof_ev_made[i]) {
         hipEventCreate(&g_prof_ev[i][0]); hipEventCreate(&g_prof_ev[i][1]); g_prof_ev_made[i] = true;
     }
     g_prof_kind[i] = kind; g_prof_flops[i] = flops;
+    strncpy(g_prof_tag[i], tag, sizeof(g_prof_tag[i]) - 1); g_prof_tag[i][sizeof(g_prof_tag[i]) - 1] = 0;
     hipEventRecord(g_prof_ev[i][0], st);
     return i;
 }
@@ -1281,12 +1279,15 @@ extern "C" int hific_prof_begin(void) { g_prof_on = true; g_prof_n = 0; return H
 // Synchronises the recorded events; out arrays have PK_NKIND entries: total ms, total FLOPs, launch count.
 extern "C" int hific_prof_end(double* ms, double* flops, int* count) {
     g_prof_on = false;
+    const char* dump_e = getenv("HIFIC_PROF_DUMP");
+    const bool dump = dump_e && atoi(dump_e) != 0;
     for (int k = 0; k < PK_NKIND; ++k) { ms[k] = 0; flops[k] = 0; count[k] = 0; }
     for (int i = 0; i < g_prof_n; ++i) {
         if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) return HIFIC_ERR_LAUNCH;
         float t = 0.f;
         hipEventElapsedTime(&t, g_prof_ev[i][0], g_prof_ev[i][1]);
         ms[g_prof_kind[i]] += t; flops[g_prof_kind[i]] += g_prof_flops[i]; count[g_prof_kind[i]]++;
+        if (dump) fprintf(stderr, "HIFIC_PROF %d %.3f %.4g %s\n", g_prof_kind[i], t * 1e3, g_prof_flops[i], g_prof_tag[i]);
     }
     g_prof_n = 0;
     return HIFIC_OK;
@@ -1309,7 +1310,10 @@ static bool choose_tile(int N, int OHt, int OWt, int ist, int span_y, int span_x
         const long long budget = pass == 0 ? pref_budget : kLdsBudget;
         double best = 1e300;
         bool found = false;
-        const int twmax = OWt < 32 ? OWt : 32;
+        const int twmax = OWt < GC_NPIX ? OWt : GC_NPIX;
+        // every patch row is a separate run of cache lines: charge ~one extra 128-byte line per row so that big
+        // planes get wide tiles (narrow tiles re-fetch each line once per tile that touches it)
+        const double line_px = (double)env_int("HIFIC_LINE_PX", 48);
         for (int tw = twmax; tw >= 1; --tw) {
             if (tw < 4 && tw != twmax) break;
             int thmax = GC_NPIX / tw; if (thmax > OHt) thmax = OHt;
@@ -1323,7 +1327,7 @@ static bool choose_tile(int N, int OHt, int OWt, int ist, int span_y, int span_x
                     const long long bytes = (long long)ni * ph * pw * pitch + fixed_bytes;
                     if (bytes > budget) continue;
                     const double tiles = (double)cdiv(OHt, th) * cdiv(OWt, tw) * cdiv(N, ni);
-                    const double cost = tiles * (128.0 * ntaps + 3.0 * (double)(ni * ph * pw));
+                    const double cost = tiles * (128.0 * ntaps + 3.0 * (double)(ni * ph) * ((double)pw + line_px));
                     // prefer wider tiles on ties (longer coalesced runs)
                     if (cost < best * (1.0 - 1e-9)) { best = cost; TH = th; TW = tw; NI = ni; found = true; }
                 }
@@ -1378,7 +1382,14 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     const int wbytes = 512 + 2 * bm * PITCH;
     int maxtaps = 1;
     for (int i = 0; i < p.nphase; ++i) if (p.ph[i].ntaps > maxtaps) maxtaps = p.ph[i].ntaps;
-    if (!choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, 72 * 1024, p.TH, p.TW, p.NI, maxtaps))
+    // Full-LDS tiles (1 workgroup per CU, fewer halo re-reads) when they still give >= one workgroup per CU;
+    // otherwise tiles small enough for two co-resident workgroups.
+    bool tiled = false;
+    if (choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, kLdsBudget, p.TH, p.TW, p.NI, maxtaps)) {
+        const long long g = (long long)cdiv(OHt, p.TH) * cdiv(OWt, p.TW) * cdiv(p.N, p.NI) * (p.Kpad / bm) * p.nphase;
+        tiled = g >= env_int("HIFIC_GC_BIGTILE_MIN_GRID", 256);
+    }
+    if (!tiled && !choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, 72 * 1024, p.TH, p.TW, p.NI, maxtaps))
         return HIFIC_ERR_UNSUPPORTED;
     p.tiles_n = cdiv(p.N, p.NI);
     long long wp_elems = 0;
@@ -1440,7 +1451,11 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     double aflops = 0;
     for (int i = 0; i < p.nphase; ++i)
         aflops += 2.0 * p.K * p.C * p.ph[i].ntaps * (double)p.N * p.ph[i].OHt * p.ph[i].OWt;
-    const int pslot = prof_open(bm == 128 ? PK_GCONV128 : (bm == 64 ? PK_GCONV64 : PK_GCONV32), aflops, st);
+    char ptag[112];
+    snprintf(ptag, sizeof(ptag), "gconv K%d C%d N%d in%dx%d out%dx%d ph%d taps%d ist%d ost%d tile%dx%dx%d bm%d grid%d",
+             p.K, p.C, p.N, p.IH, p.IW, p.OHf, p.OWf, p.nphase, maxtaps, p.ist, p.ost, p.NI, p.TH, p.TW, bm,
+             max_tiles * (p.Kpad / bm) * p.nphase);
+    const int pslot = prof_open(bm == 128 ? PK_GCONV128 : (bm == 64 ? PK_GCONV64 : PK_GCONV32), aflops, st, ptag);
 #define GC_LAUNCH(WGM, WGN, WM, WN)                                                                      \
     do {                                                                                                 \
         auto kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN>;                                                \
@@ -1687,7 +1702,11 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
         if (!p.ws) return HIFIC_ERR_WS;
     }
     dim3 grid((p.Mpad / 64) * (p.Cpad / 64), p.ngroups, p.nsplit);
-    const int pslot = prof_open(PK_WGRAD, 2.0 * p.M * p.C * p.ntaps * (double)p.N * p.AH * p.AW, st);
+    char ptag[112];
+    snprintf(ptag, sizeof(ptag), "wgrad M%d C%d N%d a%dx%d taps%d ist%d tile%dx%dx%d split%d grid%d",
+             p.M, p.C, p.N, p.AH, p.AW, p.ntaps, p.ist, p.NI, p.TH, p.TW, p.nsplit,
+             (p.Mpad / 64) * (p.Cpad / 64) * p.ngroups * p.nsplit);
+    const int pslot = prof_open(PK_WGRAD, 2.0 * p.M * p.C * p.ntaps * (double)p.N * p.AH * p.AW, st, ptag);
     bool pipe = false;
     if constexpr (std::is_same<T, bf16_t>::value) {
         int npatch_max = 0;
@@ -1774,7 +1793,9 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     auto kfn = wgrad_im2col_kernel<T>;
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int pslot = prof_open(PK_WGRAD, 2.0 * g.K * g.C * nt * (double)g.N * g.OH() * g.OW(), st);
+    char ptag[112];
+    snprintf(ptag, sizeof(ptag), "wgrad_im2col K%d C%d N%d out%dx%d taps%d split%d", g.K, g.C, g.N, g.OH(), g.OW(), nt, p.nsplit);
+    const int pslot = prof_open(PK_WGRAD, 2.0 * g.K * g.C * nt * (double)g.N * g.OH() * g.OW(), st, ptag);
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
     prof_close(pslot, st);
     int rc = hific_launch_status();

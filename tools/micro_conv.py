@@ -10,21 +10,25 @@ which = sys.argv[1] if len(sys.argv) > 1 else "all"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
 hific_amd.set_compute_dtype(torch.bfloat16)
-N, C, K, H = 16, 960, 960, 16
+E = lambda k, d: int(os.environ.get(k, d))
+N, C, K, H, R, ST = E("MN", 16), E("MC", 960), E("MK", 960), E("MH", 16), E("MR", 3), E("MS", 1)
+if ST == 1: pads = (R // 2,) * 4
+else: pads = (1, 0, 0, 1)                    # (top, left, bottom, right) of the encoder's asymmetric reflect pad
+OH = (H + pads[0] + pads[2] - R) // ST + 1
 x = torch.randn(N, C, H, H, device=dev).bfloat16().requires_grad_(True)
-w = (torch.randn(K, C, 3, 3, device=dev) * 0.01).requires_grad_(True)
+w = (torch.randn(K, C, R, R, device=dev) * 0.01).requires_grad_(True)
 b = torch.zeros(K, device=dev, requires_grad=True)
-gy = torch.randn(N, K, H, H, device=dev).bfloat16()
+gy = torch.randn(N, K, OH, OH, device=dev).bfloat16()
 ws = lib.workspace(dev)
 def run(name, fn):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(iters): fn()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / iters
-    fl = 2.0 * N * H * H * K * C * 9
+    fl = 2.0 * N * OH * OH * K * C * R * R
     print(f"{name}: {dt*1e6:.1f} us  ({fl/dt/1e12:.1f} TFLOP/s incl. pack)", flush=True)
-geom = (N, C, H, H, K, 3, 3, 1, 1, 1, 1, 1, lib.PAD_REFLECT)
-y = torch.empty(N, K, H, H, device=dev, dtype=torch.bfloat16)
+geom = (N, C, H, H, K, R, R, ST, pads[0], pads[1], pads[2], pads[3], lib.PAD_REFLECT)
+y = torch.empty(N, K, OH, OH, device=dev, dtype=torch.bfloat16)
 dx = torch.empty_like(x)
 dw = torch.empty_like(w)
 if which in ("fwd", "all"):
