@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
     const int split = blockIdx.z;
     const int PH = gp.PH, PW = gp.PW, npp = PH * PW;
     const int npatch = p.NI * npp;
-    const size_t patch_bytes = ((size_t)npatch * PITCH + 15) & ~(size_t)15;
+    const size_t patch_bytes = ((size_t)(npatch + 1) * PITCH + 15) & ~(size_t)15;   // + dump row for lanes past the patch
     constexpr int ABYTES = 64 * APITCH;
 
     int* qtab = (int*)smem;                                         // [128]
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
     if (tile_hi > p.ntiles) tile_hi = p.ntiles;
 
     u32x4_t areg[4]; unsigned aokm = 0;
-    unsigned plo[QI][NDW], phi[QI][NDW];
+    unsigned short plo[QI][NDW], phi[QI][NDW];                      // raw 16-bit loads, untouched until the store
     unsigned qoff[QI]; unsigned qokm = 0;
 
 #define WG_TILE_ORIGIN(tile_, n0_, u0_, v0_)                        \
@@ -967,15 +967,13 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
     do {                                                                                                    \
         _Pragma("unroll") for (int j = 0; j < QI; ++j) {                                                    \
             const int q = lane + 64 * j;                                                                    \
-            if (q < npatch) {                                                                               \
-                unsigned char* row = (buf_) + (size_t)q * PITCH + pwv * 4;                                  \
-                _Pragma("unroll") for (int ii = 0; ii < HALF; ++ii) {                                       \
-                    const int i = (h) * HALF + ii;                                                          \
-                    const int c = c0 + 2 * (pwv + 4 * i);                                                   \
-                    const unsigned l = (((qokm >> j) & 1u) && (cfull || c < p.C)) ? plo[j][i] : 0u;                     \
-                    const unsigned hh = (((qokm >> j) & 1u) && (cfull || c + 1 < p.C)) ? phi[j][i] : 0u;                \
-                    *(unsigned*)(row + i * 16) = l | (hh << 16);                                            \
-                }                                                                                           \
+            unsigned char* row = (buf_) + (size_t)(q < npatch ? q : npatch) * PITCH + pwv * 4;              \
+            _Pragma("unroll") for (int ii = 0; ii < HALF; ++ii) {                                           \
+                const int i = (h) * HALF + ii;                                                              \
+                const int c = c0 + 2 * (pwv + 4 * i);                                                       \
+                const unsigned l = (((qokm >> j) & 1u) && (cfull || c < p.C)) ? (unsigned)plo[j][i] : 0u;   \
+                const unsigned hh = (((qokm >> j) & 1u) && (cfull || c + 1 < p.C)) ? (unsigned)phi[j][i] : 0u; \
+                *(unsigned*)(row + i * 16) = l | (hh << 16);                                                \
             }                                                                                               \
         }                                                                                                   \
     } while (0)
@@ -985,7 +983,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
         const int colb = ((g & 1) * 16 + (i16 & 3) * 4) * 2;                                                \
         typedef __attribute__((address_space(3))) short4_t* lds_s4;                                         \
         typedef __attribute__((ext_vector_type(8))) short short8_t;                                         \
-        for (int ks = (ks_lo); ks < (ks_hi); ++ks) {                                                        \
+        _Pragma("unroll") for (int ks = (ks_lo); ks < (ks_hi); ++ks) {                                       \
             const bf16x8_t a = *(const bf16x8_t*)((ab_) + (wm * 32 + l31) * APITCH + (ks * 16 + lhi * 8) * 2); \
             const int rb = ks * 16 + (g >> 1) * 8 + (i16 >> 2);                                             \
             const unsigned char* b0row = (pb_) + (size_t)qtab[rb] * PITCH + wn * 64 + colb;                 \
@@ -1004,7 +1002,12 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
         }                                                                                                   \
     } while (0)
 
+    // Register prefetch at a distance of one full tile, branch-free: iteration t stores tile t+1 (loaded during
+    // iteration t-1) into the other LDS buffers, requests tile t+2 and then runs the 72 MFMAs of tile t, so every
+    // load has a whole tile of compute to land and the loop body is one basic block with constant load counts.
+    // Tiles past the end re-load the last tile (never consumed).
     if (tile_lo < tile_hi) {
+        const int tile_last = tile_hi - 1;
         {
             WG_TILE_ORIGIN(tile_lo, n0, u0, v0)
             WG_LOAD_A(n0, u0, v0);
@@ -1013,24 +1016,30 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
             WG_STORE_A(abuf);
             WG_STORE_P(pbuf, 0); WG_STORE_P(pbuf, 1);
         }
+        {
+            const int t1 = tile_lo + 1 < tile_hi ? tile_lo + 1 : tile_last;
+            WG_TILE_ORIGIN(t1, n0, u0, v0)
+            WG_LOAD_A(n0, u0, v0);
+            WG_DECODE_P(n0, u0, v0);
+            WG_LOAD_P(0); WG_LOAD_P(1);
+        }
         for (int tile = tile_lo; tile < tile_hi; ++tile) {
             const int cur = (tile - tile_lo) & 1;
-            unsigned char* ab = abuf + cur * ABYTES;
-            unsigned char* pb = pbuf + cur * patch_bytes;
+            const unsigned char* ab = abuf + cur * ABYTES;
+            const unsigned char* pb = pbuf + cur * patch_bytes;
             unsigned char* abn = abuf + (cur ^ 1) * ABYTES;
             unsigned char* pbn = pbuf + (cur ^ 1) * patch_bytes;
-            const bool more = (tile + 1 < tile_hi) && !(p.dbg & 1);
             __syncthreads();
-            if (more) {
-                WG_TILE_ORIGIN(tile + 1, n0, u0, v0)
+            WG_STORE_A(abn);
+            WG_STORE_P(pbn, 0); WG_STORE_P(pbn, 1);
+            {
+                const int t2 = tile + 2 < tile_hi ? tile + 2 : tile_last;
+                WG_TILE_ORIGIN(t2, n0, u0, v0)
                 WG_LOAD_A(n0, u0, v0);
                 WG_DECODE_P(n0, u0, v0);
-                WG_LOAD_P(0);
+                WG_LOAD_P(0); WG_LOAD_P(1);
             }
-            if (!(p.dbg & 2)) WG_COMPUTE(ab, pb, 0, GC_NPIX / 32);
-            if (more) { WG_STORE_P(pbn, 0); WG_LOAD_P(1); }
-            if (!(p.dbg & 2)) WG_COMPUTE(ab, pb, GC_NPIX / 32, GC_NPIX / 16);
-            if (more) { WG_STORE_A(abn); WG_STORE_P(pbn, 1); }
+            WG_COMPUTE(ab, pb, 0, GC_NPIX / 16);
         }
     }
 #undef WG_COMPUTE
@@ -1133,6 +1142,22 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
     int tile_hi = tile_lo + p.tiles_per_split;
     if (tile_hi > p.ntiles) tile_hi = p.ntiles;
 
+    // columns of this thread: k = i (f32) or 2*i + e (bf16) <-> virtual column c0 + ... = tap*4 + channel
+    constexpr int NCOL = std::is_same<T, float>::value ? NDW : 2 * NDW;
+    int coff[NCOL], cdy[NCOL], cdx[NCOL], ccol[NCOL];
+    unsigned colv = 0;
+#pragma unroll
+    for (int k = 0; k < NCOL; ++k) {
+        const int col = c0 + (std::is_same<T, float>::value ? (wv + 4 * k) : 2 * (wv + 4 * (k >> 1)) + (k & 1));
+        const int t = col >> 2, cc = col & 3;
+        const bool v = t < p.ntaps_real && cc < p.creal;
+        const int tt = t < p.ntaps_real ? t : 0;
+        cdy[k] = p.tsign * (int)p.tap_dy[tt]; cdx[k] = p.tsign * (int)p.tap_dx[tt]; ccol[k] = v ? cc : 0;
+        coff[k] = v ? (cc * (int)bplane + cdy[k] * p.BW + cdx[k]) : 0;
+        colv |= (v ? 1u : 0u) << k;
+    }
+    const int tdy_min = p.grp[0].dy_min, tdx_min = p.grp[0].dx_min, tdy_max = p.grp[0].PH, tdx_max = p.grp[0].PW;
+
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const int tx = tile % p.tiles_x;
         const int ty = (tile / p.tiles_x) % p.tiles_y;
@@ -1143,41 +1168,55 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
         // the tile that lie outside the (padded) domain must contribute nothing: they are zeroed via the B image.
         stage_T<T, DWR, PITCH>(at, p.a, p.a_f32, p.N, p.M, p.a_h, p.a_w, p.a_bmode, n0, p.NI, u0 + p.a_y0,
                                v0 + p.a_x0, 0, p.TH, p.TW, m0, tid, 256);
-        // im2col slice: rows = tile pixels, dword dw = wv + 4*i covers columns (c0 + 2*dw, c0 + 2*dw + 1)
+        // im2col slice: rows = tile pixels, dword dw = wv + 4*i covers columns (c0 + 2*dw, c0 + 2*dw + 1).
+        // The thread's NCOL columns (tap, channel) are fixed for the whole kernel (colv / coff / cdy / cdx above).
+        // Interior tiles (every tap of every pixel inside the B plane, every pixel inside the A domain: all but the
+        // rim) take the fast path: one add per element, all NCOL loads of a pixel in flight together.
+        const bool interior = (n0 + p.NI <= p.N) && (u0 + p.TH <= p.AH) && (v0 + p.TW <= p.AW) &&
+                              (u0 + p.b_y0 + tdy_min >= 0) && (u0 + p.TH - 1 + p.b_y0 + tdy_max < p.BH) &&
+                              (v0 + p.b_x0 + tdx_min >= 0) && (v0 + p.TW - 1 + p.b_x0 + tdx_max < p.BW);
         for (int q = lane; q < npix; q += 64) {
             const int img = (int)(((float)q + 0.5f) * inv_thw);
             const int rem = q - img * thw;
             const int tyy = (int)(((float)rem + 0.5f) * inv_tw);
             const int txx = rem - tyy * p.TW;
             const int n = n0 + img, ud = u0 + tyy, vd = v0 + txx;
-            const bool pix_ok = (n < p.N) && (ud < p.AH) && (vd < p.AW);
-            float vals[NDW][2];
+            unsigned raw[NCOL];
+            unsigned okm = 0;
+            if (interior) {
+                const unsigned pixbase = (unsigned)(n * p.creal) * bplane + (unsigned)((ud + p.b_y0) * p.BW + (vd + p.b_x0));
 #pragma unroll
-            for (int i = 0; i < NDW; ++i) {
+                for (int k = 0; k < NCOL; ++k) {
+                    const unsigned off = pixbase + (unsigned)coff[k];
+                    if (std::is_same<T, float>::value || p.b_f32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
+                    else raw[k] = ((const bf16_t*)p.b)[off];
+                }
+                okm = colv;
+            } else {
+                const bool pix_ok = (n < p.N) && (ud < p.AH) && (vd < p.AW);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int col = c0 + (std::is_same<T, float>::value ? (wv + 4 * i) : 2 * (wv + 4 * i) + e);
-                    const int t = col >> 2, cc = col & 3;
-                    const int tt = t < p.ntaps_real ? t : 0;
-                    int yb = ud + p.b_y0 + p.tsign * (int)p.tap_dy[tt];
-                    int xb = vd + p.b_x0 + p.tsign * (int)p.tap_dx[tt];
+                for (int k = 0; k < NCOL; ++k) {
+                    int yb = ud + p.b_y0 + cdy[k];
+                    int xb = vd + p.b_x0 + cdx[k];
                     if (p.bmode == PAD_REFLECT) { yb = reflect_idx(yb, p.BH); xb = reflect_idx(xb, p.BW); }
-                    const bool ok = pix_ok && t < p.ntaps_real && cc < p.creal && (unsigned)yb < (unsigned)p.BH &&
-                                    (unsigned)xb < (unsigned)p.BW;
-                    const unsigned off = ok ? ((unsigned)(n * p.creal + cc) * bplane + (unsigned)(yb * p.BW + xb)) : 0u;
-                    float v;
-                    if (std::is_same<T, float>::value || p.b_f32) v = ((const float*)p.b)[off];
-                    else v = bf2f(((const bf16_t*)p.b)[off]);
-                    vals[i][e] = ok ? v : 0.f;
-                    if (std::is_same<T, float>::value) break;
+                    const bool ok = pix_ok && ((colv >> k) & 1u) && (unsigned)yb < (unsigned)p.BH && (unsigned)xb < (unsigned)p.BW;
+                    const unsigned off = ok ? ((unsigned)(n * p.creal + ccol[k]) * bplane + (unsigned)(yb * p.BW + xb)) : 0u;
+                    if (std::is_same<T, float>::value || p.b_f32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
+                    else raw[k] = ((const bf16_t*)p.b)[off];
+                    okm |= (ok ? 1u : 0u) << k;
                 }
             }
             unsigned char* row = bt + (size_t)q * PITCH + wv * 4;
 #pragma unroll
             for (int i = 0; i < NDW; ++i) {
                 unsigned w;
-                if constexpr (std::is_same<T, float>::value) w = __float_as_uint(vals[i][0]);
-                else w = (unsigned)f2bf(vals[i][0]) | ((unsigned)f2bf(vals[i][1]) << 16);
+                if constexpr (std::is_same<T, float>::value) {
+                    w = ((okm >> i) & 1u) ? raw[i] : 0u;
+                } else {
+                    unsigned l = raw[2 * i], h = raw[2 * i + 1];
+                    if (p.b_f32) { l = f2bf(__uint_as_float(l)); h = f2bf(__uint_as_float(h)); }
+                    w = (((okm >> (2 * i)) & 1u) ? l : 0u) | ((((okm >> (2 * i + 1)) & 1u) ? h : 0u) << 16);
+                }
                 *(unsigned*)(row + i * 16) = w;
             }
         }
@@ -1229,6 +1268,29 @@ __global__ void wgrad_im2col_finalize_kernel(const WgParams p, int Md, int Cd) {
         const long long o = md * p.sm + cd * p.sc + p.tap_r[t] * p.sr + p.tap_s[t] * p.ss;
         if (p.accumulate) p.dw[o] += s; else p.dw[o] = s;
     }
+}
+
+// First reduction stage for many pixel splits: out[g][l] = sum over the splits of group g of ws[split][l], on the
+// flat partial images (L4 float4 per split).  Fully coalesced; leaves <= 16 groups for the layout-changing finalize.
+__global__ void wgrad_reduce_kernel(const float4* __restrict__ ws, float4* __restrict__ out, unsigned L4, int nsplit,
+                                    int per_group) {
+    const unsigned l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L4) return;
+    const int sp0 = blockIdx.y * per_group;
+    int sp1 = sp0 + per_group; if (sp1 > nsplit) sp1 = nsplit;
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    int sp = sp0;
+    for (; sp + 4 <= sp1; sp += 4) {
+        const float4 v0 = ws[(size_t)sp * L4 + l], v1 = ws[(size_t)(sp + 1) * L4 + l];
+        const float4 v2 = ws[(size_t)(sp + 2) * L4 + l], v3 = ws[(size_t)(sp + 3) * L4 + l];
+        a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+        a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; sp < sp1; ++sp) {
+        const float4 v = ws[(size_t)sp * L4 + l];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    out[(size_t)blockIdx.y * L4 + l] = a;
 }
 
 // dw[m*sm + c*sc + r*sr + s*ss] (=|+=) sum_split ws[split][m][t][c]
@@ -1714,7 +1776,7 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
             int np_ = p.NI * p.grp[gi].PH * p.grp[gi].PW;
             if (np_ > npatch_max) npatch_max = np_;
         }
-        const size_t lds_pipe = 512 + 2 * (size_t)64 * (GC_NPIX * 2 + 16) + 2 * (((size_t)npatch_max * 144 + 15) & ~(size_t)15);
+        const size_t lds_pipe = 512 + 2 * (size_t)64 * (GC_NPIX * 2 + 16) + 2 * (((size_t)(npatch_max + 1) * 144 + 15) & ~(size_t)15);
         pipe = !p.a_f32 && !p.b_f32 && p.NI * p.TH * p.TW == GC_NPIX && p.TW % 8 == 0 && p.AW % 8 == 0 &&
                npatch_max <= 192 && lds_pipe <= (size_t)kLdsBudget && !env_int("HIFIC_NO_WGPIPE", 0);
         if (pipe) {
@@ -1731,6 +1793,20 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
     prof_close(pslot, st);
     int rc = hific_launch_status();
     if (rc != HIFIC_OK || p.direct) return rc;
+    if (p.nsplit > 24) {
+        // two-stage reduction: 16 coalesced group sums first, then the (strided) finalize over 16 partials
+        const int ngrp = 16;
+        const int per_group = cdiv(p.nsplit, ngrp);
+        const int groups = cdiv(p.nsplit, per_group);
+        const size_t L = (size_t)p.Mpad * p.ntaps * p.Cpad;          // multiple of 4 (Cpad % 64 == 0)
+        float* ws2 = (float*)ws.take(groups * L * sizeof(float));
+        if (ws2) {
+            const unsigned L4 = (unsigned)(L / 4);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)L4, 256), groups), dim3(256), 0, st,
+                               (const float4*)p.ws, (float4*)ws2, L4, p.nsplit, per_group);
+            p.ws = ws2; p.nsplit = groups;
+        }
+    }
     long long total = (long long)p.M * p.C * p.ntaps;
     int gx = (int)((total + 255) / 256); if (gx > 16384) gx = 16384;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(gx), dim3(256), 0, st, p, dw, sm, sc, sr, ss, accumulate);
@@ -1774,6 +1850,16 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     p.C = nt * 4;                                   // virtual columns
     p.Mpad = cdiv(p.M, 64) * 64; p.Cpad = cdiv(p.C, 64) * 64;
     p.dbg = 0;
+    {   // extent of the signed tap offsets (interior-tile test of the kernel's fast path)
+        int ymin = 0, ymax = 0, xmin = 0, xmax = 0;
+        for (int t = 0; t < nt; ++t) {
+            const int dyv = p.tsign * p.tap_dy[t], dxv = p.tsign * p.tap_dx[t];
+            if (t == 0) { ymin = ymax = dyv; xmin = xmax = dxv; }
+            if (dyv < ymin) ymin = dyv; if (dyv > ymax) ymax = dyv;
+            if (dxv < xmin) xmin = dxv; if (dxv > xmax) xmax = dxv;
+        }
+        p.grp[0].dy_min = ymin; p.grp[0].dx_min = xmin; p.grp[0].PH = ymax; p.grp[0].PW = xmax;
+    }
     // pixel tile: 8 x 16 (whole 128-pixel K extent; multiple of 16 for the bf16 MFMA)
     p.TW = p.AW < 16 ? p.AW : 16; p.TH = GC_NPIX / p.TW; if (p.TH > p.AH) p.TH = p.AH; p.NI = 1;
     while ((p.NI * p.TH * p.TW) % 16 != 0) ++p.TH;
@@ -1849,13 +1935,13 @@ size_t gc_ws_bytes_conv(const ConvGeom& g, int dtype) {
     const size_t kp = (size_t)cdiv(g.K, 128) * 128 + 128, cp = (size_t)cdiv(g.C, 64) * 64 + 64;
     size_t packed = kp * cp * g.R * g.S * es;
     size_t padbuf = (size_t)g.N * g.C * (g.H + g.pt + g.pb) * (g.W + g.pl + g.pr) * 4;
-    size_t part = kp * cp * g.R * g.S * 4 * 16;
+    size_t part = kp * cp * g.R * g.S * 4 * 32 + (size_t)1100 * 64 * 64 * 9 * 4;   // stage-2 groups + <= ~1100 block partials
     return packed + padbuf + part + 4096;
 }
 size_t gc_ws_bytes_convT(const ConvTGeom& g, int dtype) {
     const size_t es = dtype == HIFIC_F32 ? 4 : 2;
     const size_t kp = (size_t)cdiv(g.Co, 128) * 128 + 128, cp = (size_t)cdiv(g.Ci, 64) * 64 + 64;
     size_t packed = kp * cp * g.R * g.S * es;
-    size_t part = kp * cp * g.R * g.S * 4 * 16;
+    size_t part = kp * cp * g.R * g.S * 4 * 32 + (size_t)1100 * 64 * 64 * 9 * 4;
     return packed + part + 4096;
 }
