@@ -4,6 +4,7 @@
 // HBM-bound: a workgroup owns 64 consecutive pixels x all C channels; every channel row it touches is a
 // 128 B (bf16) / 256 B (f32) coalesced run; the three channel passes after the first hit L2.
 #include "common.h"
+#include <stdlib.h>
 
 // Workgroup = 64 consecutive pixels x all C channels, NW waves: wave w owns channels w, w+NW, ...  Loads are issued
 // 8 at a time per thread (clamped index + select instead of branches) so that the three channel passes are
@@ -175,12 +176,233 @@ __global__ void cn_bwd_param_reduce_kernel(const float* __restrict__ part, float
     if (accumulate) d[c] += s; else d[c] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Register-resident variants (the ones the C-ABI dispatches to whenever a configuration fits).
+// A workgroup owns PXB consecutive pixels x all C channels.  Lane = (pixel px = lane % PXB, channel sub-group
+// lane / PXB); channel group g = wave * (64/PXB) + sub of G = NW * 64/PXB groups owns channels g, g+G, ... (at most
+// CPT of them), which the thread keeps in registers: x (and dy) are read from memory exactly once, with all CPT
+// (2 CPT) loads of a thread in flight together, instead of three latency-bound passes.  PXB < 64 trades the length
+// of the coalesced runs (PXB * 2 bytes) for workgroups: a 16x16 plane with 960 channels and batch 16 gives 256
+// workgroups at PXB = 16 instead of 64 at PXB = 64.
+// The backward kernel also produces the gamma/beta gradient partials (sum over its pixels, via lane shuffles), so x
+// and dy are not read a second time for the parameter gradients.
+// ---------------------------------------------------------------------------------------------------
+template <int PXB>
+__device__ __forceinline__ float cn_sum_subs(float v) {       // sum over the channel sub-groups of a wave (same pixel)
+#pragma unroll
+    for (int o = PXB; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int PXB>
+__device__ __forceinline__ float cn_sum_px(float v) {         // sum over the PXB pixels of one channel sub-group
+#pragma unroll
+    for (int o = PXB >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int PXB, int NW, int CPT>
+__global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, T* __restrict__ y,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             int C, int HW, float eps, int relu) {
+    constexpr int SUBS = 64 / PXB, G = NW * SUBS;
+    __shared__ float red[2][NW][PXB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane % PXB, g = wave * SUBS + lane / PXB;
+    const int n = blockIdx.y;
+    const int hw0 = blockIdx.x * PXB + px;
+    const bool ok = hw0 < HW;
+    const int hw = ok ? hw0 : HW - 1;
+    // wave-uniform base + 32-bit per-lane offsets (one VGPR per load address; C*HW < 2^32 elements per image)
+    const T* xb = x + (size_t)n * C * HW;
+    T* yb = y + (size_t)n * C * HW;
+    float v[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { const int c = g + G * k; v[k] = DT<T>::ld(xb + ((unsigned)(c < C ? c : C - 1) * (unsigned)HW + (unsigned)hw)); }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) s += (g + G * k < C) ? v[k] : 0.f;
+    s = cn_sum_subs<PXB>(s);
+    if (lane < PXB) red[0][wave][px] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[0][w][px];
+    const float mu = tot / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { const float d = v[k] - mu; q += (g + G * k < C) ? d * d : 0.f; }
+    q = cn_sum_subs<PXB>(q);
+    if (lane < PXB) red[1][wave][px] = q;
+    __syncthreads();
+    float tq = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tq += red[1][w][px];
+    const float r = rsqrtf(tq / (float)(C - 1) + eps);
+    if (ok && threadIdx.x < PXB) { mean_out[(size_t)n * HW + hw] = mu; rstd_out[(size_t)n * HW + hw] = r; }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = g + G * k;
+        if (ok && c < C) {
+            float o = gamma[c] * ((v[k] - mu) * r) + beta[c];
+            if (relu) o = o > 0.f ? o : 0.f;
+            DT<T>::st(yb + ((unsigned)c * (unsigned)HW + (unsigned)hw), o);
+        }
+    }
+}
+
+// dx as in cn_bwd_dx_kernel; part[blk][0][c] = sum_px dy'*xhat, part[blk][1][c] = sum_px dy' over the PIT pixel groups
+// of workgroup blk (dy' = dy masked by the fused ReLU).
+template <typename T, int PXB, int NW, int CPT>
+__global__ __launch_bounds__(NW * 64) void cn_bwd_reg_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             T* __restrict__ dx, float* __restrict__ part,
+                                                             int C, int HW, int relu, int pit) {
+    constexpr int SUBS = 64 / PXB, G = NW * SUBS;
+    __shared__ float red[2][NW][PXB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane % PXB, g = wave * SUBS + lane / PXB;
+    const int n = blockIdx.y;
+    float pg[CPT], pb[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { pg[k] = 0.f; pb[k] = 0.f; }
+    for (int it = 0; it < pit; ++it) {
+        const int hw0 = (blockIdx.x * pit + it) * PXB + px;
+        const bool ok = hw0 < HW;
+        const int hw = ok ? hw0 : HW - 1;
+        const T* xb = x + (size_t)n * C * HW;
+        const T* gb = dy + (size_t)n * C * HW;
+        T* dxb = dx + (size_t)n * C * HW;
+        const float mu = mean[(size_t)n * HW + hw];
+        const float r = rstd[(size_t)n * HW + hw];
+        float xv[CPT], gv[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = g + G * k; const unsigned o = (unsigned)(c < C ? c : C - 1) * (unsigned)HW + (unsigned)hw;
+            xv[k] = DT<T>::ld(xb + o); gv[k] = DT<T>::ld(gb + o);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = g + G * k; const int ci = c < C ? c : C - 1;
+            const float gmk = gamma[ci];
+            const float d = xv[k] - mu, xh = d * r;
+            float g0 = gv[k];
+            if (relu && !(gmk * xh + beta[ci] > 0.f)) g0 = 0.f;
+            if (!(ok && c < C)) g0 = 0.f;
+            pg[k] += g0 * xh; pb[k] += g0;
+            const float gg = g0 * gmk;
+            s1 += gg; s2 += gg * d;
+            xv[k] = d; gv[k] = gg;                      // keep d and g for the dx pass
+        }
+        s1 = cn_sum_subs<PXB>(s1); s2 = cn_sum_subs<PXB>(s2);
+        if (it > 0) __syncthreads();                    // previous iteration's readers are done with red
+        if (lane < PXB) { red[0][wave][px] = s1; red[1][wave][px] = s2; }
+        __syncthreads();
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { t1 += red[0][w][px]; t2 += red[1][w][px]; }
+        const float S1 = t1 / (float)C;
+        const float S2 = t2 * r * r * r / (float)(C - 1);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = g + G * k;
+            if (ok && c < C) DT<T>::st(dxb + ((unsigned)c * (unsigned)HW + (unsigned)hw), r * (gv[k] - S1) - xv[k] * S2);
+        }
+    }
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const float a = cn_sum_px<PXB>(pg[k]), b = cn_sum_px<PXB>(pb[k]);
+        const int c = g + G * k;
+        if (px == 0 && c < C) { part[(blk * 2 + 0) * C + c] = a; part[(blk * 2 + 1) * C + c] = b; }
+    }
+}
+
+// dgamma/dbeta (=|+=) column sums of part[nblk][2][C]: 64 columns x 16 row lanes per workgroup, coalesced rows
+__global__ __launch_bounds__(1024) void cn_param_colsum_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int C, int nblk, int accumulate) {
+    __shared__ float red[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int W2 = 2 * C;
+    float s = 0.f;
+    if (col < W2)
+        for (int r = rl; r < nblk; r += 16) s += part[(size_t)r * W2 + col];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < W2) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x & 63];
+        float* d = col < C ? dgamma + col : dbeta + (col - C);
+        if (accumulate) *d += t; else *d = t;
+    }
+}
+
+// configuration: fewest channel groups G with <= 32 channels per thread, then more groups (shorter pixel runs)
+// while the grid would leave CUs idle
+struct CnCfg { int pxb, nw, cpt, G; };
+// The backward kernel holds 4 values per channel in registers: it stays at <= 512 threads (256 VGPRs) and gets its
+// channel groups from narrower pixel runs instead of more waves.
+static bool cn_pick(int N, int C, int HW, CnCfg& cfg, bool bwd = false) {
+    static const int PXF[5] = {64, 64, 64, 32, 16}, NWF[5] = {4, 8, 16, 16, 16};
+    static const int PXR[5] = {64, 64, 32, 16, 8}, NWR[5] = {4, 8, 8, 8, 8};
+    const int* PX = bwd ? PXR : PXF; const int* NWS = bwd ? NWR : NWF;
+    int sel = -1;
+    for (int lim = 16; lim <= 32 && sel < 0; lim += 16)        // <= 16 channels per thread keeps the backward kernel
+        for (int i = 0; i < 5; ++i) {                          // spill-free at 1024 threads; 32 only for C > 1024
+            const int G = NWS[i] * (64 / PX[i]);
+            if (cdiv(C, G) <= lim) { sel = i; break; }
+        }
+    if (sel < 0) return false;
+    while (sel < 4) {
+        const long long blocks = (long long)cdiv(HW, PX[sel]) * N;
+        const int Gn = NWS[sel + 1] * (64 / PX[sel + 1]);
+        if (blocks >= 256 || cdiv(C, Gn) < 4) break;
+        ++sel;
+    }
+    {   // experiment knob: force a table entry (the caller still needs C / G <= 32)
+        const char* e = getenv(bwd ? "HIFIC_CN_BWD_SEL" : "HIFIC_CN_FWD_SEL");
+        if (e && atoi(e) >= 0 && atoi(e) < 5 && cdiv(C, NWS[atoi(e)] * (64 / PX[atoi(e)])) <= 32) sel = atoi(e);
+    }
+    cfg.pxb = PX[sel]; cfg.nw = NWS[sel]; cfg.G = NWS[sel] * (64 / PX[sel]);
+    cfg.cpt = cdiv(C, cfg.G) <= 16 ? 16 : 32;
+    return true;
+}
+static int cn_pit(int N, int HW, const CnCfg& cfg) {   // pixel groups per workgroup in the backward kernel
+    const long long groups = (long long)cdiv(HW, cfg.pxb);
+    int pit = (int)(groups * N / 2048);
+    if (pit < 1) pit = 1; if (pit > 16) pit = 16;
+    return pit;
+}
+
 extern "C" {
 
 // x,y: [N,C,H*W] dtype; gamma,beta: [C] f32; mean,rstd: [N,H*W] f32 (saved for backward)
 int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                           int N, int C, int HW, float eps, int relu, int dtype, hipStream_t st) {
     if (C < 2 || N <= 0 || HW <= 0) return HIFIC_ERR_ARG;
+    if (dtype != HIFIC_F32 && dtype != HIFIC_BF16) return HIFIC_ERR_ARG;
+    CnCfg cfg;
+    if (cn_pick(N, C, HW, cfg)) {
+        dim3 rgrid(cdiv(HW, cfg.pxb), N);
+#define CN_FWD_R(TT, PXB, NWV, CPT) hipLaunchKernelGGL((cn_fwd_reg_kernel<TT, PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, \
+                                           (const TT*)x, gamma, beta, (TT*)y, mean, rstd, C, HW, eps, relu)
+#define CN_FWD_C(TT, CPT)                                                                     \
+        do {                                                                                  \
+            if (cfg.pxb == 64 && cfg.nw == 4) CN_FWD_R(TT, 64, 4, CPT);                       \
+            else if (cfg.pxb == 64 && cfg.nw == 8) CN_FWD_R(TT, 64, 8, CPT);                  \
+            else if (cfg.pxb == 64) CN_FWD_R(TT, 64, 16, CPT);                                \
+            else if (cfg.pxb == 32) CN_FWD_R(TT, 32, 16, CPT);                                \
+            else CN_FWD_R(TT, 16, 16, CPT);                                                   \
+        } while (0)
+        if (dtype == HIFIC_F32) { if (cfg.cpt == 16) CN_FWD_C(float, 16); else CN_FWD_C(float, 32); }
+        else { if (cfg.cpt == 16) CN_FWD_C(bf16_t, 16); else CN_FWD_C(bf16_t, 32); }
+#undef CN_FWD_C
+#undef CN_FWD_R
+        return hific_launch_status();
+    }
     dim3 grid(cdiv(HW, 64), N);
     const int nw = C >= 480 ? 16 : (C >= 200 ? 8 : 4);
 #define CN_FWD(TT, NWV) hipLaunchKernelGGL((cn_fwd_kernel<TT, NWV>), grid, dim3(NWV * 64), 0, st, (const TT*)x, gamma, \
@@ -194,14 +416,46 @@ int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, 
 
 // ws: at least hific_channelnorm_bwd_ws_bytes(); dgamma/dbeta f32 [C]
 size_t hific_channelnorm_bwd_ws_bytes(int N, int C, int HW) {
-    (void)N; (void)HW;
-    return (size_t)64 * 2 * C * sizeof(float);
+    size_t b = (size_t)64 * 2 * C * sizeof(float);
+    CnCfg cfg;
+    if (C >= 2 && N > 0 && HW > 0 && cn_pick(N, C, HW, cfg, true)) {
+        const size_t nblk = (size_t)cdiv(cdiv(HW, cfg.pxb), cn_pit(N, HW, cfg)) * N;
+        const size_t r = nblk * 2 * C * sizeof(float);
+        if (r > b) b = r;
+    }
+    return b;
 }
 
 int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* mean,
                           const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int C, int HW, int relu,
                           int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
     if (C < 2 || N <= 0 || HW <= 0) return HIFIC_ERR_ARG;
+    if (dtype != HIFIC_F32 && dtype != HIFIC_BF16) return HIFIC_ERR_ARG;
+    CnCfg cfg;
+    if (cn_pick(N, C, HW, cfg, true)) {
+        const int pit = cn_pit(N, HW, cfg);
+        dim3 rgrid(cdiv(cdiv(HW, cfg.pxb), pit), N);
+        const size_t nblk = (size_t)rgrid.x * rgrid.y;
+        if (nblk * 2 * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
+        float* rpart = (float*)ws;
+#define CN_BWD_R(TT, PXB, NWV, CPT) hipLaunchKernelGGL((cn_bwd_reg_kernel<TT, PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, \
+                                           (const TT*)x, (const TT*)dy, gamma, beta, mean, rstd, (TT*)dx, rpart, C, HW, relu, pit)
+#define CN_BWD_C(TT, CPT)                                                                     \
+        do {                                                                                  \
+            if (cfg.pxb == 64 && cfg.nw == 4) CN_BWD_R(TT, 64, 4, CPT);                       \
+            else if (cfg.pxb == 64) CN_BWD_R(TT, 64, 8, CPT);                                 \
+            else if (cfg.pxb == 32) CN_BWD_R(TT, 32, 8, CPT);                                 \
+            else if (cfg.pxb == 16) CN_BWD_R(TT, 16, 8, CPT);                                 \
+            else CN_BWD_R(TT, 8, 8, CPT);                                                     \
+        } while (0)
+        if (dtype == HIFIC_F32) { if (cfg.cpt == 16) CN_BWD_C(float, 16); else CN_BWD_C(float, 32); }
+        else { if (cfg.cpt == 16) CN_BWD_C(bf16_t, 16); else CN_BWD_C(bf16_t, 32); }
+#undef CN_BWD_C
+#undef CN_BWD_R
+        hipLaunchKernelGGL(cn_param_colsum_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, rpart, dgamma, dbeta, C,
+                           (int)nblk, accumulate);
+        return hific_launch_status();
+    }
     int nsplit = cdiv(1024, C);
     if (nsplit > 64) nsplit = 64;
     if (nsplit * 256 > HW) nsplit = cdiv(HW, 256);

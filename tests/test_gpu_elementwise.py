@@ -21,7 +21,8 @@ def _relerr(a, b):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)], ids=["f32", "bf16"])
-@pytest.mark.parametrize("shape,relu", [((2, 60, 24, 24), True), ((2, 960, 16, 16), False), ((3, 220, 5, 7), True)])
+@pytest.mark.parametrize("shape,relu", [((2, 60, 24, 24), True), ((2, 960, 16, 16), False), ((3, 220, 5, 7), True),
+                                        ((4, 8, 250, 256), True), ((1, 1100, 3, 5), False)])
 def test_channelnorm(hific, dev, shape, relu, dt, tol):
     from hific_amd import ops
     x = _rnd(shape, 1, -2, 2)
