@@ -1441,7 +1441,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         if (p.ph[i].OHt > OHt) OHt = p.ph[i].OHt;
         if (p.ph[i].OWt > OWt) OWt = p.ph[i].OWt;
     }
-    const int wbytes = 512 + 2 * bm * PITCH;
+    int wbytes = 512 + 2 * bm * PITCH;
     int maxtaps = 1;
     for (int i = 0; i < p.nphase; ++i) if (p.ph[i].ntaps > maxtaps) maxtaps = p.ph[i].ntaps;
     // Full-LDS tiles (1 workgroup per CU, fewer halo re-reads) when they still give >= one workgroup per CU;
@@ -1454,6 +1454,20 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     if (!tiled && !choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, 72 * 1024, p.TH, p.TW, p.NI, maxtaps))
         return HIFIC_ERR_UNSUPPORTED;
     p.tiles_n = cdiv(p.N, p.NI);
+    if (bm == 128 && !env_int("HIFIC_NO_BM_TAIL", 0)) {
+        // 128-row tiles run one workgroup per CU: a grid of e.g. 1.5 x 256 workgroups (18x18 padded-gradient
+        // domain of the 16x16x960 layers) leaves half the chip idle in its second wave.  64-row tiles co-reside two
+        // per CU, so the same launch quantises at 512 slots.
+        long long tiles = 0;
+        for (int i = 0; i < p.nphase; ++i)
+            tiles += (long long)cdiv(p.ph[i].OHt, p.TH) * cdiv(p.ph[i].OWt, p.TW) * p.tiles_n;
+        const long long g128 = tiles * cdiv(p.K, 128), g64 = tiles * cdiv(p.K, 64);
+        const double eff128 = (double)p.K / (cdiv(p.K, 128) * 128.0) * (double)g128 / (double)(cdivl(g128, 256) * 256);
+        const double eff64 = (double)p.K / (cdiv(p.K, 64) * 64.0) * (double)g64 / (double)(cdivl(g64, 512) * 512);
+        if (g128 > 256 && g128 <= 512 && eff64 >= eff128 - 0.02 && eff128 < 0.8) {
+            bm = 64; p.Kpad = cdiv(p.K, bm) * bm; wbytes = 512 + 2 * bm * PITCH;
+        }
+    }
     long long wp_elems = 0;
     int max_tiles = 0;
     size_t lds = 0;
@@ -1492,9 +1506,11 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             const size_t lb = (size_t)64 * (RS | 1) * sizeof(float);
             hipLaunchKernelGGL((pack_w2_kernel<T, 0>), pg, dim3(256), lb, st, p, w, w_scale, sm, sc, RS, 1);
         } else if (contiguous && sm == RS && !env_int("HIFIC_OLD_PACK", 0)) {
-            int MB = 192 / RS; if (MB > 16) MB = 16; if (MB < 1) MB = 1;
+            int MB = env_int("HIFIC_PACK_MB", 144) / RS; if (MB > 32) MB = 32; if (MB < 1) MB = 1;
             dim3 pg(p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0), cdiv(p.Kpad, MB));
             const size_t lb = (size_t)64 * ((MB * RS) | 1) * sizeof(float);
+            if (lb > 48 * 1024)
+                hipFuncSetAttribute((const void*)pack_w2_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
             hipLaunchKernelGGL((pack_w2_kernel<T, 1>), pg, dim3(256), lb, st, p, w, w_scale, sm, sc, RS, MB);
         } else {
             long long mx = 0;
