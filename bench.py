@@ -193,7 +193,10 @@ def main():
         step()
     ms = (ctypes.c_double * 4)(); fl = (ctypes.c_double * 4)(); cnt = (ctypes.c_int * 4)()
     lib.call("hific_prof_end", ms, fl, cnt)
-    kinds = ["gconv_kernel<128-row tile>", "gconv_kernel<64-row tile>", "gconv_kernel<32-row tile>", "wgrad_kernel"]
+    kinds = ["gconv 128-row tiles (gconv_sp9_kernel<2> + gconv_kernel<..,2,2,2,2>)",
+             "gconv 64-row tiles (gconv_sp9_kernel<1> + gconv_kernel<..,2,2,1,2>)",
+             "gconv 32-row tiles (gconv_kernel<..,1,4,1,1>)",
+             "weight gradient (wgrad_pipe_kernel + wgrad_kernel + wgrad_im2col_kernel)"]
     kinds_key = ["gconv128", "gconv64", "gconv32", "wgrad"]
     per_kind = {kinds[i]: {"launches": cnt[i], "ms": round(ms[i], 3),
                            "tflops": round(fl[i] / (ms[i] * 1e-3) / 1e12, 2) if ms[i] > 0 else 0.0}
