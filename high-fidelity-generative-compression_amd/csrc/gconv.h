@@ -37,6 +37,10 @@ struct GcParams {
     int nphase;
     int tap_sw;          // kernel width S (weight tap index = r*S + s)
     int dbg;             // ablation flags for micro-benchmarks (HIFIC_DBG; 0 in production)
+    // reflect-padded data gradient: `out` is the f32 padded plane buffer (only its rim is written); pixels inside
+    // [fold_pt, fold_pt+fold_h) x [fold_pl, fold_pl+fold_w) go straight to out2 = dx[N,K,fold_h,fold_w]
+    void* out2;
+    int fold_pt, fold_pl, fold_h, fold_w, out2_f32;
     GcPhase ph[GC_MAXPH];
     short tap_dy[GC_MAXTAPS], tap_dx[GC_MAXTAPS];
     short tap_r[GC_MAXTAPS], tap_s[GC_MAXTAPS];

@@ -329,7 +329,18 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
         const bool okp = pvalid[ni] && pn[ni] < p.N && pu[ni] < ph.OHt && pv[ni] < ph.OWt &&
                          (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
         if (!okp) continue;
-        const size_t pbase = (size_t)pn[ni] * p.K * p.OHf * p.OWf + (size_t)oy * p.OWf + ox;
+        size_t plane = (size_t)p.OHf * p.OWf;
+        size_t pbase = (size_t)pn[ni] * p.K * plane + (size_t)oy * p.OWf + ox;
+        void* optr = p.out;
+        bool of32 = out_f32;
+        if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
+            const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
+            if ((unsigned)iy < (unsigned)p.fold_h && (unsigned)ix < (unsigned)p.fold_w) {
+                plane = (size_t)p.fold_h * p.fold_w;
+                pbase = (size_t)pn[ni] * p.K * plane + (size_t)iy * p.fold_w + ix;
+                optr = p.out2; of32 = std::is_same<T, float>::value || p.out2_f32;
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
@@ -338,11 +349,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
                 if (m < p.K) {
                     float v = acc[mi][ni][r];
                     if (p.bias) v += p.bias[m];
-                    const size_t idx = pbase + (size_t)m * p.OHf * p.OWf;
+                    const size_t idx = pbase + (size_t)m * plane;
                     if (p.resid) v += out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
                     if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
                     else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
-                    if (out_f32) ((float*)p.out)[idx] = v; else ((bf16_t*)p.out)[idx] = f2bf(v);
+                    if (of32) ((float*)optr)[idx] = v; else ((bf16_t*)optr)[idx] = f2bf(v);
                 }
             }
         }
@@ -552,7 +563,18 @@ __global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
         const bool okp = pvalid[ni] && pn[ni] < p.N && pu[ni] < ph.OHt && pv[ni] < ph.OWt &&
                          (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
         if (!okp) continue;
-        const size_t pbase = (size_t)pn[ni] * p.K * p.OHf * p.OWf + (size_t)oy * p.OWf + ox;
+        size_t plane = (size_t)p.OHf * p.OWf;
+        size_t pbase = (size_t)pn[ni] * p.K * plane + (size_t)oy * p.OWf + ox;
+        void* optr = p.out;
+        bool of32 = out_f32;
+        if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
+            const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
+            if ((unsigned)iy < (unsigned)p.fold_h && (unsigned)ix < (unsigned)p.fold_w) {
+                plane = (size_t)p.fold_h * p.fold_w;
+                pbase = (size_t)pn[ni] * p.K * plane + (size_t)iy * p.fold_w + ix;
+                optr = p.out2; of32 = p.out2_f32 != 0;
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
@@ -561,11 +583,11 @@ __global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
                 if (m < p.K) {
                     float v = acc[mi][ni][r];
                     if (p.bias) v += p.bias[m];
-                    const size_t idx = pbase + (size_t)m * p.OHf * p.OWf;
+                    const size_t idx = pbase + (size_t)m * plane;
                     if (p.resid) v += out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
                     if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
                     else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
-                    if (out_f32) ((float*)p.out)[idx] = v; else ((bf16_t*)p.out)[idx] = f2bf(v);
+                    if (of32) ((float*)optr)[idx] = v; else ((bf16_t*)optr)[idx] = f2bf(v);
                 }
             }
         }
@@ -626,11 +648,25 @@ __global__ __launch_bounds__(256) void pack_w2_kernel(const GcParams p, const fl
         // 64 rows (c) of `run` contiguous floats each: wave w takes rows w, w+4, ...
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         int jmax = (p.K - m0) * RS; if (jmax > run) jmax = run; if (jmax < 0) jmax = 0;
-        for (int c = wv; c < 64; c += 4) {
-            const bool cok = c0 + c < p.C;
-            const float* src = w + (long long)m0 * sm + (long long)(cok ? c0 + c : 0) * sc;
-            for (int j = lane; j < run; j += 64)
-                pk_lds[c * pitch + j] = (cok && j < jmax) ? src[j] * sc_ : 0.f;
+        // 8 rows per trip, unconditional clamped loads: 8 independent 256-byte wave loads in flight per thread
+        const float* wm = w + (long long)m0 * sm;
+        for (int j = lane; j < run; j += 64) {
+            const bool jok = j < jmax;
+            const int jc = jok ? j : 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = wv + 4 * (half * 8 + u);
+                    v[u] = wm[(long long)(c0 + c < p.C ? c0 + c : 0) * sc + jc];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = wv + 4 * (half * 8 + u);
+                    pk_lds[c * pitch + j] = (jok && c0 + c < p.C) ? v[u] * sc_ : 0.f;
+                }
+            }
         }
     }
     __syncthreads();
@@ -688,6 +724,53 @@ __global__ void reflect_fold_kernel(const float* __restrict__ src, TO* __restric
         for (int a = 0; a < ny; ++a)
             for (int b2 = 0; b2 < nx; ++b2) acc += s[ys[a] * Wp + xs[b2]];
         DT<TO>::st(dst + i, acc);
+    }
+}
+
+// Rim variant: dst already holds the interior term dxp[y+pt][x+pl] (written by the conv epilogue); add the other
+// padded positions that reflect onto (y,x) - they all lie on the rim of the padded plane, the only part of src the
+// epilogue wrote.  Touches only the few rows/columns next to the border.
+template <typename TO>
+__global__ void reflect_rim_add_kernel(const float* __restrict__ src, TO* __restrict__ dst, long long planes,
+                                       int H, int W, int pt, int pl, int pb, int pr) {
+    // Only elements in rows {1..pt} u {H-1-pb..H-2} or columns {1..pl} u {W-1-pr..W-2} receive reflected terms:
+    // enumerate exactly those (R full rows, then the nc columns of the remaining rows) instead of the whole plane.
+    const int Hp = H + pt + pb, Wp = W + pl + pr;
+    const int R = pt + pb, nc = pl + pr;
+    // tiny planes (top and bottom bands overlap): enumerate the whole plane instead
+    const bool whole = (H < R + 3) || (W < nc + 3);
+    const unsigned nrim = whole ? (unsigned)(H * W) : (unsigned)(R * W + (H - R) * nc);
+    const unsigned total = (unsigned)planes * nrim;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned pc = i / nrim;
+        const int k = (int)(i - pc * nrim);
+        int y, x;
+        if (whole) {
+            y = k / W; x = k - y * W;
+        } else if (k < R * W) {
+            const int ri = k / W; x = k - ri * W;
+            y = ri < pt ? 1 + ri : H - 1 - pb + (ri - pt);
+        } else {
+            const int k2 = k - R * W;
+            const int yi = k2 / nc, ci = k2 - yi * nc;
+            y = yi == 0 ? 0 : (yi <= H - R - 2 ? pt + yi : H - 1);
+            x = ci < pl ? 1 + ci : W - 1 - pr + (ci - pl);
+        }
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + pt;
+        if (y >= 1 && y <= pt) ys[ny++] = pt - y;
+        if (y <= H - 2 && y >= H - 1 - pb) ys[ny++] = pt + 2 * (H - 1) - y;
+        xs[nx++] = x + pl;
+        if (x >= 1 && x <= pl) xs[nx++] = pl - x;
+        if (x <= W - 2 && x >= W - 1 - pr) xs[nx++] = pl + 2 * (W - 1) - x;
+        if (ny == 1 && nx == 1) continue;
+        const float* s = src + (size_t)pc * Hp * Wp;
+        float acc = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b2 = 0; b2 < nx; ++b2)
+                if (a | b2) acc += s[ys[a] * Wp + xs[b2]];
+        TO* d = dst + (size_t)pc * H * W + y * W + x;
+        DT<TO>::st(d, DT<TO>::ld(d) + acc);
     }
 }
 
@@ -1293,6 +1376,38 @@ __global__ void wgrad_reduce_kernel(const float4* __restrict__ ws, float4* __res
     out[(size_t)blockIdx.y * L4 + l] = a;
 }
 
+// Same sums for the plain conv layout (dw[m][c][t] with the taps in raster order, sc == ntaps): block (64 c, one m)
+// reads the partial rows [t][c] coalesced along c, transposes through LDS and writes the 64 x ntaps run contiguously.
+// (The generic kernel below reads with a Cpad*4-byte stride between neighbouring threads.)
+__global__ __launch_bounds__(256) void wgrad_finalize_t_kernel(const WgParams p, float* __restrict__ dw, long long sm,
+                                                               int accumulate) {
+    extern __shared__ float fin_lds[];                     // [64][nt | 1]
+    const int nt = p.ntaps, pitch = nt | 1;
+    const int c0 = blockIdx.x * 64, m = blockIdx.y;
+    const size_t sstride = (size_t)p.Mpad * nt * p.Cpad;
+    for (int idx = threadIdx.x; idx < 64 * nt; idx += 256) {
+        const int t = idx >> 6, c = idx & 63;
+        const float* wp_ = p.ws + ((size_t)m * nt + t) * p.Cpad + c0 + c;
+        float s = 0.f;
+        int sp = 0;
+        for (; sp + 4 <= p.nsplit; sp += 4) {
+            const float v0 = wp_[(size_t)sp * sstride], v1 = wp_[(size_t)(sp + 1) * sstride];
+            const float v2 = wp_[(size_t)(sp + 2) * sstride], v3 = wp_[(size_t)(sp + 3) * sstride];
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; sp < p.nsplit; ++sp) s += wp_[(size_t)sp * sstride];
+        fin_lds[c * pitch + t] = s;
+    }
+    __syncthreads();
+    const int cn = p.C - c0 < 64 ? p.C - c0 : 64;
+    float* d = dw + (long long)m * sm + (long long)c0 * nt;
+    for (int idx = threadIdx.x; idx < cn * nt; idx += 256) {
+        const int c = idx / nt, t = idx - c * nt;
+        const float v = fin_lds[c * pitch + t];
+        if (accumulate) d[idx] += v; else d[idx] = v;
+    }
+}
+
 // dw[m*sm + c*sc + r*sr + s*ss] (=|+=) sum_split ws[split][m][t][c]
 __global__ void wgrad_finalize_kernel(const WgParams p, float* __restrict__ dw, long long sm, long long sc,
                                       long long sr, long long ss, int accumulate) {
@@ -1303,8 +1418,15 @@ __global__ void wgrad_finalize_kernel(const WgParams p, float* __restrict__ dw, 
         const unsigned j = i / nt, t = i - j * nt;
         const unsigned m = j / C, c = j - m * C;
         float s = 0.f;
-        for (int sp = 0; sp < p.nsplit; ++sp)
-            s += p.ws[(((size_t)sp * p.Mpad + m) * nt + t) * p.Cpad + c];
+        const size_t sstride = (size_t)p.Mpad * nt * p.Cpad;
+        const float* wp_ = p.ws + ((size_t)m * nt + t) * p.Cpad + c;
+        int sp = 0;
+        for (; sp + 4 <= p.nsplit; sp += 4) {                  // 4 independent loads per trip
+            const float v0 = wp_[(size_t)sp * sstride], v1 = wp_[(size_t)(sp + 1) * sstride];
+            const float v2 = wp_[(size_t)(sp + 2) * sstride], v3 = wp_[(size_t)(sp + 3) * sstride];
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; sp < p.nsplit; ++sp) s += wp_[(size_t)sp * sstride];
         const long long o = m * sm + c * sc + p.tap_r[t] * sr + p.tap_s[t] * ss;
         if (accumulate) dw[o] += s; else dw[o] = s;
     }
@@ -1627,6 +1749,10 @@ int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const fl
         padbuf = (float*)ws.take((size_t)g.N * g.C * Hp * Wp * sizeof(float));
         if (!padbuf) return HIFIC_ERR_WS;
         p.out = padbuf; p.out_f32 = 1; p.OHf = Hp; p.OWf = Wp;
+        if (!env_int("HIFIC_NO_FOLD_ROUTE", 0)) {
+            p.out2 = dx; p.out2_f32 = (dtype == HIFIC_F32 || out_f32) ? 1 : 0;
+            p.fold_pt = g.pt; p.fold_pl = g.pl; p.fold_h = g.H; p.fold_w = g.W;
+        }
     } else {
         p.out = dx; p.out_f32 = out_f32; p.OHf = g.H; p.OWf = g.W;
     }
@@ -1658,7 +1784,18 @@ int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const fl
         long long total = planes * g.H * g.W;
         int gx = (int)((total + 255) / 256); if (gx > 16384) gx = 16384;
         const bool of32 = (dtype == HIFIC_F32) || out_f32;
-        if (of32)
+        if (p.fold_h) {
+            const bool whole = (g.H < g.pt + g.pb + 3) || (g.W < g.pl + g.pr + 3);
+            const long long nrim = whole ? (long long)g.H * g.W
+                                         : (long long)(g.pt + g.pb) * g.W + (long long)(g.H - g.pt - g.pb) * (g.pl + g.pr);
+            gx = (int)((planes * nrim + 255) / 256); if (gx > 16384) gx = 16384; if (gx < 1) gx = 1;
+            if (of32)
+                hipLaunchKernelGGL(reflect_rim_add_kernel<float>, dim3(gx), dim3(256), 0, st, padbuf, (float*)dx, planes,
+                                   g.H, g.W, g.pt, g.pl, g.pb, g.pr);
+            else
+                hipLaunchKernelGGL(reflect_rim_add_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, padbuf, (bf16_t*)dx, planes,
+                                   g.H, g.W, g.pt, g.pl, g.pb, g.pr);
+        } else if (of32)
             hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(gx), dim3(256), 0, st, padbuf, (float*)dx, planes,
                                g.H, g.W, g.pt, g.pl, g.pb, g.pr);
         else
@@ -1823,6 +1960,13 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
             p.ws = ws2; p.nsplit = groups;
         }
     }
+    bool raster = (sc == p.ntaps && ss == 1 && p.ntaps <= 32);
+    for (int t = 0; t < p.ntaps && raster; ++t) raster = (p.tap_r[t] * sr + p.tap_s[t] * ss == t);
+    if (raster) {
+        const size_t lb = (size_t)64 * (p.ntaps | 1) * sizeof(float);
+        hipLaunchKernelGGL(wgrad_finalize_t_kernel, dim3(cdiv(p.C, 64), p.M), dim3(256), lb, st, p, dw, sm, accumulate);
+        return hific_launch_status();
+    }
     long long total = (long long)p.M * p.C * p.ntaps;
     int gx = (int)((total + 255) / 256); if (gx > 16384) gx = 16384;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(gx), dim3(256), 0, st, p, dw, sm, sc, sr, ss, accumulate);
@@ -1902,6 +2046,17 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     prof_close(pslot, st);
     int rc = hific_launch_status();
     if (rc != HIFIC_OK) return rc;
+    if (p.nsplit > 24) {
+        const int per_group = cdiv(p.nsplit, 16), groups = cdiv(p.nsplit, per_group);
+        const size_t L = (size_t)p.Mpad * p.Cpad;
+        float* ws2 = (float*)ws.take(groups * L * sizeof(float));
+        if (ws2) {
+            const unsigned L4 = (unsigned)(L / 4);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((int)L4, 256), groups), dim3(256), 0, st,
+                               (const float4*)p.ws, (float4*)ws2, L4, p.nsplit, per_group);
+            p.ws = ws2; p.nsplit = groups;
+        }
+    }
     long long total = (long long)g.K * g.C * nt;
     int gx = (int)((total + 255) / 256); if (gx > 8192) gx = 8192;
     hipLaunchKernelGGL(wgrad_im2col_finalize_kernel, dim3(gx), dim3(256), 0, st, p, g.K, g.C);

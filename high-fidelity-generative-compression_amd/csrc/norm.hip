@@ -327,8 +327,16 @@ __global__ __launch_bounds__(1024) void cn_param_colsum_kernel(const float* __re
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     const int W2 = 2 * C;
     float s = 0.f;
-    if (col < W2)
-        for (int r = rl; r < nblk; r += 16) s += part[(size_t)r * W2 + col];
+    if (col < W2) {
+        int r = rl;
+        for (; r + 7 * 16 < nblk; r += 8 * 16) {          // 8 independent loads per trip
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(r + 16 * j) * W2 + col];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; r < nblk; r += 16) s += part[(size_t)r * W2 + col];
+    }
     red[rl][threadIdx.x & 63] = s;
     __syncthreads();
     if (rl == 0 && col < W2) {
