@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void pack_w2_kernel(const GcParams p, const fl
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         int jmax = (p.K - m0) * RS; if (jmax > run) jmax = run; if (jmax < 0) jmax = 0;
         // 8 rows per trip, unconditional clamped loads: 8 independent 256-byte wave loads in flight per thread
-        const float* wm = w + (long long)m0 * sm;
+        const float* wm = w + (long long)(m0 < p.K ? m0 : 0) * sm;      // padded m rows: any valid address, zeroed below
         for (int j = lane; j < run; j += 64) {
             const bool jok = j < jmax;
             const int jc = jok ? j : 0;

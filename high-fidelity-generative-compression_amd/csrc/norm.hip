@@ -200,25 +200,42 @@ __device__ __forceinline__ float cn_sum_px(float v) {         // sum over the PX
     return v;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (own L2 each).  With PXB < 64 the 64/PXB workgroups that share every
+// 128-byte line of a channel row would land on different XCDs and each fetch the line from MALL/HBM (measured: the
+// 16x16x960 backward ran at the MALL rate of an 8x over-fetch).  Remap so that consecutive pixel groups share an XCD.
+__device__ __forceinline__ void cn_block_remap(int& bx, int& by, int remap) {
+    const unsigned total = gridDim.x * gridDim.y;
+    unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (remap && (total & 7u) == 0) bid = (bid & 7u) * (total >> 3) + (bid >> 3);
+    by = (int)(bid / gridDim.x); bx = (int)(bid - (unsigned)by * gridDim.x);
+}
+
 template <typename T, int PXB, int NW, int CPT>
 __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, T* __restrict__ y,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                             int C, int HW, float eps, int relu) {
+                                                             int C, int HW, float eps, int relu, int remap) {
     constexpr int SUBS = 64 / PXB, G = NW * SUBS;
     __shared__ float red[2][NW][PXB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane % PXB, g = wave * SUBS + lane / PXB;
-    const int n = blockIdx.y;
-    const int hw0 = blockIdx.x * PXB + px;
+    int bx, n;
+    cn_block_remap(bx, n, remap);
+    const int hw0 = bx * PXB + px;
     const bool ok = hw0 < HW;
     const int hw = ok ? hw0 : HW - 1;
     // wave-uniform base + 32-bit per-lane offsets (one VGPR per load address; C*HW < 2^32 elements per image)
     const T* xb = x + (size_t)n * C * HW;
     T* yb = y + (size_t)n * C * HW;
-    float v[CPT];
+    // gamma/beta are loaded here, unconditionally, with everything else: a load inside the (predicated) output
+    // loop costs one memory round trip per channel
+    float v[CPT], gm[CPT], bt[CPT];
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) { const int c = g + G * k; v[k] = DT<T>::ld(xb + ((unsigned)(c < C ? c : C - 1) * (unsigned)HW + (unsigned)hw)); }
+    for (int k = 0; k < CPT; ++k) {
+        const int c = g + G * k; const int ci = c < C ? c : C - 1;
+        v[k] = DT<T>::ld(xb + ((unsigned)ci * (unsigned)HW + (unsigned)hw));
+        gm[k] = gamma[ci]; bt[k] = beta[ci];
+    }
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) s += (g + G * k < C) ? v[k] : 0.f;
@@ -244,7 +261,7 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict
     for (int k = 0; k < CPT; ++k) {
         const int c = g + G * k;
         if (ok && c < C) {
-            float o = gamma[c] * ((v[k] - mu) * r) + beta[c];
+            float o = gm[k] * ((v[k] - mu) * r) + bt[k];
             if (relu) o = o > 0.f ? o : 0.f;
             DT<T>::st(yb + ((unsigned)c * (unsigned)HW + (unsigned)hw), o);
         }
@@ -258,17 +275,21 @@ __global__ __launch_bounds__(NW * 64) void cn_bwd_reg_kernel(const T* __restrict
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              T* __restrict__ dx, float* __restrict__ part,
-                                                             int C, int HW, int relu, int pit) {
+                                                             int C, int HW, int relu, int pit, int remap) {
     constexpr int SUBS = 64 / PXB, G = NW * SUBS;
     __shared__ float red[2][NW][PXB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane % PXB, g = wave * SUBS + lane / PXB;
-    const int n = blockIdx.y;
-    float pg[CPT], pb[CPT];
+    int bx, n;
+    cn_block_remap(bx, n, remap);
+    float pg[CPT], pb[CPT], gm[CPT], bt[CPT];
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) { pg[k] = 0.f; pb[k] = 0.f; }
+    for (int k = 0; k < CPT; ++k) {
+        const int c = g + G * k; const int ci = c < C ? c : C - 1;
+        pg[k] = 0.f; pb[k] = 0.f; gm[k] = gamma[ci]; bt[k] = beta[ci];      // loaded once, unconditionally
+    }
     for (int it = 0; it < pit; ++it) {
-        const int hw0 = (blockIdx.x * pit + it) * PXB + px;
+        const int hw0 = (bx * pit + it) * PXB + px;
         const bool ok = hw0 < HW;
         const int hw = ok ? hw0 : HW - 1;
         const T* xb = x + (size_t)n * C * HW;
@@ -285,11 +306,11 @@ __global__ __launch_bounds__(NW * 64) void cn_bwd_reg_kernel(const T* __restrict
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const int c = g + G * k; const int ci = c < C ? c : C - 1;
-            const float gmk = gamma[ci];
+            const int c = g + G * k;
+            const float gmk = gm[k];
             const float d = xv[k] - mu, xh = d * r;
             float g0 = gv[k];
-            if (relu && !(gmk * xh + beta[ci] > 0.f)) g0 = 0.f;
+            if (relu && !(gmk * xh + bt[k] > 0.f)) g0 = 0.f;
             if (!(ok && c < C)) g0 = 0.f;
             pg[k] += g0 * xh; pb[k] += g0;
             const float gg = g0 * gmk;
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void cn_bwd_reg_kernel(const T* __restrict
             if (ok && c < C) DT<T>::st(dxb + ((unsigned)c * (unsigned)HW + (unsigned)hw), r * (gv[k] - S1) - xv[k] * S2);
         }
     }
-    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t blk = (size_t)n * gridDim.x + bx;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const float a = cn_sum_px<PXB>(pg[k]), b = cn_sum_px<PXB>(pb[k]);
@@ -350,6 +371,7 @@ __global__ __launch_bounds__(1024) void cn_param_colsum_kernel(const float* __re
 
 // configuration: fewest channel groups G with <= 32 channels per thread, then more groups (shorter pixel runs)
 // while the grid would leave CUs idle
+static int cn_remap_flag(int bit) { const char* e = getenv("HIFIC_CN_REMAP"); return ((e ? atoi(e) : 3) & bit) ? 1 : 0; }
 struct CnCfg { int pxb, nw, cpt, G; };
 // The backward kernel holds 4 values per channel in registers: it stays at <= 512 threads (256 VGPRs) and gets its
 // channel groups from narrower pixel runs instead of more waves.
@@ -396,7 +418,7 @@ int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, 
     if (cn_pick(N, C, HW, cfg)) {
         dim3 rgrid(cdiv(HW, cfg.pxb), N);
 #define CN_FWD_R(TT, PXB, NWV, CPT) hipLaunchKernelGGL((cn_fwd_reg_kernel<TT, PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, \
-                                           (const TT*)x, gamma, beta, (TT*)y, mean, rstd, C, HW, eps, relu)
+                                           (const TT*)x, gamma, beta, (TT*)y, mean, rstd, C, HW, eps, relu, cn_remap_flag(1))
 #define CN_FWD_C(TT, CPT)                                                                     \
         do {                                                                                  \
             if (cfg.pxb == 64 && cfg.nw == 4) CN_FWD_R(TT, 64, 4, CPT);                       \
@@ -447,7 +469,7 @@ int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, con
         if (nblk * 2 * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
         float* rpart = (float*)ws;
 #define CN_BWD_R(TT, PXB, NWV, CPT) hipLaunchKernelGGL((cn_bwd_reg_kernel<TT, PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, \
-                                           (const TT*)x, (const TT*)dy, gamma, beta, mean, rstd, (TT*)dx, rpart, C, HW, relu, pit)
+                                           (const TT*)x, (const TT*)dy, gamma, beta, mean, rstd, (TT*)dx, rpart, C, HW, relu, pit, cn_remap_flag(2))
 #define CN_BWD_C(TT, CPT)                                                                     \
         do {                                                                                  \
             if (cfg.pxb == 64 && cfg.nw == 4) CN_BWD_R(TT, 64, 4, CPT);                       \
