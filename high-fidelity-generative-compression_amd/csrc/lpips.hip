@@ -38,20 +38,31 @@ __global__ void lpips_prep_bwd_kernel(const T* __restrict__ dout, TO* __restrict
 }
 
 // f: [2B, C, HW]; part[b][chunk] = sum over the chunk's 64 pixels of sum_c w_c (f0/|f0| - f1/|f1|)^2
+// Channel loops run LP_U channels per trip with all 2*LP_U loads in flight (clamped indices, masked contributions):
+// a one-channel-per-iteration loop is a chain of memory round trips (up to 96 of them for 384 channels).
+#define LP_U 8
 template <typename T>
 __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const T* __restrict__ f, const float* __restrict__ w,
                                                             float* __restrict__ part, int B, int C, int HW, float eps) {
     __shared__ float r0[4][64], r1[4][64];
     const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    const int hw = blockIdx.x * 64 + px;
-    const bool ok = hw < HW;
+    const int hw0 = blockIdx.x * 64 + px;
+    const bool ok = hw0 < HW;
+    const int hw = ok ? hw0 : HW - 1;
     const T* f0 = f + (size_t)b * C * HW + hw;
     const T* f1 = f + (size_t)(B + b) * C * HW + hw;
     float s0 = 0.f, s1 = 0.f;
-    if (ok) for (int c = cg; c < C; c += 4) {
-        const float a = DT<T>::ld(f0 + (size_t)c * HW), bb = DT<T>::ld(f1 + (size_t)c * HW);
-        s0 += a * a; s1 += bb * bb;
+    for (int c0 = cg; c0 < C; c0 += 4 * LP_U) {
+        float a[LP_U], bb[LP_U];
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j) {
+            const int c = c0 + 4 * j; const size_t o = (size_t)(c < C ? c : C - 1) * HW;
+            a[j] = DT<T>::ld(f0 + o); bb[j] = DT<T>::ld(f1 + o);
+        }
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j)
+            if (ok && c0 + 4 * j < C) { s0 += a[j] * a[j]; s1 += bb[j] * bb[j]; }
     }
     r0[cg][px] = s0; r1[cg][px] = s1;
     __syncthreads();
@@ -59,9 +70,16 @@ __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const T* __restrict_
     const float n1 = sqrtf(r1[0][px] + r1[1][px] + r1[2][px] + r1[3][px] + eps);
     __syncthreads();
     float d = 0.f;
-    if (ok) for (int c = cg; c < C; c += 4) {
-        const float u = DT<T>::ld(f0 + (size_t)c * HW) / n0, v = DT<T>::ld(f1 + (size_t)c * HW) / n1;
-        d += w[c] * (u - v) * (u - v);
+    for (int c0 = cg; c0 < C; c0 += 4 * LP_U) {
+        float a[LP_U], bb[LP_U], wv[LP_U];
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j) {
+            const int c = c0 + 4 * j; const int ci = c < C ? c : C - 1; const size_t o = (size_t)ci * HW;
+            a[j] = DT<T>::ld(f0 + o); bb[j] = DT<T>::ld(f1 + o); wv[j] = w[ci];
+        }
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j)
+            if (ok && c0 + 4 * j < C) { const float u = a[j] / n0, v = bb[j] / n1; d += wv[j] * (u - v) * (u - v); }
     }
     d = wave_sum(d);
     if (px == 0) r0[cg][0] = d;
@@ -91,15 +109,23 @@ __global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const T* __restrict_
     __shared__ float r0[4][64], r1[4][64];
     const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    const int hw = blockIdx.x * 64 + px;
-    const bool ok = hw < HW;
+    const int hw0 = blockIdx.x * 64 + px;
+    const bool ok = hw0 < HW;
+    const int hw = ok ? hw0 : HW - 1;
     const T* f0 = f + (size_t)b * C * HW + hw;
     const T* f1 = f + (size_t)(B + b) * C * HW + hw;
     const float g = gval[b] / (float)HW;
     float s0 = 0.f, s1 = 0.f;
-    if (ok) for (int c = cg; c < C; c += 4) {
-        const float a = DT<T>::ld(f0 + (size_t)c * HW), bb = DT<T>::ld(f1 + (size_t)c * HW);
-        s0 += a * a; s1 += bb * bb;
+    for (int c0 = cg; c0 < C; c0 += 4 * LP_U) {
+        float a[LP_U], bb[LP_U];
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j) {
+            const int c = c0 + 4 * j; const size_t o = (size_t)(c < C ? c : C - 1) * HW;
+            a[j] = DT<T>::ld(f0 + o); bb[j] = DT<T>::ld(f1 + o);
+        }
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j)
+            if (ok && c0 + 4 * j < C) { s0 += a[j] * a[j]; s1 += bb[j] * bb[j]; }
     }
     r0[cg][px] = s0; r1[cg][px] = s1;
     __syncthreads();
@@ -107,21 +133,37 @@ __global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const T* __restrict_
     const float n1 = sqrtf(r1[0][px] + r1[1][px] + r1[2][px] + r1[3][px] + eps);
     __syncthreads();
     float dot = 0.f;
-    if (ok) for (int c = cg; c < C; c += 4) {
-        const float u = DT<T>::ld(f0 + (size_t)c * HW) / n0, v = DT<T>::ld(f1 + (size_t)c * HW) / n1;
-        dot += -2.f * w[c] * (u - v) * g * v;
+    for (int c0 = cg; c0 < C; c0 += 4 * LP_U) {
+        float a[LP_U], bb[LP_U], wv[LP_U];
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j) {
+            const int c = c0 + 4 * j; const int ci = c < C ? c : C - 1; const size_t o = (size_t)ci * HW;
+            a[j] = DT<T>::ld(f0 + o); bb[j] = DT<T>::ld(f1 + o); wv[j] = w[ci];
+        }
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j)
+            if (ok && c0 + 4 * j < C) { const float u = a[j] / n0, v = bb[j] / n1; dot += -2.f * wv[j] * (u - v) * g * v; }
     }
     r0[cg][px] = dot;
     __syncthreads();
     const float S = r0[0][px] + r0[1][px] + r0[2][px] + r0[3][px];
-    if (ok) {
-        T* dp = df1 + (size_t)b * C * HW + hw;
-        for (int c = cg; c < C; c += 4) {
-            const float u = DT<T>::ld(f0 + (size_t)c * HW) / n0, v = DT<T>::ld(f1 + (size_t)c * HW) / n1;
-            const float gv = -2.f * w[c] * (u - v) * g;
-            float o = (gv - v * S) / n1;
-            if (accumulate) o += DT<T>::ld(dp + (size_t)c * HW);
-            DT<T>::st(dp + (size_t)c * HW, o);
+    T* dp = df1 + (size_t)b * C * HW + hw;
+    for (int c0 = cg; c0 < C; c0 += 4 * LP_U) {
+        float a[LP_U], bb[LP_U], wv[LP_U], old[LP_U];
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j) {
+            const int c = c0 + 4 * j; const int ci = c < C ? c : C - 1; const size_t o = (size_t)ci * HW;
+            a[j] = DT<T>::ld(f0 + o); bb[j] = DT<T>::ld(f1 + o); wv[j] = w[ci];
+            old[j] = accumulate ? DT<T>::ld(dp + o) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < LP_U; ++j) {
+            const int c = c0 + 4 * j;
+            if (ok && c < C) {
+                const float u = a[j] / n0, v = bb[j] / n1;
+                const float gv = -2.f * wv[j] * (u - v) * g;
+                DT<T>::st(dp + (size_t)c * HW, (gv - v * S) / n1 + old[j]);
+            }
         }
     }
 }
