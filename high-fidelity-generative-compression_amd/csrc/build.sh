@@ -13,4 +13,6 @@ for f in gconv elementwise norm entropy lpips capi; do
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
+# host-side (CPU) table construction for the EVALUATION path: plain g++, no device code
+g++ -O2 -std=c++17 -fPIC -shared -fno-fast-math host_tables.cpp -o ../libhific_host.so
 echo "built $OUT"

@@ -281,7 +281,52 @@ __global__ void fp_param_reduce_kernel(const float* __restrict__ part, FpPtrs P,
     if (accumulate) *dst += s; else *dst = s;
 }
 
+// ---- EVALUATION path, device half of `compress`: int32 symbols + table indices --------------
+// prior_model.py:148-156 (compute_indices: the table entry of each predicted scale = n_table-1 minus the number of
+// table[:-1] entries >= the lower-bounded scale) and :180-181 (symbols = floor(y + 0.5 - mean)), fused; the rANS
+// coder on the host then needs only these two int32 tensors instead of three float tensors.
+__global__ __launch_bounds__(256) void prior_symbols_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ table, int n_table,
+                                                            float scales_min, int* __restrict__ symbols,
+                                                            int* __restrict__ indices, long long n) {
+    __shared__ float tab[256];
+    for (int t = threadIdx.x; t < n_table; t += 256) tab[t] = table[t];
+    __syncthreads();
+    EW_LOOP(i, n) {
+        const float s = fmaxf(scale[i], scales_min);               // LowerBoundToward forward (maths.py:87-95)
+        int idx = n_table - 1;
+        for (int t = 0; t < n_table - 1; ++t) idx -= (s <= tab[t]) ? 1 : 0;
+        indices[i] = idx;
+        symbols[i] = (int)floorf((x[i] + 0.5f) - mean[i]);
+    }
+}
+// hyperprior_model.py:135-139 (indices = channel) and :169 (symbols = floor(z + 0.5))
+__global__ __launch_bounds__(256) void hyper_symbols_kernel(const float* __restrict__ z, int* __restrict__ symbols,
+                                                            int* __restrict__ indices, int C, int HW, long long n) {
+    EW_LOOP(i, n) {
+        symbols[i] = (int)floorf(z[i] + 0.5f);
+        indices[i] = (int)((i / HW) % C);
+    }
+}
+
 extern "C" {
+
+int hific_prior_symbols(const float* x, const float* mean, const float* scale, const float* table, int n_table,
+                        float scales_min, int* symbols, int* indices, long long n, hipStream_t st) {
+    if (n_table < 1 || n_table > 256 || n < 0) return HIFIC_ERR_ARG;
+    if (n == 0) return HIFIC_OK;
+    hipLaunchKernelGGL(prior_symbols_kernel, EW_GRID(n), dim3(256), 0, st, x, mean, scale, table, n_table, scales_min,
+                       symbols, indices, n);
+    return hific_launch_status();
+}
+int hific_hyper_symbols(const float* z, int* symbols, int* indices, int N, int C, int HW, hipStream_t st) {
+    if (N < 0 || C <= 0 || HW <= 0) return HIFIC_ERR_ARG;
+    const long long n = (long long)N * C * HW;
+    if (n == 0) return HIFIC_OK;
+    hipLaunchKernelGGL(hyper_symbols_kernel, EW_GRID(n), dim3(256), 0, st, z, symbols, indices, C, HW, n);
+    return hific_launch_status();
+}
 
 int hific_round_f32(const float* x, const float* mean, float* o, long long n, hipStream_t st) {
     hipLaunchKernelGGL(round_kernel, EW_GRID(n), dim3(256), 0, st, x, mean, o, n);

@@ -629,3 +629,34 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     require_gpu(p, g, m, v)
     call("hific_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
          float(eps), int(step), float(grad_scale), stream())
+
+
+# ---- EVALUATION path: device half of `compress` (int32 symbols + table indices for the host rANS coder) -------------
+SCALES_MIN = 0.11        # src/compression/prior_model.py:19
+
+
+def prior_symbols_and_indices(latents, means, scales, scale_table, scales_min=SCALES_MIN):
+    """`PriorEntropyModel.compress` up to the host handoff (prior_model.py:178-181 with compute_indices :148-156):
+    returns (symbols, indices), int32, same shape as `latents`."""
+    x, m, sc = latents.contiguous().float(), means.contiguous().float(), scales.contiguous().float()
+    tab = scale_table.to(x.device).contiguous().float()
+    require_gpu(x, m, sc, tab)
+    if m.shape != x.shape or sc.shape != x.shape:
+        raise lib.HificError("prior_symbols_and_indices: means/scales must have the shape of the latents")
+    sym = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    idx = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    call("hific_prior_symbols", ptr(x), ptr(m), ptr(sc), ptr(tab), tab.numel(), float(scales_min), ptr(sym), ptr(idx),
+         x.numel(), stream())
+    return sym, idx
+
+
+def hyper_symbols_and_indices(hyperlatents):
+    """`HyperpriorEntropyModel.compress` up to the host handoff (hyperprior_model.py:160-169): symbols = floor(z+.5),
+    indices = channel number, both int32 (N,C,H,W)."""
+    z = hyperlatents.contiguous().float()
+    require_gpu(z)
+    N, C, H, W = z.shape
+    sym = torch.empty(z.shape, dtype=torch.int32, device=z.device)
+    idx = torch.empty(z.shape, dtype=torch.int32, device=z.device)
+    call("hific_hyper_symbols", ptr(z), ptr(sym), ptr(idx), N, C, H * W, stream())
+    return sym, idx

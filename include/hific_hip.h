@@ -127,6 +127,13 @@ int hific_adam_step(float* p, const float* g, float* m, float* v, long long n, f
 /* ---- entropy model (csrc/entropy.hip), all float32 ----------------------------------------------------------- */
 /* floor(x - mean + .5) + mean: src/hyperprior.py:68-74,108-122 (mean may be NULL) */
 int hific_round_f32(const float* x, const float* mean, float* o, long long n, hipStream_t stream);
+/* EVALUATION path, device half of `compress` - int32 outputs for the host rANS coder:
+ * symbols = floor(y + 0.5 - mean) and indices = table entry of max(scale, scales_min)
+ * (src/compression/prior_model.py:148-156,180-181; table = `scale_table_tensor`, n_table <= 256) */
+int hific_prior_symbols(const float* x, const float* mean, const float* scale, const float* table, int n_table,
+                        float scales_min, int* symbols, int* indices, long long n, hipStream_t stream);
+/* symbols = floor(z + 0.5), indices = channel number (src/compression/hyperprior_model.py:135-139,169); z [N,C,HW] */
+int hific_hyper_symbols(const float* z, int* symbols, int* indices, int N, int C, int HW, hipStream_t stream);
 /* LowerBoundToward: src/helpers/maths.py:87-100 */
 int hific_lower_bound_fwd(const float* x, float bound, float* o, long long n, hipStream_t stream);
 int hific_lower_bound_bwd(const float* x, const float* dy, float bound, float* dx, long long n, hipStream_t stream);

@@ -402,3 +402,53 @@ def make_image(seed, B, H=256, W=256, dtype=torch.float32):
 def make_noise(seed, shape, dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     return (torch.rand(shape, generator=g) - 0.5).to(dtype)
+
+
+# ---- EVALUATION path: device half of `compress` ------------------------------------------------
+PRIOR_SCALES_MIN, PRIOR_SCALES_MAX, PRIOR_SCALES_LEVELS = 0.11, 256, 64          # prior_model.py:19-21
+
+
+def prior_scale_table(scales_min=PRIOR_SCALES_MIN, scales_max=PRIOR_SCALES_MAX, levels=PRIOR_SCALES_LEVELS):
+    """prior_model.py:23-25"""
+    import numpy as np
+    return torch.Tensor(np.exp(np.linspace(np.log(scales_min), np.log(scales_max), levels)))
+
+
+def prior_compute_indices(scales, scale_table, scales_min=PRIOR_SCALES_MIN):
+    """prior_model.py:148-156: index of the table entry used for each predicted scale (int32)."""
+    scales = torch.clamp(scales, min=scales_min)                       # LowerBoundToward forward, maths.py:87-95
+    indices = torch.ones_like(scales, dtype=torch.int32) * (len(scale_table) - 1)
+    for s in scale_table[:-1]:
+        indices = indices - (scales <= s).to(torch.int32)
+    return indices
+
+
+def prior_symbols(latents, means):
+    """prior_model.py:180-181"""
+    return torch.floor(latents + 0.5 - means).to(torch.int32)
+
+
+def hyper_symbols_and_indices(hyperlatents):
+    """hyperprior_model.py:135-139,160-169"""
+    N, C, H, W = hyperlatents.shape
+    indices = torch.arange(C, dtype=torch.int32).view(-1, 1, 1).repeat(1, H, W)
+    indices = torch.repeat_interleave(indices.unsqueeze(0), repeats=N, dim=0)
+    return torch.floor(hyperlatents + 0.5).to(torch.int32), indices
+
+
+def make_symbol_inputs(seed=11, shape=(2, 6, 5, 7)):
+    """Latents with exact half-integer residuals (rounding ties), scales on / around every table entry."""
+    g = torch.Generator().manual_seed(seed)
+    table = prior_scale_table()
+    means = torch.randn(shape, generator=g) * 3
+    lat = means + torch.randn(shape, generator=g) * 4
+    lat.view(-1)[::7] = (means.view(-1)[::7] + torch.randint(-6, 6, (means.view(-1)[::7].numel(),), generator=g).float()
+                         + 0.5)
+    scales = torch.exp(torch.randn(shape, generator=g) * 2.5)
+    flat = scales.view(-1)
+    n = min(flat.numel() // 3, len(table))
+    flat[:n] = table[:n]                                        # exactly on a table entry (the `<=` boundary)
+    flat[n:2 * n] = table[:n] * (1 + 1e-6)
+    flat[2 * n:3 * n] = table[:n] * (1 - 1e-6)
+    flat[-3:] = torch.tensor([0.0, 0.05, 1e4])                  # below SCALES_MIN, above the table
+    return lat, means, scales, table

@@ -53,3 +53,15 @@ def test_workspace_queries(built_lib):
     lib.hific_conv2d_ws_bytes.restype = ctypes.c_size_t
     b = lib.hific_conv2d_ws_bytes(16, 960, 16, 16, 960, 3, 3, 1, 1, 1, 1, 1, 1)
     assert 16 * 2 ** 20 < b < 2 ** 31
+
+
+def test_host_library_exports_every_declared_symbol(built_lib):
+    """libhific_host.so (CPU-side table construction, include/hific_host.h) is built next to the device library."""
+    path = os.path.join(os.path.dirname(built_lib), "libhific_host.so")
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hific_host.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(hific_[a-z0-9_]+)\s*\(", txt)))
+    assert syms == ["hific_build_cdf_rows", "hific_host_version", "hific_pmf_to_quantized_cdf"]
+    for s in syms:
+        assert hasattr(lib, s)

@@ -227,3 +227,23 @@ def test_spectral_norm_and_upcat(hific, dev):
     torch.cuda.synchronize()
     assert torch.equal(out.detach().cpu(), outr.detach())
     assert _relerr(idv.grad.cpu(), ir.grad) < 1e-6 and _relerr(cdv.grad.cpu(), cr.grad) < 1e-5
+
+
+def test_compress_symbols_and_indices_bit_exact(hific, dev):
+    """EVALUATION path, device half of `compress`: int32 symbols and table indices equal the
+    oracle's (= the reference's, tests/test_oracle_vs_reference.py::test_symbols_and_indices) exactly, including
+    rounding ties and scales exactly on table entries."""
+    from hific_amd import ops
+    for seed, shape in ((11, (2, 6, 5, 7)), (12, (1, 220, 16, 16)), (13, (3, 1, 1, 1))):
+        lat, means, scales, table = O.make_symbol_inputs(seed, shape)
+        sym, idx = ops.prior_symbols_and_indices(lat.to(dev), means.to(dev), scales.to(dev), table)
+        torch.cuda.synchronize()
+        assert sym.dtype == torch.int32 and idx.dtype == torch.int32
+        assert torch.equal(sym.cpu(), O.prior_symbols(lat, means))
+        assert torch.equal(idx.cpu(), O.prior_compute_indices(scales, table))
+    z = torch.randn(2, 320, 4, 4) * 6
+    z.view(-1)[::5] = torch.randint(-8, 8, (z.view(-1)[::5].numel(),)).float() + 0.5
+    sym, idx = ops.hyper_symbols_and_indices(z.to(dev))
+    torch.cuda.synchronize()
+    s_o, i_o = O.hyper_symbols_and_indices(z)
+    assert torch.equal(sym.cpu(), s_o) and torch.equal(idx.cpu(), i_o)

@@ -98,3 +98,24 @@ def test_packaged_lin_weights_equal_reference(ns):
     w = np.load(p)
     for i in range(5):
         assert torch.equal(torch.from_numpy(w[f"lin{i}"]), lins[i])
+
+
+def test_symbols_and_indices(ns):
+    """EVALUATION path, device half of compress: oracle restatement == reference methods (bit-exact int32)."""
+    from types import SimpleNamespace
+    from src.compression import prior_model, hyperprior_model
+    lat, means, scales, table = O.make_symbol_inputs()
+    assert torch.equal(table, prior_model.prior_scale_table())
+    stub = SimpleNamespace(scale_table=table)
+    idx_ref = prior_model.PriorEntropyModel.compute_indices(stub, scales)
+    idx = O.prior_compute_indices(scales, table)
+    assert idx.dtype == torch.int32 and torch.equal(idx, idx_ref)
+    assert int(idx.min()) == 0 and int(idx.max()) == len(table) - 1
+    assert torch.equal(O.prior_symbols(lat, means), torch.floor(lat + 0.5 - means).to(torch.int32))   # :180
+    z = torch.randn(3, 5, 2, 4) * 6
+    z.view(-1)[::5] = torch.randint(-8, 8, (z.view(-1)[::5].numel(),)).float() + 0.5
+    stub2 = SimpleNamespace(distribution=SimpleNamespace(n_channels=5))
+    ind = hyperprior_model.HyperpriorEntropyModel.compute_indices(stub2, (2, 4))
+    ind = torch.repeat_interleave(ind.unsqueeze(0), repeats=3, dim=0)                                 # :163-165
+    sym, ind_o = O.hyper_symbols_and_indices(z)
+    assert torch.equal(ind_o, ind) and torch.equal(sym, torch.floor(z + 0.5).to(torch.int32))
