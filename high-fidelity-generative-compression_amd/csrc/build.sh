@@ -14,5 +14,5 @@ done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
 # host-side (CPU) table construction for the EVALUATION path: plain g++, no device code
-g++ -O2 -std=c++17 -fPIC -shared -fno-fast-math host_tables.cpp -o ../libhific_host.so
+g++ -O2 -std=c++17 -fPIC -shared -fno-fast-math host_tables.cpp host_rans.cpp -o ../libhific_host.so
 echo "built $OUT"

@@ -28,6 +28,44 @@ int hific_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int64_t* 
 int hific_build_cdf_rows(const float* pmf, int rows, int stride, const int32_t* lengths, const float* extra,
                          int precision, int32_t* cdf, int cdf_stride);
 
+/* ---- rANS coder, scalar ("vectorize=False") path of the reference -----------------------
+ * Bit-compatible port of `entropy_coding.ans_index_encoder` / `ans_index_decoder` (src/compression/entropy_coding.py:
+ * 107-268, 479-559) over the 64-bit rANS of src/compression/ans.py:45-96: one coder state, 32-bit renormalisation
+ * words, symbols outside [offset, offset + length - 2) sent as the overflow symbol followed by a 4-bit-nibble
+ * variable-length code.  `symbols` / `indices` are the flattened int32 tensors the reference passes (the device
+ * side produces them: hific_prior_symbols / hific_hyper_symbols); cdf is [rows][stride] uint32 with per-row
+ * `cdf_length` / `cdf_offset` (the CDF / CDF_length / CDF_offset parameters of the entropy models).
+ * The encoded message is the reference's `vrans.flatten` layout: [state >> 32, state & 0xffffffff, words...]. */
+#define HIFIC_HOST_ERR_RANGE (-6)    /* index outside [0, rows), cdf_length outside [2, stride], precision outside [8,24] */
+#define HIFIC_HOST_ERR_SPACE (-7)    /* output buffer too small: *out_len holds the required number of words */
+#define HIFIC_HOST_ERR_DATA  (-8)    /* decoder ran out of words / corrupt message */
+int hific_rans_encode(const int32_t* symbols, const int32_t* indices, long long n, const uint32_t* cdf, int rows,
+                      int stride, const int32_t* cdf_length, const int32_t* cdf_offset, int precision,
+                      uint32_t* out, long long out_cap, long long* out_len);
+int hific_rans_decode(const uint32_t* encoded, long long enc_len, const int32_t* indices, long long n,
+                      const uint32_t* cdf, int rows, int stride, const int32_t* cdf_length,
+                      const int32_t* cdf_offset, int precision, int32_t* symbols);
+
+/* ---- rANS coder, vectorised ("vectorize=True", the reference's default) path -------------------------------------
+ * Bit-compatible port of `vec_ans_index_encoder` / `vec_ans_index_decoder` (entropy_coding.py:271-476, 561-673):
+ * `lanes` interleaved coder states sharing one word stack, `steps` vector pushes.  The caller lays the int32
+ * symbols / indices out as [steps][lanes] exactly as the reference does: batch 1 -> steps = H*W patches (PATCH_SIZE
+ * (1,1), row-major), lanes = C channels (`compression_utils.decompose`); batch B > 1 -> steps = B, lanes = C*H*W.
+ * Overflowing lanes are coded on a sub-stack of the masked lanes with 4-bit symbols.  The reference's quirks are
+ * reproduced, because the bitstream depends on them: every nibble iteration re-pushes nibble 0 (`counter` is reset
+ * inside the loop, :400/:642), so out-of-range symbols whose overflow code needs more than one nibble decode to the
+ * value of their lowest nibble - with the reference's decoder and with this one alike - and lanes that have run out
+ * of nibbles keep pushing their last value while any other lane still has some.  The branch for more than 14
+ * nibbles (:382-391, "Undefined behaviour") is unreachable for int32 symbols and returns HIFIC_HOST_ERR_RANGE.
+ * Message layout (`vrans.flatten`): [state >> 32 for every lane][state & 0xffffffff for every lane][words...]. */
+int hific_rans_encode_vec(const int32_t* symbols, const int32_t* indices, long long steps, long long lanes,
+                          const uint32_t* cdf, int rows, int stride, const int32_t* cdf_length,
+                          const int32_t* cdf_offset, int precision, uint32_t* out, long long out_cap,
+                          long long* out_len);
+int hific_rans_decode_vec(const uint32_t* encoded, long long enc_len, const int32_t* indices, long long steps,
+                          long long lanes, const uint32_t* cdf, int rows, int stride, const int32_t* cdf_length,
+                          const int32_t* cdf_offset, int precision, int32_t* symbols);
+
 const char* hific_host_version(void);
 
 #ifdef __cplusplus

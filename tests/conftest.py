@@ -34,3 +34,10 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_collection_modifyitems(config, items):
+    # the reference's own codec emits NumPy deprecation warnings by the hundred when it is run as the pin
+    for item in items:
+        if "test_host_rans" in item.nodeid:
+            item.add_marker(pytest.mark.filterwarnings("ignore::DeprecationWarning"))

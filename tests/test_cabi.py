@@ -62,6 +62,7 @@ def test_host_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(path)
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hific_host.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(hific_[a-z0-9_]+)\s*\(", txt)))
-    assert syms == ["hific_build_cdf_rows", "hific_host_version", "hific_pmf_to_quantized_cdf"]
+    assert syms == ["hific_build_cdf_rows", "hific_host_version", "hific_pmf_to_quantized_cdf", "hific_rans_decode",
+                    "hific_rans_decode_vec", "hific_rans_encode", "hific_rans_encode_vec"]
     for s in syms:
         assert hasattr(lib, s)

@@ -1,0 +1,104 @@
+"""Host rANS coder: the native port in libhific_host.so reproduces the reference's bitstreams
+byte for byte - scalar and vectorised paths - and its decoders return what the reference's decoders return (including
+the vectorised path's documented loss on multi-nibble overflows).  Goldens: tests/golden/make_rans_golden.py (the
+reference's own codec under the two environment shims of oracle/ref_codec_shims.py)."""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+HAVE_REF = os.path.isdir("/root/reference/src")
+
+
+@pytest.fixture(scope="module")
+def rans():
+    from hific_amd.compression import rans as r
+    return r
+
+
+@pytest.fixture(scope="module")
+def tabs():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tables_golden.npz"))
+    return {n: (g[n + "_CDF"].astype(np.uint32), g[n + "_CDF_length"].astype(np.int32), g[n + "_CDF_offset"].astype(np.int32))
+            for n in ("prior", "hyper")}
+
+
+def test_golden_bitstreams(rans, tabs):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rans_golden.npz"))
+    lossy = 0
+    for k in range(int(g["n_cases"])):
+        cdf, cl, co = tabs[str(g[f"table_{k}"])]
+        sym, idx = g[f"sym_{k}"], g[f"idx_{k}"]
+        enc, shape = rans.ans_compress(sym, idx, cdf, cl, co, sym.shape[1:], 16, vectorize=False, block_encode=True)
+        assert enc.dtype == np.uint32 and np.array_equal(enc, g[f"enc_scalar_{k}"]), k
+        dec = rans.ans_decompress(enc, idx, cdf, cl, co, shape, 16, vectorize=False, block_decode=True)
+        assert np.array_equal(dec, g[f"dec_scalar_{k}"]) and np.array_equal(dec, sym), k     # scalar path is lossless
+        enc_v, cshape = rans.ans_compress(sym, idx, cdf, cl, co, sym.shape[1:], 16, vectorize=True)
+        assert np.array_equal(enc_v, g[f"enc_vec_{k}"]) and tuple(cshape) == tuple(g[f"cshape_vec_{k}"]), k
+        dec_v = rans.ans_decompress(enc_v, idx, cdf, cl, co, cshape, 16, vectorize=True)
+        assert np.array_equal(dec_v, g[f"dec_vec_{k}"]), k
+        lossy += int(not np.array_equal(dec_v, sym))
+    assert 0 < lossy < int(g["n_cases"])        # the far-overflow cases decode lossily, exactly as in the reference
+
+
+def test_roundtrip_properties(rans, tabs):
+    rng = np.random.default_rng(5)
+    cdf, cl, co = tabs["prior"]
+    for shape in ((1, 220, 16, 16), (4, 16, 8, 8), (1, 1, 1, 1)):
+        idx = rng.integers(0, cdf.shape[0], shape).astype(np.int32)
+        width = (cl[idx] - 2).astype(np.int64)
+        sym = (co[idx] + rng.integers(0, 1 << 30, shape) % np.maximum(width, 1)).astype(np.int32)   # all in range
+        sym.flat[::17] = (co[idx] + width).flat[::17] + rng.integers(0, 7, sym.flat[::17].shape)   # one-nibble overflows
+        for vec in (False, True):
+            enc, cs = rans.ans_compress(sym, idx, cdf, cl, co, shape[1:], 16, vectorize=vec)
+            dec = rans.ans_decompress(enc, idx, cdf, cl, co, cs, 16, vectorize=vec)
+            assert np.array_equal(dec, sym), (shape, vec)
+    sym = rng.integers(-5000, 5000, (2, 3, 4, 4)).astype(np.int32)                                  # scalar: any int32
+    idx = rng.integers(0, cdf.shape[0], sym.shape).astype(np.int32)
+    enc, cs = rans.ans_compress(sym, idx, cdf, cl, co, sym.shape[1:], 16, vectorize=False)
+    assert np.array_equal(rans.ans_decompress(enc, idx, cdf, cl, co, cs, 16, vectorize=False), sym)
+    per = rans.ans_compress(sym, idx, cdf, cl, co, sym.shape[1:], 16, vectorize=False, block_encode=False)
+    assert len(per) == 2
+    assert np.array_equal(rans.ans_decompress(per, idx, cdf, cl, co, cs, 16, vectorize=False, block_decode=False), sym)
+
+
+def test_errors_are_loud(rans, tabs):
+    cdf, cl, co = tabs["hyper"]
+    sym = np.zeros((1, 2, 2, 2), np.int32); idx = np.zeros_like(sym)
+    bad = idx.copy(); bad.flat[3] = cdf.shape[0]
+    with pytest.raises(rans.RansError):
+        rans.ans_compress(sym, bad, cdf, cl, co, (2, 2, 2), 16)
+    with pytest.raises(rans.RansError):
+        rans.ans_compress(sym, idx, cdf, cl, co, (2, 2, 2), 40)
+    enc, cs = rans.ans_compress(sym + 100000, idx, cdf, cl, co, (2, 2, 2), 16)
+    with pytest.raises(rans.RansError):
+        rans.ans_decompress(enc[:3], idx, cdf, cl, co, cs, 16)           # truncated message
+    with pytest.raises(rans.RansError):
+        rans.ans_compress(sym[0], idx[0], cdf, cl, co, (2, 2, 2), 16)    # not (N,C,H,W)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="needs the reference checkout")
+def test_against_reference_codec(rans, tabs):
+    import ref_loader, ref_codec_shims
+    ref_loader.load()
+    _, cu = ref_codec_shims.apply()
+    rng = np.random.default_rng(99)
+    for name, (cdf, cl, co) in tabs.items():
+        for shape in ((1, 6, 3, 4), (2, 5, 2, 3)):
+            idx = rng.integers(0, cdf.shape[0], shape).astype(np.int32)
+            sym = np.round(rng.normal(0, 6, shape)).astype(np.int32)
+            sym.flat[0] = 70000; sym.flat[5] = -12345
+            for vec in (False, True):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    enc_r, cs_r = cu.ans_compress(sym, idx, cdf, cl, co, shape[1:], precision=16, vectorize=vec, block_encode=True)
+                    dec_r = cu.ans_decompress(enc_r, idx, cdf, cl, co, cs_r, precision=16, vectorize=vec, block_decode=True)
+                enc, cs = rans.ans_compress(sym, idx, cdf, cl, co, shape[1:], 16, vectorize=vec)
+                assert np.array_equal(enc, np.asarray(enc_r, dtype=np.uint32)) and tuple(cs) == tuple(cs_r)
+                dec = rans.ans_decompress(enc, idx, cdf, cl, co, cs, 16, vectorize=vec)
+                assert np.array_equal(dec, np.asarray(dec_r).reshape(shape).astype(np.int32))
