@@ -102,3 +102,47 @@ def test_against_reference_codec(rans, tabs):
                 assert np.array_equal(enc, np.asarray(enc_r, dtype=np.uint32)) and tuple(cs) == tuple(cs_r)
                 dec = rans.ans_decompress(enc, idx, cdf, cl, co, cs, 16, vectorize=vec)
                 assert np.array_equal(dec, np.asarray(dec_r).reshape(shape).astype(np.int32))
+
+
+def _container_case():
+    rng = np.random.default_rng(3)
+    from hific_amd.compression import container
+    co = container.CompressionOutput(
+        hyperlatents_encoded=rng.integers(0, 2 ** 32, 321, dtype=np.uint64).astype(np.uint32),
+        latents_encoded=rng.integers(0, 2 ** 32, 4567, dtype=np.uint64).astype(np.uint32),
+        hyperlatent_spatial_shape=(4, 6), batch_shape=1, spatial_shape=(256, 384),
+        hyper_coding_shape=(320, 1, 1), latent_coding_shape=(220, 1, 1))
+    return container, co
+
+
+def test_hfc_container_roundtrip_and_layout(tmp_path):
+    container, co = _container_case()
+    path = str(tmp_path / "a.hfc")
+    actual_bpp, _ = container.save_compressed_format(co, path)
+    raw = open(path, "rb").read()
+    assert len(raw) == 2 * 11 + 4 + (4 + 4 * 321 + 4) + (4 + 4 * 4567 + 4)
+    assert raw[22:26] == b"\x46\xE2\x84\x92" and raw[-4:] == b"\x46\xE2\x84\x92"
+    assert abs(actual_bpp - 8.0 * len(raw) / (256 * 384)) < 1e-12
+    back = container.load_compressed_format(path)
+    assert back.hyperlatent_spatial_shape == (4, 6) and back.spatial_shape == (256, 384) and back.batch_shape == 1
+    assert back.hyper_coding_shape == (320, 1, 1) and back.latent_coding_shape == (220, 1, 1)
+    assert np.array_equal(back.hyperlatents_encoded, co.hyperlatents_encoded)
+    assert np.array_equal(back.latents_encoded, co.latents_encoded)
+    open(path, "wb").write(raw[:100])
+    with pytest.raises(container.ContainerError):
+        container.load_compressed_format(path)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="needs the reference checkout")
+def test_hfc_container_bytes_equal_reference(tmp_path):
+    import ref_loader, ref_codec_shims
+    ref_loader.load()
+    _, cu = ref_codec_shims.apply()
+    container, co = _container_case()
+    ours, theirs = str(tmp_path / "ours.hfc"), str(tmp_path / "ref.hfc")
+    container.save_compressed_format(co, ours)
+    from types import SimpleNamespace
+    cu.save_compressed_format(SimpleNamespace(total_bpp=0.5, **co._asdict()), theirs)
+    assert open(ours, "rb").read() == open(theirs, "rb").read()
+    back = cu.load_compressed_format(ours)                      # the reference reads what we write
+    assert np.array_equal(back.latents_encoded, co.latents_encoded) and back.latent_coding_shape == (220, 1, 1)
