@@ -1,0 +1,85 @@
+"""EVALUATION path: `Hyperprior.compress_forward / decompress_forward` (src/hyperprior.py:195-274) as a
+device-agnostic orchestration of the pieces this package provides:
+
+    networks (analysis / synthesis_mu / synthesis_std)  - the HIP modules on the GPU, or any callables
+    symbol extraction                                    - ops.prior_symbols_and_indices / hyper_symbols_and_indices
+    rANS coder + tables                                  - compression.rans / compression.tables (libhific_host.so)
+
+The networks and the symbol extractors are passed in as callables, so the same code runs with the device modules
+(`hific_amd.hyperprior.Hyperprior.compress_forward`) and, in the CPU tests, with the oracle's functional networks,
+where it is pinned byte for byte against the reference's `compress_forward`.
+"""
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import rans
+from .container import CompressionOutput
+
+EntropyTables = namedtuple("EntropyTables", ["CDF", "CDF_offset", "CDF_length"])          # int32 tensors / arrays
+CodecNets = namedtuple("CodecNets", ["analysis", "synthesis_mu", "synthesis_std"])        # callables tensor -> tensor
+SymbolFns = namedtuple("SymbolFns", ["hyper", "prior", "prior_indices"])
+# hyper(z) -> (symbols, indices); prior(y, means, scales, scale_table) -> (symbols, indices);
+# prior_indices(scales, scale_table) -> indices          (all int32, (N,C,H,W))
+
+PRECISION = 16                 # entropy_models.PRECISION_P
+SCALE_LOWER_BOUND = 0.11       # hyperprior.py: scale_lower_bound / MIN_SCALE
+
+
+def _tab(t):
+    f = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return f(t.CDF).astype(np.uint32), f(t.CDF_length).astype(np.int32), f(t.CDF_offset).astype(np.int32)
+
+
+def compress_forward(latents, spatial_shape, nets, hyper_tables, prior_tables, scale_table, symbol_fns,
+                     vectorize=True, block_encode=True, precision=PRECISION, scale_lower_bound=SCALE_LOWER_BOUND):
+    """hyperprior.py:195-246 without the (reporting-only) entropy estimates.  Returns the 7-field
+    `CompressionOutput` that `container.save_compressed_format` writes."""
+    hyperlatents = nets.analysis(latents)
+    hyper_hw = tuple(int(s) for s in hyperlatents.shape[2:])
+    batch = int(latents.shape[0])
+    # hyperlatents: symbols = floor(z + .5), one table row per channel (hyperprior_model.py:141-199)
+    sym, idx = symbol_fns.hyper(hyperlatents)
+    cdf, cl, co = _tab(hyper_tables)
+    hyp_enc, hyper_coding_shape = rans.ans_compress(sym, idx, cdf, cl, co, tuple(sym.shape[1:]), precision,
+                                                    vectorize=vectorize, block_encode=block_encode)
+    # the encoder continues from what the decoder will see (hyperprior.py:211-215)
+    hyp_sym = rans.ans_decompress(hyp_enc, idx, cdf, cl, co, hyper_coding_shape, precision, vectorize=vectorize,
+                                  block_decode=block_encode)
+    hyperlatents_decoded = torch.from_numpy(np.asarray(hyp_sym)).to(latents.dtype).to(latents.device)
+    means = nets.synthesis_mu(hyperlatents_decoded)
+    scales = torch.clamp(nets.synthesis_std(hyperlatents_decoded), min=scale_lower_bound)    # LowerBoundToward fwd
+    sym, idx = symbol_fns.prior(latents, means, scales, scale_table)
+    cdf, cl, co = _tab(prior_tables)
+    lat_enc, latent_coding_shape = rans.ans_compress(sym, idx, cdf, cl, co, tuple(sym.shape[1:]), precision,
+                                                     vectorize=vectorize, block_encode=block_encode)
+    return CompressionOutput(hyperlatents_encoded=hyp_enc, latents_encoded=lat_enc,
+                             hyperlatent_spatial_shape=hyper_hw, batch_shape=batch,
+                             spatial_shape=tuple(int(s) for s in spatial_shape),
+                             hyper_coding_shape=tuple(int(s) for s in hyper_coding_shape),
+                             latent_coding_shape=tuple(int(s) for s in latent_coding_shape))
+
+
+def decompress_forward(compression_output, nets, hyper_tables, prior_tables, scale_table, symbol_fns, n_hyper_channels,
+                       device="cpu", dtype=torch.float32, vectorize=True, block_decode=True, precision=PRECISION,
+                       scale_lower_bound=SCALE_LOWER_BOUND):
+    """hyperprior.py:248-274: returns the dequantised latents (symbols + means), (N,C,H,W) on `device`."""
+    co_ = compression_output
+    B = int(co_.batch_shape)
+    Hh, Wh = (int(s) for s in co_.hyperlatent_spatial_shape)
+    idx = np.ascontiguousarray(np.broadcast_to(np.arange(n_hyper_channels, dtype=np.int32).reshape(1, -1, 1, 1),
+                                               (B, n_hyper_channels, Hh, Wh)))                # hyperprior_model.py:135-139
+    cdf, cl, co = _tab(hyper_tables)
+    hyp_sym = rans.ans_decompress(co_.hyperlatents_encoded, idx, cdf, cl, co, tuple(co_.hyper_coding_shape), precision,
+                                  vectorize=vectorize, block_decode=block_decode)
+    hyperlatents_decoded = torch.from_numpy(np.asarray(hyp_sym)).to(dtype).to(device)
+    means = nets.synthesis_mu(hyperlatents_decoded)
+    scales = torch.clamp(nets.synthesis_std(hyperlatents_decoded), min=scale_lower_bound)
+    idx = symbol_fns.prior_indices(scales, scale_table)
+    idx = idx.detach().cpu().numpy() if isinstance(idx, torch.Tensor) else np.asarray(idx)
+    cdf, cl, co = _tab(prior_tables)
+    lat_sym = rans.ans_decompress(co_.latents_encoded, idx, cdf, cl, co, tuple(co_.latent_coding_shape), precision,
+                                  vectorize=vectorize, block_decode=block_decode)
+    symbols = torch.from_numpy(np.asarray(lat_sym)).to(means.dtype).to(means.device)
+    return symbols + means                                                                     # dequantize, :246

@@ -112,5 +112,70 @@ def build_hyperprior_tables(likelihood_fn, lower_tail, upper_tail, precision=16)
     return cdf, (-minima).to(torch.int32), (pmf_length + 2).to(torch.int32)
 
 
+# ---- factorised hyperlatent density on the host (table construction only; the training path runs in entropy.hip) -----
+TAIL_MASS = 2 ** (-8)          # entropy_models.TAIL_MASS
+MIN_LIKELIHOOD = 1e-9
+
+
+def _density_params(params, prefix=""):
+    """H_k, a_k, b_k (k = 0..3) as float32 CPU tensors from a module / state_dict-like mapping."""
+    get = (lambda n: getattr(params, n)) if not isinstance(params, dict) else (lambda n: params[prefix + n])
+    return [tuple(get(f"{n}_{k}").detach().float().cpu() for n in ("H", "a", "b")) for k in range(4)]
+
+
+def _cdf_logits(par, x):
+    """hyperprior_model.py:305-326; x (C,1,L)."""
+    logits = x
+    for H, a, b in par:
+        logits = torch.bmm(torch.nn.functional.softplus(H), logits)
+        logits = logits + b
+        logits = logits + torch.tanh(a) * torch.tanh(logits)
+    return logits
+
+
+def _density_likelihood(par, x):
+    """hyperprior_model.py:349-377 in collapsed (C,1,L) format."""
+    up = _cdf_logits(par, x + 0.5)
+    lo = _cdf_logits(par, x - 0.5)
+    sign = -torch.sign(up + lo)
+    lik = torch.abs(torch.sigmoid(sign * up) - torch.sigmoid(sign * lo))
+    return torch.clamp(lik, min=MIN_LIKELIHOOD)                       # LowerBoundToward forward
+
+
+def estimate_tails(cdf, target, shape, extra_counts=24):
+    """compression_utils.py:30-80: Adam iteration (lr 1e-2, betas .9/.99) for x with cdf(x) == target, run until
+    every element has passed its optimum by `extra_counts` steps.  Same float32 operation sequence as the reference."""
+    lr, eps, beta_1, beta_2 = 1e-2, 1e-8, 0.9, 0.99
+    tails = torch.zeros(shape, dtype=torch.float32, requires_grad=True)
+    m = torch.zeros(shape, dtype=torch.float32)
+    v = torch.ones(shape, dtype=torch.float32)
+    counts = torch.zeros(shape, dtype=torch.int32)
+    while torch.min(counts) < extra_counts:
+        loss = abs(cdf(tails) - target)
+        loss.backward(torch.ones_like(tails))
+        tgrad = tails.grad
+        with torch.no_grad():
+            m = beta_1 * m + (1. - beta_1) * tgrad
+            v = beta_2 * v + (1. - beta_2) * torch.square(tgrad)
+            tails -= lr * m / (torch.sqrt(v) + eps)
+        counts = torch.where(torch.logical_or(counts > 0, tgrad * tails.detach() > 0), counts + 1, counts)
+        tails.grad.zero_()
+    return tails.detach()
+
+
+def build_hyperprior_tables_from_params(params, prefix="", tail_mass=TAIL_MASS, precision=16):
+    """`HyperpriorEntropyModel.build_tables` (hyperprior_model.py:42-105) from the density's parameters
+    (`Hyperprior.hyperlatent_likelihood` module, or a state_dict with `prefix`): tails by `estimate_tails`
+    (:331-341), pmf by the density's likelihood, rows by the native quantiser."""
+    import math
+    par = _density_params(params, prefix)
+    C = par[0][0].shape[0]
+    cdf_fn = lambda x: _cdf_logits(par, x)
+    lower = estimate_tails(cdf_fn, -math.log(2. / tail_mass - 1.), (C, 1, 1)).reshape(C)
+    upper = estimate_tails(cdf_fn, math.log(2. / tail_mass - 1.), (C, 1, 1)).reshape(C)
+    with torch.no_grad():
+        return build_hyperprior_tables(lambda s: _density_likelihood(par, s), lower, upper, precision)
+
+
 def host_version():
     return _load().hific_host_version().decode()

@@ -3,8 +3,10 @@ HyperInfo): same constructor signature, attribute names (`analysis_net`, `synthe
 `hyperlatent_likelihood`, `amortization_models`) and the same order of noise draws from torch's global RNG
 (hyperlatent noise, then latent noise: src/hyperprior.py:283,305).  All arithmetic runs in csrc/entropy.hip.
 
-The EVALUATION-mode methods (compress_forward / decompress_forward, src/hyperprior.py:195-274) hand numpy arrays
-to the host rANS coder and are out of scope for this round."""
+The EVALUATION-mode methods (`build_tables`, `compress_forward`, `decompress_forward`, src/hyperprior.py:183-274) are
+the device modules plugged into `compression.codec` (symbols/indices from csrc/entropy.hip, tables + rANS coder from
+libhific_host.so); the orchestration and the host pieces are pinned byte for byte on the CPU
+(tests/test_host_codec.py), this GPU wiring has not been run on a GPU yet."""
 from collections import namedtuple
 
 import numpy as np
@@ -92,16 +94,61 @@ class Hyperprior(CodingModel):
             self.likelihood_logistic = 1
         else:
             raise ValueError('Unknown likelihood model: {}'.format(likelihood_type))
+        self.hyperlatent_filters = hyperlatent_filters
+        self.likelihood_type = likelihood_type
+        self.vectorize_encoding = vectorize_encoding
+        self.block_encode = block_encode
+        self._tables = None
         if entropy_code is True:
-            raise NotImplementedError(
-                "entropy_code=True builds the host rANS tables (reference src/compression/*): out of scope for the "
-                "MI355X hot path; use the reference's host coder with this module's outputs")
+            self.build_tables()
 
-    def compress_forward(self, *a, **k):
-        raise NotImplementedError("host rANS coding path (src/hyperprior.py:195) is out of scope this round")
+    # ---- EVALUATION path (src/hyperprior.py:183-274) -----------------------------------------------------------
+    def build_tables(self):
+        """Prior tables (64 scales, prior_model.py:77-120) and hyperprior tables from the current density parameters
+        (hyperprior_model.py:42-105; the reference rebuilds these after loading a checkpoint, compress.py:61)."""
+        import scipy.stats
+        from .compression import codec, tables
+        scale_table = torch.Tensor(np.exp(np.linspace(np.log(0.11), np.log(256), 64)))         # prior_model.py:23-25
+        scale_table = torch.clamp(scale_table, min=self.scale_lower_bound)                       # :60
+        if self.likelihood_logistic:
+            std_cdf, std_q = torch.sigmoid, (lambda q: scipy.stats.logistic.ppf(q))
+        else:
+            std_cdf, std_q = (lambda x: 0.5 * torch.erfc(-(2 ** -0.5) * x)), (lambda q: scipy.stats.norm.ppf(q))
+        prior = codec.EntropyTables(*tables.build_prior_tables(scale_table, std_cdf, std_q))
+        hyp = codec.EntropyTables(*tables.build_hyperprior_tables_from_params(self.hyperlatent_likelihood))
+        self._tables = (hyp, prior, scale_table)
+        return self._tables
 
-    def decompress_forward(self, *a, **k):
-        raise NotImplementedError("host rANS coding path (src/hyperprior.py:248) is out of scope this round")
+    def _codec_parts(self):
+        from .compression import codec
+        if self._tables is None:
+            self.build_tables()
+        nets = codec.CodecNets(self.analysis_net, self.synthesis_mu, self.synthesis_std)
+        fns = codec.SymbolFns(
+            hyper=ops.hyper_symbols_and_indices, prior=ops.prior_symbols_and_indices,
+            prior_indices=lambda scales, tab: ops.prior_symbols_and_indices(scales, scales, scales, tab)[1])
+        return nets, fns
+
+    def compress_forward(self, latents, spatial_shape, **kwargs):
+        """hyperprior.py:195-246 (without the reporting-only entropy estimates): 7-field CompressionOutput."""
+        from .compression import codec
+        nets, fns = self._codec_parts()
+        hyp, prior, scale_table = self._tables
+        with torch.no_grad():
+            return codec.compress_forward(latents.float(), spatial_shape, nets, hyp, prior, scale_table, fns,
+                                          vectorize=self.vectorize_encoding, block_encode=self.block_encode,
+                                          scale_lower_bound=self.scale_lower_bound)
+
+    def decompress_forward(self, compression_output, device):
+        """hyperprior.py:248-274: dequantised latents on `device`."""
+        from .compression import codec
+        nets, fns = self._codec_parts()
+        hyp, prior, scale_table = self._tables
+        with torch.no_grad():
+            return codec.decompress_forward(compression_output, nets, hyp, prior, scale_table, fns,
+                                            n_hyper_channels=self.hyperlatent_filters, device=device,
+                                            vectorize=self.vectorize_encoding, block_decode=self.block_encode,
+                                            scale_lower_bound=self.scale_lower_bound)
 
     def forward(self, latents, spatial_shape, **kwargs):
         if latents.dtype != torch.float32:

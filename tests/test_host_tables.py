@@ -104,3 +104,27 @@ def test_against_imported_reference(tables):
                 tables.pmf_to_quantized_cdf(pmf, prec)
             continue
         assert torch.equal(tables.pmf_to_quantized_cdf(pmf, prec), want), trial
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="needs the reference checkout")
+def test_hyperprior_tables_from_parameters_equal_reference(tables):
+    """Tail estimation (Adam iteration) + density + quantiser, all on our side, against the reference's
+    `HyperpriorEntropyModel.build_tables` for the same (perturbed) density parameters."""
+    import contextlib, io
+    import ref_loader
+    ref_loader.load()
+    from src.compression import hyperprior_model
+    torch.manual_seed(3)
+    hd = hyperprior_model.HyperpriorDensity(n_channels=24)
+    with torch.no_grad():
+        for p in hd.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    hem = hyperprior_model.HyperpriorEntropyModel(distribution=hd)
+    with contextlib.redirect_stderr(io.StringIO()):
+        hem.build_tables()
+    cdf, off, ln = tables.build_hyperprior_tables_from_params(hd, tail_mass=hem.tail_mass, precision=hem.precision)
+    assert torch.equal(off, hem.CDF_offset.data) and torch.equal(ln, hem.CDF_length.data)
+    assert torch.equal(cdf, hem.CDF.data)
+    sd = {"x." + k: v for k, v in hd.state_dict().items()}
+    cdf2, _, _ = tables.build_hyperprior_tables_from_params(sd, prefix="x.", tail_mass=hem.tail_mass, precision=hem.precision)
+    assert torch.equal(cdf2, cdf)
