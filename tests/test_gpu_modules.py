@@ -185,3 +185,28 @@ def test_model_losses_and_grads_fp32(hific, dev, sd, gan):
     params = dict(model.named_parameters())
     for k in watch:
         assert _relerr(params[k].grad.cpu(), sdr[k].grad) < 1e-2, k
+
+
+@pytest.mark.xfail(strict=False, reason="EVALUATION-path GPU wiring (Hyperprior.compress_forward / decompress_forward): "
+                                        "every piece is tested (tests/test_host_*.py, test_compress_symbols_*), the "
+                                        "composition on the device had no GPU minutes left in round 1 - first run here")
+def test_zz_hyperprior_compress_roundtrip(hific, dev, tmp_path):
+    """compress_forward -> .hfc -> decompress_forward on the device modules: the decoder reproduces the latents
+    quantised around the means that the (same) synthesis kernels predict from the decoded hyperlatents."""
+    import hific_amd
+    from hific_amd.compression import container
+    hific.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    hp = hific_amd.hyperprior.Hyperprior(bottleneck_capacity=24, hyperlatent_filters=32).to(dev).eval()
+    hp.build_tables()
+    y = (O.make_noise(3, (1, 24, 16, 16)) * 3).to(dev)
+    out = hp.compress_forward(y, (256, 256))
+    path = str(tmp_path / "gpu.hfc")
+    container.save_compressed_format(out, path)
+    y_hat = hp.decompress_forward(container.load_compressed_format(path), dev)
+    with torch.no_grad():
+        z_hat = torch.floor(hp.analysis_net(y) + 0.5)
+        mu = hp.synthesis_mu(z_hat)
+    torch.cuda.synchronize()
+    assert y_hat.shape == y.shape
+    assert torch.equal(y_hat.cpu(), (torch.floor(y + 0.5 - mu) + mu).cpu())
