@@ -197,7 +197,9 @@ def test_zz_hyperprior_compress_roundtrip(hific, dev, tmp_path):
     from hific_amd.compression import container
     hific.set_compute_dtype(torch.float32)
     torch.manual_seed(0)
-    hp = hific_amd.hyperprior.Hyperprior(bottleneck_capacity=24, hyperlatent_filters=32).to(dev).eval()
+    # scalar coder: lossless for any symbol (the vectorised default is lossy on multi-nibble overflows, like the reference)
+    hp = hific_amd.hyperprior.Hyperprior(bottleneck_capacity=24, hyperlatent_filters=32,
+                                         vectorize_encoding=False).to(dev).eval()
     hp.build_tables()
     y = (O.make_noise(3, (1, 24, 16, 16)) * 3).to(dev)
     out = hp.compress_forward(y, (256, 256))
