@@ -17,9 +17,15 @@ def built_lib():
     """Make sure libhific_hip.so exists (cross-compiles on CPU-only hosts)."""
     import __graft_entry__ as g
     so = os.path.join(g.PKG, "libhific_hip.so")
-    if not os.path.exists(so):
+    if not os.path.exists(so) or not os.path.exists(os.path.join(g.PKG, "libhific_host.so")):
         g.build()
     return so
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _libs_built(built_lib):
+    """Every test module may assume both shared libraries exist (fresh clones have neither: *.so is git-ignored)."""
+    return built_lib
 
 
 @pytest.fixture(scope="session")
