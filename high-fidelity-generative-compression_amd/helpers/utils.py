@@ -18,3 +18,16 @@ def get_scheduled_params(param, param_schedule, step_counter, ignore_schedule=Fa
 class Struct:
     def __init__(self, **entries):
         self.__dict__.update(entries)
+
+
+def pad_factor(input_image, spatial_dims, factor):
+    """Reflect-pad (N,C,H,W) at the bottom/right so that H and W are divisible by `factor`
+    (src/helpers/utils.py:50-62; used by Model.compress on the image and on the latents)."""
+    import torch.nn.functional as F
+    factor_H, factor_W = (factor, factor) if isinstance(factor, int) else factor
+    H, W = spatial_dims[0], spatial_dims[1]
+    pad_H = (factor_H - (H % factor_H)) % factor_H
+    pad_W = (factor_W - (W % factor_W)) % factor_W
+    if pad_H == 0 and pad_W == 0:
+        return input_image
+    return F.pad(input_image, pad=(0, pad_W, 0, pad_H), mode='reflect')

@@ -40,11 +40,11 @@ class Model(nn.Module):
         self.writeout = True
         if getattr(args, 'use_latent_mixture_model', False):
             raise NotImplementedError("DLMM variant is off by default (default_config.py:89) and out of scope")
-        if model_mode == ModelModes.EVALUATION:
-            raise NotImplementedError("EVALUATION mode drives the host rANS coder (out of scope this round)")
         self.image_dims = self.args.image_dims
         self.batch_size = self.args.batch_size
-        self.entropy_code = False
+        # EVALUATION mode (model.py:60-62): the Hyperprior carries the rANS tables (rebuild them with
+        # `model.Hyperprior.build_tables()` after loading a checkpoint, as compress.py:61 does)
+        self.entropy_code = model_mode == ModelModes.EVALUATION
 
         self.Encoder = encoder.Encoder(self.image_dims, self.batch_size, C=self.args.latent_channels,
                                        channel_norm=self.args.use_channel_norm)
@@ -90,6 +90,33 @@ class Model(nn.Module):
             raise NotImplementedError("normalize_input_image=True (tanh output) is off in the reference defaults")
         intermediates = Intermediates(x, reconstruction, lat_disc, hyperinfo.total_nbpp, hyperinfo.total_qbpp)
         return intermediates, hyperinfo
+
+    # ---- EVALUATION path (model.py:262-344); GPU wiring not yet run on a device, see DESIGN.md section 7 ----------
+    def compress(self, x, silent=True):
+        """x -> Encoder -> latents -> Hyperprior.compress_forward: CompressionOutput for `container.save_compressed_format`."""
+        from .helpers import utils
+        assert self.model_mode == ModelModes.EVALUATION and (self.training is False), \
+            f'Set model mode to {ModelModes.EVALUATION} for compression.'
+        spatial_shape = tuple(x.size()[2:])
+        with torch.no_grad():
+            x = utils.pad_factor(x, x.size()[2:], 2 ** self.Encoder.n_downsampling_layers)
+            y = self.Encoder(x.contiguous())
+            y = utils.pad_factor(y.float(), y.size()[2:], 2 ** self.Hyperprior.analysis_net.n_downsampling_layers)
+            return self.Hyperprior.compress_forward(y.contiguous(), spatial_shape)
+
+    def decompress(self, compression_output):
+        """CompressionOutput -> latents (host decode + synthesis nets) -> Generator -> crop to the image size, in [0,1]."""
+        assert self.model_mode == ModelModes.EVALUATION and (self.training is False), \
+            f'Set model mode to {ModelModes.EVALUATION} for decompression.'
+        device = next(self.Generator.parameters()).device
+        with torch.no_grad():
+            latents_decoded = self.Hyperprior.decompress_forward(compression_output, device=device)
+            reconstruction = self.Generator(latents_decoded.contiguous())
+            if self.args.normalize_input_image is True:
+                raise NotImplementedError("normalize_input_image=True (tanh output) is off in the reference defaults")
+            H, W = compression_output.spatial_shape
+            reconstruction = reconstruction[:, :, :H, :W]
+            return torch.clamp(reconstruction.float(), min=0., max=1.)
 
     def discriminator_forward(self, intermediates, train_generator):
         """Real/gen batch through D.  Reproduces the reference's pairing quirk: images are cat([real, gen]) while

@@ -212,3 +212,30 @@ def test_zz_hyperprior_compress_roundtrip(hific, dev, tmp_path):
     torch.cuda.synchronize()
     assert y_hat.shape == y.shape
     assert torch.equal(y_hat.cpu(), (torch.floor(y + 0.5 - mu) + mu).cpu())
+
+
+@pytest.mark.xfail(strict=False, reason="EVALUATION-path GPU wiring (Model.compress / decompress): first device run, see above")
+def test_zz_model_compress_decompress(hific, dev, tmp_path):
+    """Model.compress -> .hfc -> Model.decompress at a size that needs both paddings (image 72x88 -> 80x96, latents
+    5x6 -> 8x8): reconstruction has the image's size, lies in [0,1] and equals the Generator run on the decoded latents."""
+    import hific_amd
+    from hific_amd.compression import container
+    from hific_amd.default_config import make_args, mse_lpips_args, ModelTypes, ModelModes
+    hific.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    args = make_args(mse_lpips_args, n_residual_blocks=1)
+    model = hific_amd.Model(args, model_type=ModelTypes.COMPRESSION, model_mode=ModelModes.EVALUATION).to(dev).eval()
+    model.Hyperprior.vectorize_encoding = False
+    model.Hyperprior.build_tables()
+    x = O.make_image(9, 1, 72, 88).to(dev)
+    out = model.compress(x)
+    assert tuple(out.spatial_shape) == (72, 88)
+    path = str(tmp_path / "img.hfc")
+    container.save_compressed_format(out, path)
+    rec = model.decompress(container.load_compressed_format(path))
+    torch.cuda.synchronize()
+    assert tuple(rec.shape) == (1, 3, 72, 88) and float(rec.min()) >= 0.0 and float(rec.max()) <= 1.0
+    with torch.no_grad():
+        lat = model.Hyperprior.decompress_forward(out, device=dev)
+        ref = torch.clamp(model.Generator(lat)[:, :, :72, :88].float(), 0.0, 1.0)
+    assert torch.equal(rec.cpu(), ref.cpu())
