@@ -74,6 +74,17 @@ class CodingModel(nn.Module):
                                     self.likelihood_logistic)
 
 
+class _EntropyModelHandle:
+    """What the reference's driver touches on `Hyperprior.hyperprior_entropy_model` (compress.py:61,122:
+    `.build_tables()` after a checkpoint load): forwards to the owning module's host-side table construction."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def build_tables(self, **kwargs):
+        return self._owner.build_tables()
+
+
 class Hyperprior(CodingModel):
     def __init__(self, bottleneck_capacity=220, hyperlatent_filters=LARGE_HYPERLATENT_FILTERS, mode='large',
                  likelihood_type='gaussian', scale_lower_bound=MIN_SCALE, entropy_code=False,
@@ -100,6 +111,7 @@ class Hyperprior(CodingModel):
         self.block_encode = block_encode
         self._tables = None
         if entropy_code is True:
+            object.__setattr__(self, 'hyperprior_entropy_model', _EntropyModelHandle(self))   # not a sub-module
             self.build_tables()
 
     # ---- EVALUATION path (src/hyperprior.py:183-274) -----------------------------------------------------------
