@@ -4,15 +4,29 @@ set -e
 cd "$(dirname "$0")"
 OUT=../libhific_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
+SRCS="gconv elementwise norm entropy lpips capi"
 OBJS=""
-for f in gconv elementwise norm entropy lpips capi; do
+PIDS=""
+NAMES=""
+for f in $SRCS; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ gconv.h -nt $f.o ]; then
+    rm -f $f.o                                    # a failed compile must never leave a stale object to link
     hipcc $FLAGS -c $f.hip -o $f.o &
+    PIDS="$PIDS $!"
+    NAMES="$NAMES $f"
   fi
   OBJS="$OBJS $f.o"
 done
-wait
+# a bare `wait` always returns 0: collect every compile's status
+i=0
+for pid in $PIDS; do
+  i=$((i + 1))
+  if ! wait $pid; then
+    echo "hipcc failed on $(echo $NAMES | cut -d' ' -f$i).hip" >&2
+    exit 1
+  fi
+done
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
-# host-side (CPU) table construction for the EVALUATION path: plain g++, no device code
+# host-side (CPU) table construction + rANS coder for the EVALUATION path: plain g++, no device code
 g++ -O2 -std=c++17 -fPIC -shared -fno-fast-math host_tables.cpp host_rans.cpp -o ../libhific_host.so
 echo "built $OUT"
