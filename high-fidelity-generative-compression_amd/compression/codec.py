@@ -15,7 +15,14 @@ import numpy as np
 import torch
 
 from . import rans
-from .container import CompressionOutput
+
+# what `Hyperprior.compress_forward` returns (src/hyperprior.py:25-39): the 7 fields the container stores plus the
+# Shannon estimates that Model.compress / compress.py / save_compressed_format report (`.total_bpp` etc.).  The loader
+# (container.load_compressed_format) returns the reference's 7-field tuple of compression_utils.py:20-28.
+CompressionOutput = namedtuple("CompressionOutput",
+                               ["hyperlatents_encoded", "latents_encoded", "hyperlatent_spatial_shape", "batch_shape",
+                                "spatial_shape", "hyper_coding_shape", "latent_coding_shape", "hyperlatent_bits",
+                                "latent_bits", "total_bits", "hyperlatent_bpp", "latent_bpp", "total_bpp"])
 
 EntropyTables = namedtuple("EntropyTables", ["CDF", "CDF_offset", "CDF_length"])          # int32 tensors / arrays
 CodecNets = namedtuple("CodecNets", ["analysis", "synthesis_mu", "synthesis_std"])        # callables tensor -> tensor
@@ -33,9 +40,12 @@ def _tab(t):
 
 
 def compress_forward(latents, spatial_shape, nets, hyper_tables, prior_tables, scale_table, symbol_fns,
-                     vectorize=True, block_encode=True, precision=PRECISION, scale_lower_bound=SCALE_LOWER_BOUND):
-    """hyperprior.py:195-246 without the (reporting-only) entropy estimates.  Returns the 7-field
-    `CompressionOutput` that `container.save_compressed_format` writes."""
+                     vectorize=True, block_encode=True, precision=PRECISION, scale_lower_bound=SCALE_LOWER_BOUND,
+                     bits_fn=None):
+    """hyperprior.py:195-246.  Returns the reference's 13-field `CompressionOutput`.  `bits_fn(hyperlatents, latents,
+    means, scales) -> (hyperlatent_bits, latent_bits)` supplies the Shannon estimates of
+    `_estimate_compression_bits` (hyperprior_model.py:108-131, prior_model.py:122-145); without it the reporting
+    fields carry the ATTAINED sizes (32 bits per emitted rANS word)."""
     hyperlatents = nets.analysis(latents)
     hyper_hw = tuple(int(s) for s in hyperlatents.shape[2:])
     batch = int(latents.shape[0])
@@ -54,11 +64,19 @@ def compress_forward(latents, spatial_shape, nets, hyper_tables, prior_tables, s
     cdf, cl, co = _tab(prior_tables)
     lat_enc, latent_coding_shape = rans.ans_compress(sym, idx, cdf, cl, co, tuple(sym.shape[1:]), precision,
                                                      vectorize=vectorize, block_encode=block_encode)
+    if bits_fn is not None:
+        hyper_bits, latent_bits = (float(b) for b in bits_fn(hyperlatents, latents, means, scales))
+    else:
+        hyper_bits, latent_bits = 32.0 * len(hyp_enc), 32.0 * len(lat_enc)
+    n_pixels = float(np.prod([int(s) for s in spatial_shape]))
     return CompressionOutput(hyperlatents_encoded=hyp_enc, latents_encoded=lat_enc,
                              hyperlatent_spatial_shape=hyper_hw, batch_shape=batch,
                              spatial_shape=tuple(int(s) for s in spatial_shape),
                              hyper_coding_shape=tuple(int(s) for s in hyper_coding_shape),
-                             latent_coding_shape=tuple(int(s) for s in latent_coding_shape))
+                             latent_coding_shape=tuple(int(s) for s in latent_coding_shape),
+                             hyperlatent_bits=hyper_bits, latent_bits=latent_bits, total_bits=hyper_bits + latent_bits,
+                             hyperlatent_bpp=hyper_bits / n_pixels, latent_bpp=latent_bits / n_pixels,
+                             total_bpp=(hyper_bits + latent_bits) / n_pixels)
 
 
 def decompress_forward(compression_output, nets, hyper_tables, prior_tables, scale_table, symbol_fns, n_hyper_channels,

@@ -173,6 +173,25 @@ __global__ void bce_bwd_kernel(const float* __restrict__ z, float target, const 
         if (accumulate) dz[i] += v; else dz[i] = v;
     }
 }
+// ---- least-squares GAN term on the sigmoid output: mean over n of (sigmoid(z) - target)^2 ----------
+__global__ __launch_bounds__(256) void lsq_partial_kernel(const float* __restrict__ z, float target,
+                                                          float* __restrict__ part, long long n) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    EW_LOOP(i, n) { const float d = 1.f / (1.f + expf(-z[i])) - target; s += d * d; }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// dz (=|+=) g * 2 (s - target) s (1 - s) / n,  s = sigmoid(z)
+__global__ void lsq_bwd_kernel(const float* __restrict__ z, float target, const float* __restrict__ g,
+                               float* __restrict__ dz, long long n, float inv_n, int accumulate) {
+    const float gg = *g * 2.f * inv_n;
+    EW_LOOP(i, n) {
+        const float sg = 1.f / (1.f + expf(-z[i]));
+        const float v = gg * (sg - target) * sg * (1.f - sg);
+        if (accumulate) dz[i] += v; else dz[i] = v;
+    }
+}
 __global__ void sigmoid_kernel(const float* __restrict__ z, float* __restrict__ o, long long n) {
     EW_LOOP(i, n) o[i] = 1.f / (1.f + expf(-z[i]));
 }
@@ -406,6 +425,21 @@ int hific_bce_fwd(const float* z, float target, float* out, long long n, void* w
 int hific_bce_bwd(const float* z, float target, const float* g, float* dz, long long n, int accumulate,
                   hipStream_t st) {
     hipLaunchKernelGGL(bce_bwd_kernel, EW_GRID(n), dim3(256), 0, st, z, target, g, dz, n, 1.f / (float)n, accumulate);
+    return hific_launch_status();
+}
+// out[0] = mean (sigmoid(z) - target)^2 (losses.py:43-50 on D_real / D_gen = sigmoid(logits)); ws >= 256 floats
+int hific_lsq_sigmoid_fwd(const float* z, float target, float* out, long long n, void* ws, size_t ws_bytes,
+                          hipStream_t st) {
+    const int nb = 256;
+    if (ws_bytes < nb * sizeof(float)) return HIFIC_ERR_WS;
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(lsq_partial_kernel, dim3(nb), dim3(256), 0, st, z, target, part, n);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f / (float)n, out);
+    return hific_launch_status();
+}
+int hific_lsq_sigmoid_bwd(const float* z, float target, const float* g, float* dz, long long n, int accumulate,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(lsq_bwd_kernel, EW_GRID(n), dim3(256), 0, st, z, target, g, dz, n, 1.f / (float)n, accumulate);
     return hific_launch_status();
 }
 int hific_sigmoid_f32(const float* z, float* o, long long n, hipStream_t st) {

@@ -26,14 +26,14 @@ __global__ void lpips_prep_kernel(const void* __restrict__ src0, int s0_f32, con
         DT<T>::st(out + i, ((a * v + b) - shift[c]) / scale[c]);
     }
 }
-// dsrc1[j] = dout[half + j] * a / scale_c
+// dsrc1[j] = dgen[j] * a / scale_c      (dgen = gradient w.r.t. the pred half of the prepped batch, [B,3,HW])
 template <typename T, typename TO>
-__global__ void lpips_prep_bwd_kernel(const T* __restrict__ dout, TO* __restrict__ dsrc1, int B, int HW, float a) {
+__global__ void lpips_prep_bwd_kernel(const T* __restrict__ dgen, TO* __restrict__ dsrc1, int B, int HW, float a) {
     const float scale[3] = {.458f, .448f, .450f};
     const long long half = (long long)B * 3 * HW;
     EW_LOOP(j, half) {
         const int c = (int)((j / HW) % 3);
-        DT<TO>::st(dsrc1 + j, DT<T>::ld(dout + half + j) * a / scale[c]);
+        DT<TO>::st(dsrc1 + j, DT<T>::ld(dgen + j) * a / scale[c]);
     }
 }
 
@@ -181,7 +181,8 @@ int hific_lpips_prep(const void* src0, int s0_f32, const void* src1, int s1_f32,
     else return HIFIC_ERR_ARG;
     return hific_launch_status();
 }
-// dout: [2B,3,HW] dtype; dsrc1: [B,3,HW] (f32 when out_f32 else dtype)
+// dgen: [B,3,HW] dtype (gradient of the pred half only; the target half carries none); dsrc1: [B,3,HW]
+// (f32 when out_f32 else dtype)
 int hific_lpips_prep_bwd(const void* dout, void* dsrc1, int B, int HW, int normalize, int dtype, int out_f32,
                          hipStream_t st) {
     const float a = normalize ? 2.f : 1.f;

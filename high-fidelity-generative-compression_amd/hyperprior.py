@@ -141,15 +141,26 @@ class Hyperprior(CodingModel):
             prior_indices=lambda scales, tab: ops.prior_symbols_and_indices(scales, scales, scales, tab)[1])
         return nets, fns
 
+    def _shannon_bits(self, hyperlatents, latents, means, scales):
+        """`_estimate_compression_bits` of both entropy models (hyperprior_model.py:108-131, prior_model.py:122-145):
+        -sum log2(likelihood(quantised) + 1e-9), on the likelihood kernels of the training path."""
+        inv_q = 1.0 / -np.log(2.)
+        qz = ops.RoundFn.apply(hyperlatents.contiguous(), None)
+        hyper_bits = ops.LogSumFn.apply(self.hyperlatent_likelihood(qz).contiguous(), 1e-9, inv_q)
+        qy = ops.RoundFn.apply(latents.contiguous(), means.contiguous())
+        latent_bits = ops.LogSumFn.apply(self.latent_likelihood(qy, mean=means, scale=scales).contiguous(), 1e-9, inv_q)
+        return hyper_bits.item(), latent_bits.item()
+
     def compress_forward(self, latents, spatial_shape, **kwargs):
-        """hyperprior.py:195-246 (without the reporting-only entropy estimates): 7-field CompressionOutput."""
+        """hyperprior.py:195-246: the reference's 13-field CompressionOutput (entropy-coded words, shapes, Shannon
+        estimates)."""
         from .compression import codec
         nets, fns = self._codec_parts()
         hyp, prior, scale_table = self._tables
         with torch.no_grad():
             return codec.compress_forward(latents.float(), spatial_shape, nets, hyp, prior, scale_table, fns,
                                           vectorize=self.vectorize_encoding, block_encode=self.block_encode,
-                                          scale_lower_bound=self.scale_lower_bound)
+                                          scale_lower_bound=self.scale_lower_bound, bits_fn=self._shannon_bits)
 
     def decompress_forward(self, compression_output, device):
         """hyperprior.py:248-274: dequantised latents on `device`."""
@@ -189,6 +200,8 @@ class Hyperprior(CodingModel):
 
         latent_means = self.synthesis_mu(hd_mu)
         latent_scales = self.synthesis_std(hd_std)
+        if getattr(self, 'keep_debug', False):          # parity tests: symbols = round(decoded - means)
+            self.debug_latent_means = latent_means.detach().float().clone()
         latent_scales = lower_bound_toward(latent_scales, self.scale_lower_bound)
 
         mu_a, mu_b = ops.fork(latent_means)

@@ -45,6 +45,8 @@ SIGNATURES = {
     "hific_mse_bwd": (I, [P, P, P, P, L, F, I, P]),
     "hific_bce_fwd": (I, [P, F, P, L, P, Z, P]),
     "hific_bce_bwd": (I, [P, F, P, P, L, I, P]),
+    "hific_lsq_sigmoid_fwd": (I, [P, F, P, L, P, Z, P]),
+    "hific_lsq_sigmoid_bwd": (I, [P, F, P, P, L, I, P]),
     "hific_sigmoid_f32": (I, [P, P, L, P]),
     "hific_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "hific_upcat_bwd": (I, [P, P, I, I, P, I, I, I, I, I, I, I, P]),

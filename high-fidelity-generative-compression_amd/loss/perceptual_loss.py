@@ -131,9 +131,7 @@ class LpipsFn(Function):
                 grad = din
         # grad is now d/d(prepped gen image) -> d/d pred
         dpred = torch.empty(ctx.in_shape, dtype=ctx.pred_dtype, device=g.device)
-        # lpips_prep_bwd reads the [2B,...] layout: pass a pointer such that (ptr + half) lands on `grad`
-        half_bytes = grad.numel() * grad.element_size()
-        call("hific_lpips_prep_bwd", grad.data_ptr() - half_bytes, ptr(dpred), B, ctx.in_shape[2] * ctx.in_shape[3],
+        call("hific_lpips_prep_bwd", ptr(grad), ptr(dpred), B, ctx.in_shape[2] * ctx.in_shape[3],
              ctx.normalize, cd, 1 if ctx.pred_dtype == torch.float32 else 0, stream())
         return (dpred, None, None, None) + (None,) * len(wb)
 
@@ -143,7 +141,12 @@ class PerceptualLoss(nn.Module):
     registered: they never appear in a HiFIC state_dict, but they follow `.to()/.cuda()` of the owning model."""
 
     def __init__(self, model='net-lin', net='alex', colorspace='rgb', spatial=False, use_gpu=True, gpu_ids=[0],
-                 version='0.1', backbone_seed=1234):
+                 version='0.1', backbone_seed=1234, backbone_state_dict=None, backbone_path=None,
+                 allow_random_backbone=False):
+        """Backbone weights, in order of precedence: `backbone_state_dict` (torchvision alexnet keys), `backbone_path`
+        / $HIFIC_LPIPS_ALEX_WEIGHTS (a torch.save'd state_dict: torchvision's alexnet-owt-*.pth works as is).  With
+        neither, the backbone is a *seeded random* AlexNet - fine for benchmarks and parity tests
+        (`allow_random_backbone=True` says so explicitly), wrong for real training: a loud warning is issued."""
         super().__init__()
         if model != 'net-lin' or net != 'alex' or colorspace != 'rgb' or spatial or version != '0.1':
             raise NotImplementedError("hific_amd PerceptualLoss implements the configuration HiFIC uses: "
@@ -160,6 +163,25 @@ class PerceptualLoss(nn.Module):
         for i in range(5):
             t[f"lin{i}"] = torch.from_numpy(lin[f"lin{i}"].copy())
         object.__setattr__(self, "_t", t)          # plain dict: invisible to state_dict()/parameters()
+        backbone_path = backbone_path or os.environ.get("HIFIC_LPIPS_ALEX_WEIGHTS")
+        self.backbone_source = "seeded-random"
+        if backbone_state_dict is None and backbone_path:
+            backbone_state_dict = torch.load(backbone_path, map_location="cpu")
+            self.backbone_source = backbone_path
+        elif backbone_state_dict is not None:
+            self.backbone_source = "state_dict"
+        if backbone_state_dict is not None:
+            self.load_backbone_state_dict(backbone_state_dict)
+        elif not allow_random_backbone:
+            import logging
+            import warnings
+            msg = ("hific_amd PerceptualLoss: NO pretrained AlexNet weights given - the LPIPS backbone is a seeded "
+                   "RANDOM network (the reference downloads torchvision's ImageNet AlexNet, pretrained_networks.py:59). "
+                   "Training against it optimises a meaningless perceptual term. Pass backbone_path= / "
+                   "backbone_state_dict=, set $HIFIC_LPIPS_ALEX_WEIGHTS, or call load_backbone_state_dict(); "
+                   "allow_random_backbone=True silences this for benchmarks and tests.")
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
+            logging.getLogger("hific_amd").warning(msg)
         if use_gpu and torch.cuda.is_available():
             dev = torch.device("cuda", gpu_ids[0] if gpu_ids else 0)
             for k in t:
@@ -178,6 +200,7 @@ class PerceptualLoss(nn.Module):
 
     def load_backbone_state_dict(self, sd):
         """Accepts torchvision alexnet keys (`features.N.weight`) or bare `N.weight`."""
+        self.backbone_source = "state_dict"
         with torch.no_grad():
             for idx in ALEX_FEATURE_IDX:
                 for nm in ("weight", "bias"):

@@ -28,6 +28,20 @@ def get_compute_dtype():
     return _compute_dtype
 
 
+# Bumped by every in-place parameter update that bypasses torch's version counters (optim.FusedAdam writes the
+# arena with a raw kernel): cached derived data (packed bf16 weights) is keyed on it.
+_weights_epoch = 0
+
+
+def note_weights_changed():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def weights_epoch():
+    return _weights_epoch
+
+
 def _cd():
     return HIFIC_F32 if _compute_dtype == torch.float32 else HIFIC_BF16
 
@@ -509,6 +523,28 @@ class BCELogitsFn(Function):
         g = g.contiguous().float()
         dz = torch.empty_like(z)
         call("hific_bce_bwd", ptr(z), ctx.target, ptr(g), ptr(dz), z.numel(), 0, stream())
+        return dz, None
+
+
+class LsqSigmoidFn(Function):
+    """mean((sigmoid(z) - target)^2): the least-squares GAN term on the Discriminator's sigmoid output."""
+
+    @staticmethod
+    def forward(ctx, z, target):
+        require_gpu(z)
+        out = torch.empty((), dtype=torch.float32, device=z.device)
+        wsp, wsb = _ws(z)
+        call("hific_lsq_sigmoid_fwd", ptr(z), float(target), ptr(out), z.numel(), wsp, wsb, stream())
+        ctx.target = float(target)
+        ctx.save_for_backward(z)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        dz = torch.empty_like(z)
+        call("hific_lsq_sigmoid_bwd", ptr(z), ctx.target, ptr(g), ptr(dz), z.numel(), 0, stream())
         return dz, None
 
 

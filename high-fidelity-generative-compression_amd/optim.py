@@ -73,6 +73,56 @@ class ParamArena:
         o = self.offsets[i]
         return o, self.params[i].numel()
 
+    def rebind(self):
+        """Re-establishes the aliasing `p.data` / `p.grad` -> arena slices for parameters that were re-pointed
+        behind the arena's back (any nn.Module._apply: model.cpu() / .to(device) / .float(), as the reference's
+        save_model does every epoch, utils.py:116-145).  The parameter's current values win (they are what the user
+        sees, e.g. after load_state_dict on a moved model).  Returns the number of parameters that had strayed;
+        raises if one now lives on another device."""
+        base, gbase = self.flat.data_ptr(), self.flat_grad.data_ptr()
+        strayed = 0
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                n = p.numel()
+                want = base + 4 * o
+                grad_ok = p.grad is not None and p.grad.data_ptr() == gbase + 4 * o
+                if p.data_ptr() == want and grad_ok:
+                    continue
+                if p.device != self.flat.device:
+                    raise RuntimeError(
+                        f"ParamArena: parameter {i} {tuple(p.shape)} now lives on {p.device}, the arena on "
+                        f"{self.flat.device}; move the model back before optimizer.step() (its weights would "
+                        f"otherwise stay frozen copies)")
+                if p.data_ptr() != want:
+                    self.flat[o:o + n].copy_(p.data.reshape(-1).to(torch.float32))
+                    p.data = self.flat[o:o + n].view(p.shape)
+                    strayed += 1
+                if not grad_ok:
+                    # _apply re-points `p.grad.data` IN PLACE, i.e. the slot's own view object: make a new one
+                    gview = self.flat_grad[o:o + n].view(p.shape)
+                    self.slots[i].grad = gview
+                    p.grad = gview
+                    self.slots[i].fresh = True          # whatever the detached .grad held is not in the slot
+        return strayed
+
+    def zero_unwritten(self):
+        """Zeroes the slots that received no gradient since zero_grad() (they still hold an older step's values):
+        the optimizer then sees a zero gradient for them, like the reference's opt.zero_grad() (torch 1.6: grads are
+        zeroed, not dropped) followed by a backward that does not reach the parameter."""
+        lo = hi = None
+        for s, o in zip(self.slots, self.offsets):
+            if not s.fresh:
+                continue
+            n = (s.grad.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if hi == o:
+                hi = o + n
+            else:
+                if lo is not None:
+                    self.flat_grad[lo:hi].zero_()
+                lo, hi = o, o + n
+        if lo is not None:
+            self.flat_grad[lo:hi].zero_()
+
 
 class FusedAdam:
     """torch.optim.Adam semantics (amsgrad=False, weight_decay=0) over one ParamArena."""
@@ -84,13 +134,54 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(self.arena.flat)
         self.step_count = 0
         self.grad_scale = 1.0
-        self.param_groups = [dict(lr=lr, params=self.arena.params)]
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False,
+                                  params=self.arena.params)]
 
     def step(self):
+        self.arena.rebind()
+        self.arena.zero_unwritten()
         self.step_count += 1
+        g = self.param_groups[0]
         ops.adam_step(self.arena.flat, self.arena.flat_grad, self.exp_avg, self.exp_avg_sq,
-                      self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps, self.step_count,
-                      self.grad_scale)
+                      g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count, self.grad_scale)
+        ops.note_weights_changed()
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
+
+    # ---- checkpointing in torch.optim.Adam's own format (the reference saves `*_optimizer_state_dict`, -------------
+    # ---- utils.py:131-137, and restores them in load_model, utils.py:191-197) ---------------------------------------
+    def state_dict(self):
+        state = {}
+        if self.step_count > 0:
+            for i, p in enumerate(self.arena.params):
+                o, n = self.arena.slice_of(i)
+                state[i] = dict(step=torch.tensor(float(self.step_count)),
+                                exp_avg=self.exp_avg[o:o + n].view(p.shape).clone(),
+                                exp_avg_sq=self.exp_avg_sq[o:o + n].view(p.shape).clone())
+        g = self.param_groups[0]
+        group = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=0, amsgrad=False,
+                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(self.arena.params))))
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.arena.params):
+            raise ValueError("optimizer state_dict does not match this parameter group")
+        if groups[0].get("weight_decay", 0) or groups[0].get("amsgrad", False):
+            raise ValueError("FusedAdam implements torch.optim.Adam with weight_decay=0, amsgrad=False")
+        g = self.param_groups[0]
+        g["lr"], g["betas"], g["eps"] = groups[0]["lr"], tuple(groups[0]["betas"]), groups[0]["eps"]
+        steps = set()
+        with torch.no_grad():
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            for k, st in sd["state"].items():
+                i = int(k)
+                o, n = self.arena.slice_of(i)
+                self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdam keeps one step count per group; the state_dict holds several: %s" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0

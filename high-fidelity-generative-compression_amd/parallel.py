@@ -2,34 +2,47 @@
 bucketed all-reduces that overlap the remaining backward.
 
 The reference has no multi-GPU path (train.py:303-308 raises NotImplementedError), so there is no call pattern to
-mirror; the only semantics to keep is "gradient = mean over the global batch" (every loss is a batch mean).
+mirror; the only semantics to keep is "gradient = mean over the global batch" (every loss is a batch mean) and one
+rate-penalty branch for the whole job (`allreduce_scalar_mean`, used by loss/losses.py:weighted_rate_loss).
 
 Design for xGMI (7 point-to-point links per GPU, no switch): the gradient of a ParamArena is already one flat
 float32 tensor, so a bucket is a contiguous slice (no flatten/copy); buckets are sealed in *reverse* arena order,
 which is the order backward produces them, and each sealed bucket is handed to RCCL (`torch.distributed`, backend
 "nccl" == RCCL on ROCm) as an async all-reduce on RCCL's own stream while the compute stream keeps running the
 rest of backward.  Bucket size defaults to ~32 MiB: the 960x960x3x3 residual-block weights are 33 MB each, so a
-bucket is about one such tensor — large enough for RCCL to spread over all links, small enough that the first
+bucket is about one such tensor - large enough for RCCL to spread over all links, small enough that the first
 all-reduce starts after ~1/18 of the residual stack's backward.  The division by world size is folded into the
 fused Adam kernel (grad_scale).
+
+Sealing rule: a bucket is sealed when every one of its slots has received its *expected number of writes* for this
+backward (1 unless registered otherwise through `expected_writes`: a module applied twice per forward, such as
+HyperpriorDensity when both of its likelihood evaluations are in the loss, writes its slots twice).  A write that
+arrives after its bucket has been reduced cannot be repaired (the other ranks' contributions are already mixed in):
+it raises instead of training on a silently wrong gradient.  Arenas whose write pattern is not fixed (the
+Discriminator's slots are written by the G-turn and the D-turn of one optimizer step) use eager=False: everything is
+reduced in finish().
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class BucketedGradReducer:
-    def __init__(self, arena, bucket_mbytes=32, process_group=None, eager=True):
+    def __init__(self, arena, bucket_mbytes=32, process_group=None, eager=True, expected_writes=None):
+        """expected_writes: {parameter or slot index: writes per backward} for slots written more than once."""
         self.arena = arena
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         cap = int(bucket_mbytes * (1 << 20) / 4)
+        nslots = len(arena.slots)
         # contiguous slot ranges, built from the END of the arena (backward order)
         self.buckets = []          # (lo_elem, hi_elem, n_slots)
-        self.slot_bucket = [0] * len(arena.slots)
-        hi_slot = len(arena.slots)
+        self.slot_bucket = [0] * nslots
+        hi_slot = nslots
         while hi_slot > 0:
             lo_slot = hi_slot - 1
-            hi_elem = arena.numel if hi_slot == len(arena.slots) else arena.offsets[hi_slot]
+            hi_elem = arena.numel if hi_slot == nslots else arena.offsets[hi_slot]
             while lo_slot > 0 and hi_elem - arena.offsets[lo_slot - 1] <= cap:
                 lo_slot -= 1
             b = len(self.buckets)
@@ -37,14 +50,23 @@ class BucketedGradReducer:
                 self.slot_bucket[i] = b
             self.buckets.append((arena.offsets[lo_slot], hi_elem, hi_slot - lo_slot))
             hi_slot = lo_slot
-        self.pending = [0] * len(self.buckets)
-        self.launched = [False] * len(self.buckets)
+        self.expected = [1] * nslots
+        if expected_writes:
+            index_of = {id(p): i for i, p in enumerate(arena.params)}
+            for key, n in expected_writes.items():
+                i = key if isinstance(key, int) else index_of[id(key)]
+                self.expected[i] = int(n)
         self.works = []
-        # eager=False: reduce everything in finish() (used for the Discriminator arena, whose slots are written by
-        # two backward passes per optimizer step)
-        self.active = self.world > 1 or (dist.is_initialized() and __import__('os').environ.get('HIFIC_FORCE_DIST') == '1')
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('HIFIC_FORCE_DIST') == '1')
+        self.eager = bool(eager)
+        self._reset()
         if self.active and eager:
             arena.on_write = self._on_write
+
+    def _reset(self):
+        self.count = [0] * len(self.expected)
+        self.remaining = [b[2] for b in self.buckets]      # slots of each bucket still short of their write count
+        self.launched = [False] * len(self.buckets)
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
@@ -53,14 +75,23 @@ class BucketedGradReducer:
                                           async_op=True))
 
     def _on_write(self, slot):
-        b = self.slot_bucket[slot.index]
-        self.pending[b] += 1
-        if self.pending[b] == self.buckets[b][2] and not self.launched[b]:
-            self._launch(b)
+        i = slot.index
+        b = self.slot_bucket[i]
+        if self.launched[b]:
+            raise RuntimeError(
+                f"gradient slot {i} ({tuple(self.arena.params[i].shape)}) was written after its bucket had been "
+                f"all-reduced: it receives more than {self.expected[i]} write(s) per backward. Register the count with "
+                f"BucketedGradReducer(..., expected_writes={{param: n}}) or use eager=False for this arena.")
+        self.count[i] += 1
+        if self.count[i] == self.expected[i]:
+            self.remaining[b] -= 1
+            if self.remaining[b] == 0:
+                self._launch(b)
 
     def finish(self):
-        """Launch whatever is not sealed yet (parameters that received no gradient this turn), wait for all
-        collectives on the current stream, reset for the next backward.  Returns the gradient scale 1/world."""
+        """Launch whatever is not sealed yet (parameters that received fewer writes than expected this turn, or a
+        deferred arena), wait for all collectives on the current stream, reset for the next backward.  Returns the
+        gradient scale 1/world."""
         if self.active:
             for b in range(len(self.buckets)):
                 if not self.launched[b]:
@@ -68,14 +99,13 @@ class BucketedGradReducer:
             for w in self.works:
                 w.wait()
         self.works = []
-        self.pending = [0] * len(self.buckets)
-        self.launched = [False] * len(self.buckets)
+        self._reset()
         return 1.0 / self.world
 
 
 def allreduce_scalar_mean(t, process_group=None):
-    """Global-batch mean of a 0-d loss term (used for the rate-penalty branch so every rank picks the same lambda,
-    SURVEY §8e)."""
+    """Global-batch mean of a 0-d loss term (the rate-penalty branch: every rank must pick the same lambda,
+    SURVEY section 8e).  Identity when torch.distributed is not initialised or the world has one rank."""
     if dist.is_initialized() and dist.get_world_size(process_group) > 1:
         t = t.detach().clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)

@@ -108,6 +108,12 @@ int hific_bce_fwd(const float* z, float target, float* out, long long n, void* w
                   hipStream_t stream);
 int hific_bce_bwd(const float* z, float target, const float* g, float* dz, long long n, int accumulate,
                   hipStream_t stream);
+/* least-squares GAN loss on the sigmoid output, src/loss/losses.py:43-50 (`D_real`, `D_gen` = sigmoid(logits),
+   src/network/discriminator.py:84-85): out[0] = mean (sigmoid(z) - target)^2 and its gradient w.r.t. the logits */
+int hific_lsq_sigmoid_fwd(const float* z, float target, float* out, long long n, void* ws, size_t ws_bytes,
+                          hipStream_t stream);
+int hific_lsq_sigmoid_bwd(const float* z, float target, const float* g, float* dz, long long n, int accumulate,
+                          hipStream_t stream);
 int hific_sigmoid_f32(const float* z, float* o, long long n, hipStream_t stream);   /* discriminator.py:84 */
 /* torch.cat((x, nn.Upsample(16,'nearest')(y)), 1): src/network/discriminator.py:36,75-77 */
 int hific_upcat_fwd(const void* img, const void* ctx, void* out, int N, int Ci, int Cc, int H, int W, int f,
@@ -159,7 +165,7 @@ int hific_factorized_lik_bwd(const float* x, const float* const* params, const f
 /* ---- LPIPS taps (csrc/lpips.hip) — perceptual_loss.py:36-46, networks_basic.py:61-108 ------------------------- */
 int hific_lpips_prep(const void* src0, int s0_f32, const void* src1, int s1_f32, void* out, int B, int HW,
                      int normalize, int dtype, hipStream_t stream);
-int hific_lpips_prep_bwd(const void* dout, void* dsrc1, int B, int HW, int normalize, int dtype, int out_f32,
+int hific_lpips_prep_bwd(const void* dgen /* [B,3,HW]: pred half only */, void* dsrc1, int B, int HW, int normalize, int dtype, int out_f32,
                          hipStream_t stream);
 int hific_lpips_tap_fwd(const void* f, const float* w, float* val, int B, int C, int HW, int accumulate, int dtype,
                         void* ws, size_t ws_bytes, hipStream_t stream);

@@ -47,6 +47,79 @@ def _worker(rank, world, port, eager, q):
         dist.destroy_process_group()
 
 
+def _worker_multiwrite(rank, world, port, q):
+    """A training-step-shaped write pattern: parameter 1 is written TWICE per backward (a module applied twice per
+    forward, e.g. HyperpriorDensity with both likelihood evaluations in the loss).  With its expected write count
+    registered the bucket is reduced only after the second accumulation; unregistered, the second write is refused
+    loudly instead of racing the in-flight all-reduce."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hific_amd import optim, parallel
+        ps = [torch.nn.Parameter(torch.zeros(n)) for n in (300, 70000, 5, 130000)]
+        arena = optim.ParamArena(ps)
+        red = parallel.BucketedGradReducer(arena, bucket_mbytes=0.25, eager=True, expected_writes={ps[1]: 2})
+
+        def write(i, val):
+            s = ps[i]._hific_slot
+            if s.take():
+                s.grad.add_(val)
+            else:
+                s.grad.fill_(val)
+            s.written()
+
+        for it in range(2):
+            write(3, 1.0 + rank)
+            write(1, 10.0 * (rank + 1))          # first use of the shared module
+            assert not red.launched[red.slot_bucket[1]], "bucket sealed before the slot's last write"
+            write(2, 2.0)
+            write(1, 5.0)                         # second use: accumulates, THEN the bucket may go
+            write(0, float(it))
+            assert red.finish() == 0.5
+            assert torch.allclose(ps[1].grad, torch.full_like(ps[1].grad, 10.0 * 3 + 5.0 * 2))
+            assert torch.allclose(ps[3].grad, torch.full_like(ps[3].grad, 3.0))
+            assert torch.allclose(ps[2].grad, torch.full_like(ps[2].grad, 4.0))
+            arena.zero_grad()
+        # the same pattern WITHOUT the registration must fail loudly on the late write
+        red2 = parallel.BucketedGradReducer(arena, bucket_mbytes=0.25, eager=True)
+        write(3, 1.0); write(1, 1.0)
+        try:
+            write(1, 1.0)
+            q.put((rank, "late write was accepted")); return
+        except RuntimeError as e:
+            assert "expected_writes" in str(e)
+        red2.finish()
+        # global-batch rate branch: both ranks pick the same lambda from the mean q_bpp
+        from hific_amd.loss import losses
+        from hific_amd.default_config import make_args, mse_lpips_args
+        a = make_args(mse_lpips_args)
+        target = a.target_rate * a.target_schedule["vals"][0]
+        qbpp = torch.tensor(target + (0.3 if rank == 0 else -0.1))       # rank 0 above, rank 1 below, mean above
+        _, pen = losses.weighted_rate_loss(a, torch.tensor(1.0), qbpp, step_counter=1)
+        _, pen_dev = losses.weighted_rate_loss(a, torch.tensor(1.0), qbpp, step_counter=1, device_select=True)
+        assert pen == a.lambda_A * a.lambda_schedule["vals"][0] and float(pen_dev) == pen, (pen, float(pen_dev))
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multiwrite_slots_and_global_rate_branch_world2(hific):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_worker_multiwrite, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
+
+
 @pytest.mark.parametrize("eager", [True, False])
 def test_bucketed_allreduce_world2(hific, eager):
     ctx = mp.get_context("spawn")

@@ -57,6 +57,7 @@ def _one_step(hific, dev, dt, seed):
     hific.set_compute_dtype(dt)
     torch.manual_seed(seed)
     model = hific_amd.Model(make_args(mse_lpips_args, batch_size=16), model_type=ModelTypes.COMPRESSION,
+                            allow_random_lpips_backbone=True,
                             device_rate_select=True).to(dev).train()
     amort = optim.FusedAdam([p for m in model.amortization_models for p in m.parameters()], lr=1e-4)
     hyper = optim.FusedAdam(list(model.Hyperprior.hyperlatent_likelihood.parameters()), lr=1e-4)

@@ -89,10 +89,17 @@ def test_hyperprior_fp32(hific, dev, sd, training):
     for f in ("latent_nbpp", "hyperlatent_nbpp", "total_nbpp", "latent_qbpp", "hyperlatent_qbpp", "total_qbpp"):
         a, b = float(getattr(h, f)), float(getattr(hr, f))
         assert abs(a - b) < 1e-3 * abs(b), (f, a, b)
-    # bit-exact quantised indices
-    idx_h = torch.floor(h.decoded.detach().cpu() - hr.latent_means.detach() + 0.5)
-    assert torch.equal(O.quantized_indices(y, hr.latent_means.detach()),
-                       idx_h.to(torch.int64)) or _relerr(h.decoded.detach().cpu(), hr.decoded.detach()) < 1e-5
+    # quantised indices: exact, except where the oracle's own y - mu sits within f32 noise of a rounding tie
+    # (decoded = index + mu, so round(decoded - mu_oracle) recovers the HIP path's index)
+    idx_o = O.quantized_indices(y, hr.latent_means.detach())
+    idx_h = torch.round(h.decoded.detach().cpu() - hr.latent_means.detach()).to(torch.int64)
+    flips = idx_h != idx_o
+    if flips.any():
+        frac = y - hr.latent_means.detach() + 0.5
+        frac = frac - torch.floor(frac)
+        tie = torch.minimum(frac, 1 - frac)
+        assert int(flips.sum()) <= 2 and float(tie[flips].max()) < 1e-4, (int(flips.sum()), float(tie[flips].max()))
+        assert int(((idx_h - idx_o).abs() > 1).sum()) == 0
     assert _relerr(yd.grad.cpu(), yr.grad) < 1e-2
     params = dict(hp.named_parameters())
     for k in ("analysis_net.conv1.weight", "synthesis_mu.conv2.weight", "synthesis_std.conv3.bias",
@@ -133,7 +140,8 @@ def test_model_losses_and_grads_fp32(hific, dev, sd, gan):
     from hific_amd.default_config import make_args, mse_lpips_args, hific_args, ModelTypes
     hific.set_compute_dtype(torch.float32)
     args = make_args(hific_args if gan else mse_lpips_args, n_residual_blocks=N_RES)
-    model = hific_amd.Model(args, model_type=ModelTypes.COMPRESSION_GAN if gan else ModelTypes.COMPRESSION)
+    model = hific_amd.Model(args, model_type=ModelTypes.COMPRESSION_GAN if gan else ModelTypes.COMPRESSION,
+                            allow_random_lpips_backbone=True)
     model.load_state_dict({k: v for k, v in sd.items() if gan or not k.startswith("Discriminator.")}, strict=True)
     bb = O.make_alex_backbone()
     model.perceptual_loss.load_backbone_state_dict(bb)
@@ -187,9 +195,6 @@ def test_model_losses_and_grads_fp32(hific, dev, sd, gan):
         assert _relerr(params[k].grad.cpu(), sdr[k].grad) < 1e-2, k
 
 
-@pytest.mark.xfail(strict=False, reason="EVALUATION-path GPU wiring (Hyperprior.compress_forward / decompress_forward): "
-                                        "every piece is tested (tests/test_host_*.py, test_compress_symbols_*), the "
-                                        "composition on the device had no GPU minutes left in round 1 - first run here")
 def test_zz_hyperprior_compress_roundtrip(hific, dev, tmp_path):
     """compress_forward -> .hfc -> decompress_forward on the device modules: the decoder reproduces the latents
     quantised around the means that the (same) synthesis kernels predict from the decoded hyperlatents."""
@@ -214,7 +219,6 @@ def test_zz_hyperprior_compress_roundtrip(hific, dev, tmp_path):
     assert torch.equal(y_hat.cpu(), (torch.floor(y + 0.5 - mu) + mu).cpu())
 
 
-@pytest.mark.xfail(strict=False, reason="EVALUATION-path GPU wiring (Model.compress / decompress): first device run, see above")
 def test_zz_model_compress_decompress(hific, dev, tmp_path):
     """Model.compress -> .hfc -> Model.decompress at a size that needs both paddings (image 72x88 -> 80x96, latents
     5x6 -> 8x8): reconstruction has the image's size, lies in [0,1] and equals the Generator run on the decoded latents."""
@@ -224,12 +228,21 @@ def test_zz_model_compress_decompress(hific, dev, tmp_path):
     hific.set_compute_dtype(torch.float32)
     torch.manual_seed(0)
     args = make_args(mse_lpips_args, n_residual_blocks=1)
-    model = hific_amd.Model(args, model_type=ModelTypes.COMPRESSION, model_mode=ModelModes.EVALUATION).to(dev).eval()
+    model = hific_amd.Model(args, model_type=ModelTypes.COMPRESSION, model_mode=ModelModes.EVALUATION,
+                            allow_random_lpips_backbone=True).to(dev).eval()
     model.Hyperprior.vectorize_encoding = False
     model.Hyperprior.build_tables()
     x = O.make_image(9, 1, 72, 88).to(dev)
     out = model.compress(x)
     assert tuple(out.spatial_shape) == (72, 88)
+    # the reference's reporting fields (Shannon estimates from the likelihood kernels) next to the attained size
+    attained = 32.0 * (len(out.hyperlatents_encoded) + len(out.latents_encoded))
+    assert out.total_bits > 0 and abs(out.total_bpp - out.total_bits / (72 * 88)) < 1e-6
+    assert 0.3 < out.total_bits / attained < 3.0, (out.total_bits, attained)
+    # EVALUATION-mode forward (model.py:357-366): clamped reconstruction and the quantised rate
+    rec_f, q_bpp = model(x[:, :, :64, :80].contiguous())
+    assert tuple(rec_f.shape) == (1, 3, 64, 80) and float(rec_f.min()) >= 0.0 and float(rec_f.max()) <= 1.0
+    assert float(q_bpp) > 0
     path = str(tmp_path / "img.hfc")
     container.save_compressed_format(out, path)
     rec = model.decompress(container.load_compressed_format(path))

@@ -8,7 +8,7 @@ from oracle import hific_oracle as O
 
 def test_state_dict_schema_matches_reference_layout(hific):
     from hific_amd.default_config import make_args, hific_args, ModelTypes
-    m = hific.Model(make_args(hific_args), model_type=ModelTypes.COMPRESSION_GAN)
+    m = hific.Model(make_args(hific_args), model_type=ModelTypes.COMPRESSION_GAN, allow_random_lpips_backbone=True)
     sd = m.state_dict()
     want = {k: tuple(s) for k, s, _ in O._shapes(gan=True)}
     assert set(sd) == set(want) and len(sd) == 168
@@ -120,3 +120,50 @@ def test_injection_into_reference_model(hific):
                         "src.model"):
             if modname in sys.modules:
                 importlib.reload(sys.modules[modname])
+
+
+def test_param_arena_rebind_zero_unwritten_and_adam_state_dict(hific):
+    """optim.ParamArena survives nn.Module._apply (the reference's save_model does model.cpu() -> .to(device) every
+    epoch), does not feed stale gradients to the optimizer, and FusedAdam checkpoints in torch.optim.Adam's format."""
+    import torch
+    from hific_amd import optim
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    params = list(lin.parameters())
+    opt = optim.FusedAdam(params, lr=1e-3)
+    arena = opt.arena
+    assert arena.rebind() == 0
+    before = [p.detach().clone() for p in params]
+    lin.double().float()                                  # any _apply re-points .data (and .grad) away from the arena
+    assert any(p.data_ptr() != arena.flat.data_ptr() + 4 * o for p, o in zip(params, arena.offsets))
+    with torch.no_grad():
+        params[0].add_(1.0)                               # the user-visible tensor is the truth after a stray
+    assert arena.rebind() == len(params)
+    for p, o, b in zip(params, arena.offsets, before):
+        assert p.data_ptr() == arena.flat.data_ptr() + 4 * o and p.grad.data_ptr() == arena.flat_grad.data_ptr() + 4 * o
+    assert torch.equal(params[0], before[0] + 1.0) and torch.equal(params[1], before[1])
+    # stale gradients: only slot 2 is written this "backward"; the others must read as zero at step time
+    arena.flat_grad.fill_(7.0)
+    arena.zero_grad()
+    s = params[2]._hific_slot
+    assert s.take() == 0
+    s.grad.fill_(3.0)
+    arena.zero_unwritten()
+    assert float(params[2].grad.min()) == 3.0
+    for i in (0, 1, 3):
+        assert float(params[i].grad.abs().max()) == 0.0
+    # state_dict round trip through torch.optim.Adam's own loader
+    opt.step_count = 4
+    opt.exp_avg.copy_(torch.arange(arena.numel, dtype=torch.float32) * 1e-3)
+    opt.exp_avg_sq.copy_(torch.arange(arena.numel, dtype=torch.float32) * 1e-6)
+    sd = opt.state_dict()
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in params], lr=1.0)
+    ref.load_state_dict(sd)                               # torch accepts our format
+    assert ref.param_groups[0]["lr"] == 1e-3 and float(ref.state[ref.param_groups[0]["params"][1]]["step"]) == 4.0
+    opt2 = optim.FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in params], lr=5.0)
+    opt2.load_state_dict(ref.state_dict())                # and we accept torch's
+    assert opt2.step_count == 4 and opt2.param_groups[0]["lr"] == 1e-3
+    for i in range(len(params)):
+        o, n = arena.slice_of(i)
+        assert torch.equal(opt2.exp_avg[o:o + n], opt.exp_avg[o:o + n])
+        assert torch.equal(opt2.exp_avg_sq[o:o + n], opt.exp_avg_sq[o:o + n])
