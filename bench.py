@@ -1,30 +1,49 @@
 #!/usr/bin/env python
-"""HiFIC hot-path benchmark (contract: see the task brief / DESIGN.md §Measurement).
+"""HiFIC hot-path benchmark (contract: task brief / DESIGN.md section 5).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" = one training step of the HiFIC-low *compression* model (BASELINE.json configs[1]): forward
-(Encoder -> Hyperprior -> Generator -> MSE + LPIPS + rate) + backward + the two Adam updates (amortisation and
-hyperprior-density parameters, reference train.py:54-59), bf16 compute with f32 master weights, batch 16 of
-synthetic 256x256 RGB crops per GPU, random-init weights.  `--config gan` times configs[2] (G-turn + D-turn).
+N > 1 without a torch.distributed environment re-executes itself under `python -m torch.distributed.run` with N ranks
+(one per GPU, RCCL); when the driver launches the ranks itself (RANK / WORLD_SIZE set) it runs as that rank.
+
+Headline (`value`): BASELINE.json configs[2] - HiFIC-low *compression_gan* training, batch 16 of synthetic 256x256
+RGB crops per GPU, bf16 MFMA compute with float32 master weights.  A "step" is one G-D cycle as the reference's
+train loop runs it (train.py:119-141): G-turn (forward Encoder -> Hyperprior -> Generator -> MSE + LPIPS + rate + D,
+backward, Adam on the amortisation and hyperprior-density groups) on one batch, then D-turn (full forward, D loss,
+backward, Adam on the Discriminator) on the next batch: 2 x 16 images per step.
+
+The same JSON line also carries (N = 1 only, measured in the same process right after the headline):
+  * `compression`: configs[1], the no-GAN model's training step (16 images per step)
+  * `fwd_ms_per_image`: EVALUATION-mode forward (model.py:357-366: reconstruction + q_bpp, no losses), no-grad
+  * `roofline`: the dominant GEMM kernel FUNCTION of the headline step, timed live with HIP event pairs on the
+    launch stream (in-library profiler), algorithmic FLOPs on the op's real output domain, against the dense bf16
+    MFMA peak; `traffic` = HBM bytes per launch of that kernel from two rocprofv3 --pmc passes (FETCH_SIZE,
+    WRITE_SIZE) of a short child run of this script, or null
+  * `cpu_baseline`: the oracle (CPU restatement of the reference) on the host cores, bounded sample of the same
+    G-D cycle
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-# algorithmic work per image of the compression training step: 151.9 GMAC = 303.7 GFLOP
-FLOP_PER_IMAGE_COMPRESSION = 303.7e9
-MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic work per image, GMAC -> FLOP = 2 x
+GFLOP_PER_IMAGE = {
+    "compression": 303.7,            # training step of the no-GAN model: fwd 51.68 + bwd 100.18 GMAC
+    "forward": 103.4,                # 51.68 GMAC
+}
+GMAC_G_TURN, GMAC_D_TURN = 161.2, 62.8      # per image of the G-turn / D-turn batch (D weight-gradient quirk included)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def parse():
@@ -32,43 +51,50 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per turn")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--config", default="compression", choices=["compression", "gan"])
+    ap.add_argument("--config", default="gan", choices=["gan", "compression"], help="headline workload")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-extras", action="store_true", help="headline only (no compression/fwd/roofline legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--cpu-timeout", type=int, default=150)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-timeout", type=int, default=240)
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def build(args, dev):
+# ---------------------------------------------------------------------------------------------------------------
+def build(args, dev, config):
+    import torch
     import hific_amd
     from hific_amd import optim, parallel
     from hific_amd.default_config import make_args, mse_lpips_args, hific_args, ModelTypes
     hific_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    gan = args.config == "gan"
+    gan = config == "gan"
     torch.manual_seed(0)
     margs = make_args(hific_args if gan else mse_lpips_args, batch_size=args.batch,
                       image_dims=(3, args.size, args.size), latent_dims=(220, args.size // 16, args.size // 16))
     model = hific_amd.Model(margs, model_type=ModelTypes.COMPRESSION_GAN if gan else ModelTypes.COMPRESSION,
-                            device_rate_select=True)
+                            device_rate_select=True, allow_random_lpips_backbone=True)
     model = model.to(dev).train()
     # parameter groups exactly as train.py:287-301
-    amort = []
-    for m in model.amortization_models:
-        amort += list(m.parameters())
+    amort = [p for m in model.amortization_models for p in m.parameters()]
     hyper = list(model.Hyperprior.hyperlatent_likelihood.parameters())
     opts = {"amort": optim.FusedAdam(amort, lr=1e-4), "hyper": optim.FusedAdam(hyper, lr=1e-4)}
     if gan:
         opts["disc"] = optim.FusedAdam(list(model.Discriminator.parameters()), lr=1e-4)
-    reducers = {k: parallel.BucketedGradReducer(o.arena, eager=(k != "disc")) for k, o in opts.items()}
+    # amort: every slot is written exactly once per backward -> buckets go to RCCL as backward produces them;
+    # hyper (14 080 parameters, a module applied twice per forward) and disc (written by both turns): one
+    # all-reduce in finish()
+    reducers = {k: parallel.BucketedGradReducer(o.arena, eager=(k == "amort")) for k, o in opts.items()}
     return model, opts, reducers
 
 
-def make_step(args, model, opts, reducers, dev):
-    gan = args.config == "gan"
+def make_step(args, model, opts, reducers, dev, config):
+    import torch
+    gan = config == "gan"
     gen = torch.Generator(device=dev).manual_seed(1234 + int(os.environ.get("RANK", "0")))
     B, S = args.batch, args.size
 
@@ -87,8 +113,8 @@ def make_step(args, model, opts, reducers, dev):
         losses["compression"].backward()
         reduce_and_step(["amort", "hyper"])
         if gan:
-            # D-turn on a distinct batch (train.py:129-136); the D gradients deposited by the G-turn stay in the
-            # slots (reference quirk, SURVEY §3.2): disc.zero_grad() only runs after disc.step()
+            # D-turn on the next batch (train.py:129-136); the D gradients deposited by the G-turn stay in the
+            # slots (reference quirk, SURVEY section 3.2): disc.zero_grad() only runs after disc.step()
             losses = model(batch(), train_generator=False, writeout=False)
             losses["disc"].backward()
             reduce_and_step(["disc"])
@@ -98,50 +124,150 @@ def make_step(args, model, opts, reducers, dev):
     return step
 
 
-def _cpu_baseline_worker(size, B, steps, threads):
+def timed(step, steps, warmup, fence):
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return time.perf_counter() - t0
+
+
+def profile_kernels(step, nsteps):
+    """HIP-event pairs around every GEMM-class launch of `nsteps` further steps -> per kernel function totals."""
+    from hific_amd import lib
+    MAXK = 32
+    lib.call("hific_prof_begin")
+    for _ in range(nsteps):
+        step()
+    ms = (ctypes.c_double * MAXK)(); fl = (ctypes.c_double * MAXK)(); cnt = (ctypes.c_int * MAXK)()
+    names = ctypes.create_string_buffer(MAXK * 64)
+    nk = lib.raw("hific_prof_end")(MAXK, ms, fl, cnt, names)
+    if nk < 0:
+        raise RuntimeError(f"hific_prof_end failed ({nk})")
+    out = {}
+    for k in range(nk):
+        nm = names.raw[k * 64:(k + 1) * 64].split(b"\0", 1)[0].decode()
+        if cnt[k] > 0:
+            out[nm] = {"launches_per_step": cnt[k] / nsteps, "ms_per_step": ms[k] / nsteps,
+                       "avg_launch_us": ms[k] * 1e3 / cnt[k], "gflop_per_launch": fl[k] / cnt[k] / 1e9,
+                       "tflops": fl[k] / (ms[k] * 1e-3) / 1e12 if ms[k] > 0 else 0.0}
+    return out
+
+
+# ---- HBM traffic of one kernel function: rocprofv3 --pmc child runs ---------------------------------------------
+def _rocpd_counter(dbdir, counter, kernel_substr):
+    import sqlite3
+    tot, n = 0.0, 0
+    for db in glob.glob(os.path.join(dbdir, "**", "*.db"), recursive=True):
+        cur = sqlite3.connect(db).cursor()
+        try:
+            rows = cur.execute("select kernel_name, count(*), sum(value) from counters_collection "
+                               "where counter_name=? group by kernel_name", (counter,)).fetchall()
+        except Exception:
+            continue
+        for name, c, v in rows:
+            if kernel_substr in name:
+                tot += v; n += c
+    return (tot / n) if n else None
+
+
+def measure_traffic(args, kernel_name):
+    """Two separate counter passes (FETCH_SIZE / WRITE_SIZE cannot share one: TCC slots), each a short child run
+    of this script (1 warm-up + 1 step, headline only).  Units: KB; FETCH_SIZE counts 64 B per 128-B request of a
+    wide stream on gfx950 -> read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM section)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    sub = kernel_name.split("<")[0] if "gconv_kernel" not in kernel_name else "gconv_kernel"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hific_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+               "--traffic-child", "--steps", "1", "--warmup", "1", "--batch", str(args.batch), "--size", str(args.size),
+               "--config", args.config, "--dtype", args.dtype]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)
+            try:
+                p.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)
+                return None, f"{counter} pass timed out"
+            # exact template instance when it is unambiguous in the trace, else the function family
+            v = _rocpd_counter(d, counter, kernel_name) or _rocpd_counter(d, counter, sub)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        if v is None:
+            return None, f"{counter}: kernel not found in the counter database"
+        vals[counter] = v
+    rd, wr = 2.0 * vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
+    return {"bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "write_bytes": round(wr),
+            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KB x 1024, FETCH x 2 (gfx950)"}, None
+
+
+# ---- CPU baseline -----------------------------------------------------------------------------------------------
+def _cpu_baseline_worker(size, B, steps, threads, gan):
     """Runs in a child process (no GPU context): reference arithmetic (oracle restatement, torch CPU float32)."""
     import numpy as np
+    import torch
     from oracle import hific_oracle as O
     torch.set_num_threads(threads)
-    sd = {k: torch.nn.Parameter(v) for k, v in O.make_state_dict(seed=0, gan=False).items()}
+    sd = {k: (torch.nn.Parameter(v) if v.dtype.is_floating_point and "weight_u" not in k and "weight_v" not in k else v)
+          for k, v in O.make_state_dict(seed=0, gan=gan).items()}
     bb = O.make_alex_backbone()
     lpips_w = np.load(os.path.join(ROOT, "high-fidelity-generative-compression_amd", "loss", "weights",
                                    "lpips_alex_lin_v0.1.npz"))
     lins = [torch.from_numpy(lpips_w[f"lin{i}"].copy()) for i in range(5)]
     hyper_keys = [k for k in sd if "hyperlatent_likelihood" in k]
-    amort = torch.optim.Adam([v for k, v in sd.items() if k not in hyper_keys], lr=1e-4)
+    disc_keys = [k for k in sd if k.startswith("Discriminator.") and isinstance(sd[k], torch.nn.Parameter)]
+    amort_keys = [k for k in sd if isinstance(sd[k], torch.nn.Parameter) and k not in hyper_keys and k not in disc_keys]
+    amort = torch.optim.Adam([sd[k] for k in amort_keys], lr=1e-4)
     hyper = torch.optim.Adam([sd[k] for k in hyper_keys], lr=1e-4)
+    disc = torch.optim.Adam([sd[k] for k in disc_keys], lr=1e-4) if gan else None
     times = []
     for it in range(steps + 1):
-        x = O.make_image(100 + it, B, size, size)
+        xa, xb = O.make_image(100 + 2 * it, B, size, size), O.make_image(101 + 2 * it, B, size, size)
         t0 = time.time()
-        out = O.model_forward(sd, bb, lins, x, step_counter=it + 1, training=True, gan=False)
+        out = O.model_forward(sd, bb, lins, xa, step_counter=it + 1, training=True, gan=gan, train_generator=True)
         out["compression"].backward()
         amort.step(); hyper.step()
         amort.zero_grad(); hyper.zero_grad()
+        if gan:
+            for k, v in out["new_uv"].items():
+                sd[k] = v
+            out = O.model_forward(sd, bb, lins, xb, step_counter=it + 1, training=True, gan=True, train_generator=False)
+            out["disc"].backward()
+            disc.step(); disc.zero_grad(); amort.zero_grad(); hyper.zero_grad()
+            for k, v in out["new_uv"].items():
+                sd[k] = v
         times.append(time.time() - t0)
     t = sorted(times[1:])[len(times[1:]) // 2]
-    print(json.dumps({"images_per_s": B / t, "step_s": t}), flush=True)
+    print(json.dumps({"images_per_s": B * (2 if gan else 1) / t, "step_s": t}), flush=True)
 
 
 def cpu_baseline(args):
     """The oracle ("port" of the reference's CPU path) timed on this box's host cores on a bounded sample of the
-    same workload: compression training step (fwd + bwd + 2x Adam), batch `cpu_batch`, 1 warm-up + `cpu_steps`
-    timed steps, in a child process with a hard time limit so the GPU line can never be lost to it."""
-    import subprocess
+    headline workload, in a child process with a hard time limit so the GPU line can never be lost to it."""
     ncores = os.cpu_count() or 1
     threads = min(ncores, int(os.environ.get("HIFIC_CPU_THREADS", "32")))
+    gan = args.config == "gan"
     cmd = [sys.executable, "-c",
            f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
-           f"bench._cpu_baseline_worker({args.size}, {args.cpu_batch}, {args.cpu_steps}, {threads})"]
+           f"bench._cpu_baseline_worker({args.size}, {args.cpu_batch}, {args.cpu_steps}, {threads}, {gan})"]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
-    sample = (f"oracle (torch-CPU float32 restatement of the reference) compression train step, batch "
-              f"{args.cpu_batch}, {args.size}x{args.size}, 1 warm-up + {args.cpu_steps} timed steps (median), "
+    sample = (f"oracle (torch-CPU float32 restatement of the reference) "
+              f"{'compression_gan G-turn + D-turn cycle' if gan else 'compression training step'} (fwd + bwd + Adam), batch "
+              f"{args.cpu_batch} per turn, {args.size}x{args.size}, 1 warm-up + {args.cpu_steps} timed (median), "
               f"{threads} threads of {ncores} logical cores")
     try:
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_timeout)
-        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-        r = json.loads(line)
+        r = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
         return {"value": round(r["images_per_s"], 4), "unit": "images/s", "cores": threads, "kind": "port",
                 "sample": sample}
     except Exception as e:
@@ -149,24 +275,34 @@ def cpu_baseline(args):
                 "sample": sample + f" -- FAILED: {type(e).__name__}"}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+def respawn(args):
+    """`python bench.py --gpus N` from a plain shell: become N ranks under torch.distributed.run."""
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        respawn(args)
+    import torch
+    import torch.distributed as dist
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("HIFIC_FORCE_DIST") == "1"   # the latter: 1-rank RCCL smoke test
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-
-    from hific_amd import lib
-    model, opts, reducers = build(args, dev)
-    step = make_step(args, model, opts, reducers, dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def fence():
         torch.cuda.synchronize()
@@ -174,64 +310,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    cfg = args.config
+    model, opts, reducers = build(args, dev, cfg)
+    step = make_step(args, model, opts, reducers, dev, cfg)
+    if args.traffic_child:                       # counter pass of measure_traffic(): a few steps, nothing else
+        timed(step, args.steps, args.warmup, fence)
+        return
+    elapsed = timed(step, args.steps, args.warmup, fence)
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # live roofline of the dominant kernel: same steps again with HIP events around every GEMM-class launch
-    lib.call("hific_prof_begin")
-    for _ in range(max(1, min(args.steps, 4))):
-        step()
-    ms = (ctypes.c_double * 4)(); fl = (ctypes.c_double * 4)(); cnt = (ctypes.c_int * 4)()
-    lib.call("hific_prof_end", ms, fl, cnt)
-    kinds = ["gconv 128-row tiles (gconv_sp9_kernel<2> + gconv_kernel<..,2,2,2,2>)",
-             "gconv 64-row tiles (gconv_sp9_kernel<1> + gconv_kernel<..,2,2,1,2>)",
-             "gconv 32-row tiles (gconv_kernel<..,1,4,1,1>)",
-             "weight gradient (wgrad_pipe_kernel + wgrad_kernel + wgrad_im2col_kernel)"]
-    kinds_key = ["gconv128", "gconv64", "gconv32", "wgrad"]
-    per_kind = {kinds[i]: {"launches": cnt[i], "ms": round(ms[i], 3),
-                           "tflops": round(fl[i] / (ms[i] * 1e-3) / 1e12, 2) if ms[i] > 0 else 0.0}
-                for i in range(4) if cnt[i] > 0}
-    dom = max(range(4), key=lambda i: ms[i])
-    traffic = None
-    try:   # HBM bytes per launch of the dominant kernel class: rocprofv3 FETCH_SIZE(x2 on gfx950)+WRITE_SIZE, see profiles/
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get(kinds_key[dom])
-    except Exception:
-        traffic = None
-    achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
-    imgs_per_step = args.batch * (2 if args.config == "gan" else 1)
+    imgs_per_step = args.batch * (2 if cfg == "gan" else 1)
     value = world * imgs_per_step * args.steps / elapsed
+    ms_step = elapsed / args.steps * 1e3
+    tflop_step = (2 * (GMAC_G_TURN + GMAC_D_TURN) if cfg == "gan" else GFLOP_PER_IMAGE["compression"]) \
+        * args.batch * (args.size / 256.0) ** 2 / 1e3
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    what = ("compression_gan G-turn + D-turn cycle (2 batches)" if cfg == "gan" else "compression training step")
     out = {
         "metric": "training images/sec (256x256) HiFIC-low", "value": round(value, 3), "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"HiFIC-low {'compression_gan (G-turn + D-turn)' if args.config == 'gan' else 'compression'}"
-                               f" training step, batch {args.batch}/GPU, {args.size}x{args.size} RGB, {args.dtype} compute, "
-                               f"f32 master weights, fwd+bwd+Adam, random-init weights",
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": kinds[dom], "achieved": round(achieved, 2),
-                     "peak": MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                     "frac": round(achieved / (MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                     "avg_launch_us": round(ms[dom] * 1e3 / max(cnt[dom], 1), 2), "traffic": traffic,
-                     "per_kernel": per_kind,
-                     "step_model": {"algorithmic_tflop_per_step": round(FLOP_PER_IMAGE_COMPRESSION * args.batch / 1e12, 3),
-                                    "whole_step_tflops": round(FLOP_PER_IMAGE_COMPRESSION * args.batch /
-                                                               (elapsed / args.steps) / 1e12, 2)
-                                    if args.config == "compression" else None}},
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"HiFIC-low {what}, batch {args.batch}/GPU/turn, {args.size}x{args.size} RGB, "
+                               f"{args.dtype} MFMA compute, f32 master weights, fwd+bwd+Adam, random-init weights "
+                               f"(BASELINE configs[{2 if cfg == 'gan' else 1}])",
+                   "images_per_step": world * imgs_per_step, "global_batch": world * args.batch,
+                   "parallelism": f"dp{world}"},
+        "step_model": {"algorithmic_tflop_per_step_per_gpu": round(tflop_step, 3),
+                       "whole_step_tflops_per_gpu": round(tflop_step / (ms_step * 1e-3), 1),
+                       "whole_step_frac_of_mfma_peak": round(tflop_step / (ms_step * 1e-3) / peak, 4)},
     }
+    extras = world == 1 and not args.no_extras
+    if extras:
+        # ---- roofline of the dominant kernel function of the headline step (live HIP events) --------------------
+        prof = profile_kernels(step, max(1, min(args.steps, 4)))
+        dom = max(prof, key=lambda k: prof[k]["ms_per_step"])
+        d = prof[dom]
+        traffic, why = (None, "skipped")
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(d["tflops"] / peak, 4), "avg_launch_us": round(d["avg_launch_us"], 2),
+            "algorithmic_gflop_per_launch": round(d["gflop_per_launch"], 3),
+            "launches_per_step": d["launches_per_step"], "traffic": None,
+            "per_kernel": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in
+                           sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+            "gemm_class_ms_per_step": round(sum(v["ms_per_step"] for v in prof.values()), 3),
+        }
+        del model, opts, reducers, step
+        torch.cuda.empty_cache()
+        # ---- configs[1]: compression (no GAN) training step ---------------------------------------------------
+        if cfg == "gan":
+            m2, o2, r2 = build(args, dev, "compression")
+            s2 = make_step(args, m2, o2, r2, dev, "compression")
+            e2 = timed(s2, args.steps, args.warmup, fence)
+            out["compression"] = {"value": round(args.batch * args.steps / e2, 3), "unit": "images/s",
+                                  "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                                  "workload": "BASELINE configs[1]: compression (no GAN) training step, same batch/dtype",
+                                  "whole_step_tflops": round(GFLOP_PER_IMAGE["compression"] * args.batch *
+                                                             (args.size / 256.0) ** 2 / 1e3 / (e2 / args.steps), 1)}
+            del m2, o2, r2, s2
+            torch.cuda.empty_cache()
+        # ---- forward ms/image: EVALUATION-mode forward (model.py:357-366) ---------------------------------------
+        import hific_amd
+        from hific_amd.default_config import make_args, hific_args, ModelTypes, ModelModes
+        margs = make_args(hific_args, batch_size=args.batch, image_dims=(3, args.size, args.size),
+                          latent_dims=(220, args.size // 16, args.size // 16))
+        torch.manual_seed(0)
+        ev = hific_amd.Model(margs, model_type=ModelTypes.COMPRESSION_GAN, model_mode=ModelModes.EVALUATION,
+                             allow_random_lpips_backbone=True, build_tables=False).to(dev).eval()
+        xg = torch.Generator(device=dev).manual_seed(7)
+        xe = torch.rand((args.batch, 3, args.size, args.size), generator=xg, device=dev)
+
+        def fwd():
+            with torch.no_grad():
+                return ev(xe)
+        ef = timed(fwd, max(args.steps, 10), args.warmup, fence)
+        per_img = ef / max(args.steps, 10) / args.batch * 1e3
+        out["fwd_ms_per_image"] = round(per_img, 4)
+        out["fwd"] = {"workload": f"EVALUATION-mode Model.forward (Encoder -> Hyperprior -> Generator, clamp; returns "
+                                  f"reconstruction + q_bpp), no-grad, batch {args.batch}, {args.dtype}",
+                      "ms_per_batch": round(per_img * args.batch, 3), "images_per_s": round(1e3 / per_img, 1),
+                      "tflops": round(GFLOP_PER_IMAGE["forward"] * (args.size / 256.0) ** 2 / 1e3 / (per_img * 1e-3), 1)}
+        del ev
+        torch.cuda.empty_cache()
+        if not args.no_traffic and os.environ.get("HIFIC_BENCH_PMC", "1") != "0":
+            traffic, why = measure_traffic(args, dom)
+        out["roofline"]["traffic"] = traffic
+        if traffic is None:
+            out["roofline"]["traffic_note"] = why
+        else:
+            us = out["roofline"]["avg_launch_us"]
+            out["roofline"]["hbm_gbps_at_avg_launch"] = round(traffic["bytes_per_launch"] / (us * 1e-6) / 1e9, 1)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if use_dist:

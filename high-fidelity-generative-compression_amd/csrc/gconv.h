@@ -37,6 +37,7 @@ struct GcParams {
     int nphase;
     int tap_sw;          // kernel width S (weight tap index = r*S + s)
     int dbg;             // ablation flags for micro-benchmarks (HIFIC_DBG; 0 in production)
+    double aflops;       // algorithmic FLOPs of the op on its real output domain (profiler only)
     // reflect-padded data gradient: `out` is the f32 padded plane buffer (only its rim is written); pixels inside
     // [fold_pt, fold_pt+fold_h) x [fold_pl, fold_pl+fold_w) go straight to out2 = dx[N,K,fold_h,fold_w]
     void* out2;

@@ -1437,44 +1437,61 @@ __global__ void wgrad_finalize_kernel(const WgParams p, float* __restrict__ dw, 
 // kernel kind, with the algorithmic FLOPs of each launch.  Used by bench.py for the live roofline figure.
 // ---------------------------------------------------------------------------------------------------
 #define PROF_MAX 16384
-enum { PK_GCONV128 = 0, PK_GCONV64 = 1, PK_GCONV32 = 2, PK_WGRAD = 3, PK_NKIND = 4 };
+#define PROF_MAXKINDS 32
+#define PROF_NAMELEN 64
+// kinds are kernel functions, registered by name on first use (the table only grows while profiling is on)
 static bool g_prof_on = false;
 static int g_prof_n = 0;
+static int g_prof_nk = 0;
+static char g_prof_kname[PROF_MAXKINDS][PROF_NAMELEN];
 static hipEvent_t g_prof_ev[PROF_MAX][2];
 static bool g_prof_ev_made[PROF_MAX];
 static int g_prof_kind[PROF_MAX];
 static double g_prof_flops[PROF_MAX];
 static char g_prof_tag[PROF_MAX][112];     // launch shape, printed per launch when HIFIC_PROF_DUMP=1
 
-static int prof_open(int kind, double flops, hipStream_t st, const char* tag = "") {
+static int prof_open(const char* kname, double flops, hipStream_t st, const char* tag = "") {
     if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
+    int k = 0;
+    while (k < g_prof_nk && strcmp(g_prof_kname[k], kname) != 0) ++k;
+    if (k == g_prof_nk) {
+        if (g_prof_nk >= PROF_MAXKINDS) return -1;
+        strncpy(g_prof_kname[k], kname, PROF_NAMELEN - 1); g_prof_kname[k][PROF_NAMELEN - 1] = 0;
+        ++g_prof_nk;
+    }
     const int i = g_prof_n++;
     if (!g_prof_ev_made[i]) {
         hipEventCreate(&g_prof_ev[i][0]); hipEventCreate(&g_prof_ev[i][1]); g_prof_ev_made[i] = true;
     }
-    g_prof_kind[i] = kind; g_prof_flops[i] = flops;
+    g_prof_kind[i] = k; g_prof_flops[i] = flops;
     strncpy(g_prof_tag[i], tag, sizeof(g_prof_tag[i]) - 1); g_prof_tag[i][sizeof(g_prof_tag[i]) - 1] = 0;
     hipEventRecord(g_prof_ev[i][0], st);
     return i;
 }
 static void prof_close(int i, hipStream_t st) { if (i >= 0) hipEventRecord(g_prof_ev[i][1], st); }
 
-extern "C" int hific_prof_begin(void) { g_prof_on = true; g_prof_n = 0; return HIFIC_OK; }
-// Synchronises the recorded events; out arrays have PK_NKIND entries: total ms, total FLOPs, launch count.
-extern "C" int hific_prof_end(double* ms, double* flops, int* count) {
+extern "C" int hific_prof_begin(void) { g_prof_on = true; g_prof_n = 0; g_prof_nk = 0; return HIFIC_OK; }
+// Synchronises the recorded events.  Fills, for up to max_kinds kernel functions: total ms, total algorithmic FLOPs,
+// launch count and the kernel name (names: max_kinds x 64 chars).  Returns the number of kinds (<0: error code).
+extern "C" int hific_prof_end(int max_kinds, double* ms, double* flops, int* count, char* names) {
     g_prof_on = false;
     const char* dump_e = getenv("HIFIC_PROF_DUMP");
     const bool dump = dump_e && atoi(dump_e) != 0;
-    for (int k = 0; k < PK_NKIND; ++k) { ms[k] = 0; flops[k] = 0; count[k] = 0; }
+    const int nk = g_prof_nk < max_kinds ? g_prof_nk : max_kinds;
+    for (int k = 0; k < nk; ++k) {
+        ms[k] = 0; flops[k] = 0; count[k] = 0;
+        strncpy(names + (size_t)k * PROF_NAMELEN, g_prof_kname[k], PROF_NAMELEN);
+    }
     for (int i = 0; i < g_prof_n; ++i) {
         if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) return HIFIC_ERR_LAUNCH;
         float t = 0.f;
         hipEventElapsedTime(&t, g_prof_ev[i][0], g_prof_ev[i][1]);
-        ms[g_prof_kind[i]] += t; flops[g_prof_kind[i]] += g_prof_flops[i]; count[g_prof_kind[i]]++;
-        if (dump) fprintf(stderr, "HIFIC_PROF %d %.3f %.4g %s\n", g_prof_kind[i], t * 1e3, g_prof_flops[i], g_prof_tag[i]);
+        const int k = g_prof_kind[i];
+        if (k < nk) { ms[k] += t; flops[k] += g_prof_flops[i]; count[k]++; }
+        if (dump) fprintf(stderr, "HIFIC_PROF %s %.3f %.4g %s\n", g_prof_kname[k], t * 1e3, g_prof_flops[i], g_prof_tag[i]);
     }
     g_prof_n = 0;
-    return HIFIC_OK;
+    return nk;
 }
 
 // ===================================================================================================
@@ -1648,14 +1665,24 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     }
     p.max_tiles = max_tiles;
     dim3 grid(max_tiles * (p.Kpad / bm), 1, p.nphase);
-    double aflops = 0;
-    for (int i = 0; i < p.nphase; ++i)
-        aflops += 2.0 * p.K * p.C * p.ph[i].ntaps * (double)p.N * p.ph[i].OHt * p.ph[i].OWt;
+    // algorithmic FLOPs of the op (set by the caller on the op's REAL output domain: a reflect-padded data gradient
+    // computes on the padded plane, which is extra work, not extra useful FLOPs)
+    const double aflops = p.aflops;
     char ptag[112];
     snprintf(ptag, sizeof(ptag), "gconv K%d C%d N%d in%dx%d out%dx%d ph%d taps%d ist%d ost%d tile%dx%dx%d bm%d grid%d",
              p.K, p.C, p.N, p.IH, p.IW, p.OHf, p.OWf, p.nphase, maxtaps, p.ist, p.ost, p.NI, p.TH, p.TW, bm,
              max_tiles * (p.Kpad / bm) * p.nphase);
-    const int pslot = prof_open(bm == 128 ? PK_GCONV128 : (bm == 64 ? PK_GCONV64 : PK_GCONV32), aflops, st, ptag);
+    bool use_sp9 = false;
+    if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
+        use_sp9 = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 &&
+                  p.NI * p.ph[0].PH * p.ph[0].PW <= 192 && !env_int("HIFIC_NO_SP", 0) &&
+                  64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(p.NI * p.ph[0].PH * p.ph[0].PW + 1) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
+    }
+    char kname[PROF_NAMELEN];
+    if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d>", bm / 64);
+    else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
+                  bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
+    const int pslot = prof_open(kname, aflops, st, ptag);
 #define GC_LAUNCH(WGM, WGN, WM, WN)                                                                      \
     do {                                                                                                 \
         auto kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN>;                                                \
@@ -1666,9 +1693,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     bool sp_done = false;
     if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
         // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, patch <= 192 pixels
-        bool ok = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 &&
-                  p.NI * p.ph[0].PH * p.ph[0].PW <= 192 && !env_int("HIFIC_NO_SP", 0);
-        if (ok) {
+        if (use_sp9) {
             const int npatch = p.NI * p.ph[0].PH * p.ph[0].PW;
             const size_t lds_sp = 64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(npatch + 1) * PITCH + 15) & ~(size_t)15);
             if (lds_sp <= (size_t)kLdsBudget) {
@@ -1729,6 +1754,7 @@ int gc_conv_fwd(const ConvGeom& g, const void* x, const float* w, const float* w
     ph.ntaps = nt; ph.tap0 = 0; ph.ooy = 0; ph.oox = 0; ph.OHt = p.OHf; ph.OWt = p.OWf;
     finish_phase(ph, p);
     const long long RS = (long long)g.R * g.S;
+    p.aflops = 2.0 * g.K * g.C * (double)RS * g.N * g.OH() * g.OW();
     return launch_gconv(p, dtype, w, w_scale, (long long)g.C * RS, RS, g.S, 1, ws, st);
 }
 
@@ -1776,6 +1802,7 @@ int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const fl
     }
     p.nphase = np;
     const long long RS = (long long)g.R * g.S;
+    p.aflops = 2.0 * g.K * g.C * (double)RS * g.N * g.OH() * g.OW();       // same MACs as the forward op
     // out-channel m = c (stride RS), reduction channel = k (stride C*RS)
     int rc = launch_gconv(p, dtype, w, w_scale, RS, (long long)g.C * RS, g.S, 1, ws, st);
     if (rc != HIFIC_OK) return rc;
@@ -1835,6 +1862,7 @@ int gc_convT_fwd(const ConvTGeom& g, const void* x, const float* w, const float*
     }
     p.nphase = np;
     const long long RS = (long long)g.R * g.S;
+    p.aflops = 2.0 * g.Ci * g.Co * (double)RS * g.N * g.H * g.W;           // every (input pixel, tap) pair once
     // w[ci][co][r][s]: m = co (stride RS), reduction channel ci (stride Co*RS)
     return launch_gconv(p, dtype, w, nullptr, RS, (long long)g.Co * RS, g.S, 1, ws, st);
 }
@@ -1853,6 +1881,7 @@ int gc_convT_bwd_data(const ConvTGeom& g, const void* dy, const float* w, void* 
     ph.ntaps = nt; ph.tap0 = 0; ph.OHt = g.H; ph.OWt = g.W;
     finish_phase(ph, p);
     const long long RS = (long long)g.R * g.S;
+    p.aflops = 2.0 * g.Ci * g.Co * (double)RS * g.N * g.H * g.W;
     // m = ci (stride Co*RS), reduction channel co (stride RS)
     return launch_gconv(p, dtype, w, nullptr, (long long)g.Co * RS, RS, g.S, 1, ws, st);
 }
@@ -1921,7 +1950,6 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
     snprintf(ptag, sizeof(ptag), "wgrad M%d C%d N%d a%dx%d taps%d ist%d tile%dx%dx%d split%d grid%d",
              p.M, p.C, p.N, p.AH, p.AW, p.ntaps, p.ist, p.NI, p.TH, p.TW, p.nsplit,
              (p.Mpad / 64) * (p.Cpad / 64) * p.ngroups * p.nsplit);
-    const int pslot = prof_open(PK_WGRAD, 2.0 * p.M * p.C * p.ntaps * (double)p.N * p.AH * p.AW, st, ptag);
     bool pipe = false;
     if constexpr (std::is_same<T, bf16_t>::value) {
         int npatch_max = 0;
@@ -1932,6 +1960,16 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
         const size_t lds_pipe = 512 + 2 * (size_t)64 * (GC_NPIX * 2 + 16) + 2 * (((size_t)(npatch_max + 1) * 144 + 15) & ~(size_t)15);
         pipe = !p.a_f32 && !p.b_f32 && p.NI * p.TH * p.TW == GC_NPIX && p.TW % 8 == 0 && p.AW % 8 == 0 &&
                npatch_max <= 192 && lds_pipe <= (size_t)kLdsBudget && !env_int("HIFIC_NO_WGPIPE", 0);
+    }
+    const int pslot = prof_open(pipe ? "wgrad_pipe_kernel" : (std::is_same<T, float>::value ? "wgrad_kernel<f32>" : "wgrad_kernel<bf16>"),
+                                2.0 * p.M * p.C * p.ntaps * (double)p.N * p.AH * p.AW, st, ptag);
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        int npatch_max = 0;
+        for (int gi = 0; gi < p.ngroups; ++gi) {
+            int np_ = p.NI * p.grp[gi].PH * p.grp[gi].PW;
+            if (np_ > npatch_max) npatch_max = np_;
+        }
+        const size_t lds_pipe = 512 + 2 * (size_t)64 * (GC_NPIX * 2 + 16) + 2 * (((size_t)(npatch_max + 1) * 144 + 15) & ~(size_t)15);
         if (pipe) {
             hipFuncSetAttribute((const void*)wgrad_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
             hipLaunchKernelGGL(wgrad_pipe_kernel, grid, dim3(256), lds_pipe, st, p);
@@ -2041,7 +2079,8 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
         hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     char ptag[112];
     snprintf(ptag, sizeof(ptag), "wgrad_im2col K%d C%d N%d out%dx%d taps%d split%d", g.K, g.C, g.N, g.OH(), g.OW(), nt, p.nsplit);
-    const int pslot = prof_open(PK_WGRAD, 2.0 * g.K * g.C * nt * (double)g.N * g.OH() * g.OW(), st, ptag);
+    const int pslot = prof_open(std::is_same<T, float>::value ? "wgrad_im2col_kernel<f32>" : "wgrad_im2col_kernel<bf16>",
+                                2.0 * g.K * g.C * nt * (double)g.N * g.OH() * g.OW(), st, ptag);
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
     prof_close(pslot, st);
     int rc = hific_launch_status();

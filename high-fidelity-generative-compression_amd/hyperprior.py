@@ -88,7 +88,7 @@ class _EntropyModelHandle:
 class Hyperprior(CodingModel):
     def __init__(self, bottleneck_capacity=220, hyperlatent_filters=LARGE_HYPERLATENT_FILTERS, mode='large',
                  likelihood_type='gaussian', scale_lower_bound=MIN_SCALE, entropy_code=False,
-                 vectorize_encoding=True, block_encode=True):
+                 vectorize_encoding=True, block_encode=True, lazy_tables=False):
         super().__init__(n_channels=bottleneck_capacity)
         self.bottleneck_capacity = bottleneck_capacity
         self.scale_lower_bound = scale_lower_bound
@@ -112,7 +112,8 @@ class Hyperprior(CodingModel):
         self._tables = None
         if entropy_code is True:
             object.__setattr__(self, 'hyperprior_entropy_model', _EntropyModelHandle(self))   # not a sub-module
-            self.build_tables()
+            if not lazy_tables:          # lazy: built on the first compress/decompress (a forward never needs them)
+                self.build_tables()
 
     # ---- EVALUATION path (src/hyperprior.py:183-274) -----------------------------------------------------------
     def build_tables(self):

@@ -29,7 +29,7 @@ Disc_out = namedtuple("disc_out", ["D_real", "D_gen", "D_real_logits", "D_gen_lo
 class Model(nn.Module):
     def __init__(self, args, logger=None, storage_train=None, storage_test=None, model_mode=ModelModes.TRAINING,
                  model_type=ModelTypes.COMPRESSION, device_rate_select=False, lpips_backbone=None,
-                 allow_random_lpips_backbone=False):
+                 allow_random_lpips_backbone=False, build_tables=True):
         """`lpips_backbone`: path or state_dict of torchvision's pretrained AlexNet (also `args.lpips_backbone`,
         $HIFIC_LPIPS_ALEX_WEIGHTS); without it PerceptualLoss warns loudly (see loss/perceptual_loss.py)."""
         super().__init__()
@@ -54,7 +54,7 @@ class Model(nn.Module):
                                              channel_norm=args.use_channel_norm, sample_noise=args.sample_noise,
                                              noise_dim=args.noise_dim)
         self.Hyperprior = hyperprior.Hyperprior(bottleneck_capacity=C, likelihood_type=args.likelihood_type,
-                                                entropy_code=self.entropy_code)
+                                                entropy_code=self.entropy_code, lazy_tables=not build_tables)
         self.amortization_models = [self.Encoder, self.Generator, *self.Hyperprior.amortization_models]
         self.use_discriminator = (model_type == ModelTypes.COMPRESSION_GAN and model_mode != ModelModes.EVALUATION)
         self.discriminator_steps, self.Discriminator = 0, None

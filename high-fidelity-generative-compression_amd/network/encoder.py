@@ -23,7 +23,7 @@ class Encoder(nn.Module):
                 return channel.ChannelNorm2D_wrap(ch, fuse_relu=True, **norm_kwargs)
         else:
             def norm(ch):
-                return instance.InstanceNorm2D_wrap(ch, **norm_kwargs)
+                return instance.InstanceNorm2D_wrap(ch, fuse_relu=True, **norm_kwargs)
 
         # index 0 = the reference's pad module (no parameters), index 3 = its activation module
         self.conv_block1 = nn.Sequential(

@@ -12,7 +12,7 @@ def _norm_factory(channel_norm):
     norm_kwargs = dict(momentum=0.1, affine=True, track_running_stats=False)
     if channel_norm is True:
         return lambda ch, relu=False: channel.ChannelNorm2D_wrap(ch, fuse_relu=relu, **norm_kwargs)
-    return lambda ch, relu=False: instance.InstanceNorm2D_wrap(ch, **norm_kwargs)
+    return lambda ch, relu=False: instance.InstanceNorm2D_wrap(ch, fuse_relu=relu, **norm_kwargs)
 
 
 class ResidualBlock(nn.Module):

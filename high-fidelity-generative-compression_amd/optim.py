@@ -98,11 +98,13 @@ class ParamArena:
                     p.data = self.flat[o:o + n].view(p.shape)
                     strayed += 1
                 if not grad_ok:
-                    # _apply re-points `p.grad.data` IN PLACE, i.e. the slot's own view object: make a new one
+                    # _apply re-points `p.grad.data` IN PLACE, i.e. the slot's own view object, so a backward that
+                    # ran after the move wrote its gradient into that stray storage: bring it home, keep `fresh`
                     gview = self.flat_grad[o:o + n].view(p.shape)
+                    if p.grad is not None and p.grad.shape == p.shape and not self.slots[i].fresh:
+                        gview.copy_(p.grad.to(torch.float32))
                     self.slots[i].grad = gview
                     p.grad = gview
-                    self.slots[i].fresh = True          # whatever the detached .grad held is not in the slot
         return strayed
 
     def zero_unwritten(self):

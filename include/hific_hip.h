@@ -173,11 +173,15 @@ int hific_lpips_tap_bwd(const void* f, const float* w, const float* gval, void* 
                         int accumulate, int dtype, hipStream_t stream);
 
 /* ---- in-library profiler (bench.py roofline) ------------------------------------------------------------------
- * HIP event pairs around every GEMM-class kernel launch on its launch stream.  Kinds: 0/1/2 = gconv_kernel with
- * 128/64/32-row tiles, 3 = wgrad_kernel.  hific_prof_end synchronises and returns per kind: total ms, total
- * algorithmic FLOPs (2*K*C*taps*N*OH*OW), launch count (arrays of 4). */
+ * Measurement facility, OFF unless hific_prof_begin() was called, and the one exception to the contract above: it
+ * keeps process-global state (an event pool created on demand with hipEventCreate, never freed), is not thread-safe
+ * and must not be enabled during hipGraph capture.  Between begin and end every GEMM-class launch is bracketed by
+ * an event pair on the launch stream and keyed by its KERNEL FUNCTION (e.g. "gconv_sp9_kernel<2>", "wgrad_pipe_kernel").
+ * hific_prof_end synchronises and returns, per kernel function (at most max_kinds): total ms, total ALGORITHMIC
+ * FLOPs (2*MACs of the op on its real output domain), launch count, name (max_kinds x 64 chars, NUL-terminated).
+ * Return value: number of kernel functions seen (>= 0) or a negative error code. */
 int hific_prof_begin(void);
-int hific_prof_end(double* ms, double* flops, int* count);
+int hific_prof_end(int max_kinds, double* ms, double* flops, int* count, char* names);
 
 #ifdef __cplusplus
 }

@@ -95,8 +95,13 @@ def _install_shims():
         sys.modules["autograd"], sys.modules["autograd.extend"], sys.modules["autograd.numpy"] = ag, ext, agn
 
 
-def load():
-    """Returns the reference's top-level modules as a namespace: .model, .default_config, .hyperprior, ..."""
+def load(root=None):
+    """Returns the reference's top-level modules as a namespace: .model, .default_config, .hyperprior, ...
+    `root`: directory holding `default_config.py` and `src/` (default /root/reference; the GPU test passes the
+    directory it unpacked oracle/_ref/reference_src.tar.gz into)."""
+    global REF_ROOT
+    if root is not None:
+        REF_ROOT = root
     if not available():
         raise RuntimeError("reference not present (expected at %s)" % REF_ROOT)
     _install_shims()

@@ -204,6 +204,71 @@ def test_adam_matches_torch(hific, dev):
     assert (p.cpu() - ref.detach()).abs().max().item() < 1e-7
 
 
+def test_fused_adam_survives_module_moves_and_checkpoints(hific, dev):
+    """FusedAdam over a ParamArena == torch.optim.Adam through: a model.cpu() -> .to(device) round trip between steps
+    (the reference's save_model, utils.py:116-145), a parameter that receives no gradient in a step (zero gradient,
+    not the previous step's), and a state_dict hand-over torch -> FusedAdam in the middle of training."""
+    from hific_amd import optim
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5)).to(dev)
+    ref = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5))
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    opt = optim.FusedAdam(list(net.parameters()), lr=1e-3)
+
+    def both_step(it, skip_last=False):
+        for (pn, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            g = _rnd(tuple(q.shape), 100 * it + q.numel())
+            if skip_last and pn.startswith("1."):
+                q.grad = torch.zeros_like(q)          # torch 1.6 zero_grad(): zero gradient, moments still decay
+                continue
+            q.grad = g.clone()
+            s = p._hific_slot
+            assert s.take() == 0
+            s.grad.copy_(g.to(dev))
+        ropt.step(); opt.step()
+        ropt.zero_grad(); opt.zero_grad()
+
+    both_step(1)
+    both_step(2, skip_last=True)
+    net.cpu(); net.to(dev)                           # parameters leave the arena ...
+    both_step(3)                                     # ... and step() re-binds them instead of updating frozen copies
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert (p.detach().cpu() - q.detach()).abs().max().item() < 2e-7
+    # hand-over: a fresh FusedAdam resumes from torch's own optimizer state_dict
+    net2 = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5)).to(dev)
+    net2.load_state_dict(ref.state_dict())
+    opt2 = optim.FusedAdam(list(net2.parameters()), lr=9.0)
+    opt2.load_state_dict(ropt.state_dict())
+    net, opt = net2, opt2
+    both_step(4)
+    for p, q in zip(net2.parameters(), ref.parameters()):
+        assert (p.detach().cpu() - q.detach()).abs().max().item() < 2e-7
+    sd = opt2.state_dict()
+    assert float(sd["state"][0]["step"]) == 4.0 and sd["param_groups"][0]["lr"] == 1e-3
+
+
+def test_least_squares_gan_loss(hific, dev):
+    """losses.py:43-50 on D = sigmoid(logits): values and the gradient w.r.t. the logits."""
+    from collections import namedtuple
+    from hific_amd.loss import losses
+    D = namedtuple("D", ["D_real", "D_gen", "D_real_logits", "D_gen_logits"])
+    zr, zg = _rnd((512,), 1) * 3, _rnd((512,), 2) * 3
+    zr_r, zg_r = zr.clone().requires_grad_(True), zg.clone().requires_grad_(True)
+    dr, dg = torch.sigmoid(zr_r), torch.sigmoid(zg_r)
+    D_ref = 0.5 * (torch.mean((dr - 1.0) ** 2) + torch.mean(dg ** 2))
+    G_ref = 0.5 * torch.mean((dg - 1.0) ** 2)
+    (D_ref + 2.0 * G_ref).backward()
+    zr_d, zg_d = zr.to(dev).requires_grad_(True), zg.to(dev).requires_grad_(True)
+    D_loss, G_loss = losses.gan_losses("least_squares", D(None, None, zr_d, zg_d))
+    (D_loss + 2.0 * G_loss).backward()
+    torch.cuda.synchronize()
+    assert abs(float(D_loss) - float(D_ref)) < 1e-6 and abs(float(G_loss) - float(G_ref)) < 1e-6
+    assert _relerr(zr_d.grad.cpu(), zr_r.grad) < 1e-5 and _relerr(zg_d.grad.cpu(), zg_r.grad) < 1e-5
+    with pytest.raises(ValueError):
+        losses.gan_losses("hinge", D(None, None, zr_d, zg_d))
+
+
 def test_spectral_norm_and_upcat(hific, dev):
     from hific_amd import ops
     w = _rnd((8, 5, 4, 4), 1)

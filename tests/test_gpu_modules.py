@@ -252,3 +252,28 @@ def test_zz_model_compress_decompress(hific, dev, tmp_path):
         lat = model.Hyperprior.decompress_forward(out, device=dev)
         ref = torch.clamp(model.Generator(lat)[:, :, :72, :88].float(), 0.0, 1.0)
     assert torch.equal(rec.cpu(), ref.cpu())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_instance_norm_variant_trains(hific, dev, dt):
+    """use_channel_norm=False: HIP convs + the PyTorch instance-norm fallback, forward and backward on the device,
+    against the same network assembled from torch ops on the CPU."""
+    import torch.nn.functional as F
+    from hific_amd.network.encoder import Encoder
+    hific.set_compute_dtype(dt)
+    torch.manual_seed(0)
+    enc = Encoder((3, 64, 64), 2, C=220, channel_norm=False)
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    x = O.make_image(1, 2, 64, 64)
+    enc = enc.to(dev)
+    y = enc(x.to(dev))
+    y.float().sum().backward()
+    torch.cuda.synchronize()
+    # CPU restatement of encoder.py with InstanceNorm (pads: 3 / asymmetric (0,1,1,0) / 1, all reflect)
+    h = x
+    for i, (pad, st) in enumerate([((3, 3, 3, 3), 1)] + [((0, 1, 1, 0), 2)] * 4, start=1):
+        h = F.conv2d(F.pad(h, pad, mode="reflect"), sd[f"conv_block{i}.1.weight"], sd[f"conv_block{i}.1.bias"], stride=st)
+        h = F.relu(F.instance_norm(h, weight=sd[f"conv_block{i}.2.weight"], bias=sd[f"conv_block{i}.2.bias"]))
+    h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"), sd["conv_block_out.1.weight"], sd["conv_block_out.1.bias"])
+    assert _relerr(y.detach().float().cpu(), h) < (1e-3 if dt == torch.float32 else 6e-2)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())

@@ -167,3 +167,21 @@ def test_param_arena_rebind_zero_unwritten_and_adam_state_dict(hific):
         o, n = arena.slice_of(i)
         assert torch.equal(opt2.exp_avg[o:o + n], opt.exp_avg[o:o + n])
         assert torch.equal(opt2.exp_avg_sq[o:o + n], opt.exp_avg_sq[o:o + n])
+
+
+def test_instance_norm_variant_constructs_like_the_reference(hific):
+    """use_channel_norm=False (src/normalisation/instance.py:7-15): documented PyTorch fallback, reference key layout
+    (`weight` / `bias` instead of `gamma` / `beta`)."""
+    import torch
+    from hific_amd.network.encoder import Encoder
+    from hific_amd.network.generator import Generator
+    from hific_amd.normalisation import instance
+    enc = Encoder((3, 64, 64), 2, C=220, channel_norm=False)
+    gen = Generator((220, 4, 4), 2, C=220, n_residual_blocks=1, channel_norm=False)
+    assert "conv_block1.2.weight" in enc.state_dict() and "conv_block1.2.gamma" not in enc.state_dict()
+    assert "resblock_0.norm1.bias" in gen.state_dict() and "upconv_block2.1.weight" in gen.state_dict()
+    m = instance.InstanceNorm2D_wrap(5, fuse_relu=True)
+    x = torch.randn(2, 5, 6, 7)
+    ref = torch.relu(torch.nn.InstanceNorm2d(5, affine=True)(x))
+    assert torch.allclose(m(x), ref, atol=1e-6)
+    assert m(x.bfloat16()).dtype == torch.bfloat16
