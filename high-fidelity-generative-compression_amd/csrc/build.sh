@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../libhific_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
-SRCS="gconv elementwise norm entropy lpips capi"
+SRCS="gconv elementwise norm entropy lpips augment capi"
 OBJS=""
 PIDS=""
 NAMES=""

@@ -68,6 +68,7 @@ SIGNATURES = {
     "hific_lpips_prep_bwd": (I, [P, P, I, I, I, I, I, P]),
     "hific_lpips_tap_fwd": (I, [P, P, P, I, I, I, I, I, P, Z, P]),
     "hific_lpips_tap_bwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "hific_augment_crop": (I, [P, P, P, P, P, I, I, I, I, P, P]),
     "hific_prof_begin": (I, []),
     "hific_prof_end": (I, [I, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int), c_char_p]),
 }

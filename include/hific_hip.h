@@ -172,6 +172,23 @@ int hific_lpips_tap_fwd(const void* f, const float* w, float* val, int B, int C,
 int hific_lpips_tap_bwd(const void* f, const float* w, const float* gval, void* df1, int B, int C, int HW,
                         int accumulate, int dtype, hipStream_t stream);
 
+/* ---- training-time augmentation (csrc/augment.hip) - src/helpers/datasets.py:206-216 ----------------------------
+ * RandomHorizontalFlip -> Resize((ceil(s H), ceil(s W)), PIL bilinear) -> RandomCrop(crop) -> ToTensor [-> Normalize]
+ * for a batch of decoded uint8 HWC images in one launch; integer-exact with Pillow's 8-bit resampler.  The random
+ * draws and the fixed-point weights of the crop window (Resample.c precompute_coeffs, double precision) come from the
+ * host (hific_amd/helpers/augment.py).  imgs: device array of B hific_aug_image; xb/yb: int32 [B][crop][2] = (first
+ * source index, tap count) per crop column/row; xk/yk: int32 [B][crop][kmax] weights (22 fractional bits);
+ * out: float32 [B,3,crop,crop]. */
+typedef struct hific_aug_image {
+    const unsigned char* src;   /* uint8 [H][W][3], device memory */
+    int H, W;
+    int flip;                   /* horizontal flip before the resize */
+    int resize_x, resize_y;     /* 0: the axis keeps its size (no resampling pass, as in Pillow) */
+    int top, left;              /* crop origin in the resized image */
+} hific_aug_image;
+int hific_augment_crop(const void* imgs, const int* xb, const int* xk, const int* yb, const int* yk, int B, int crop,
+                       int kmax, int normalize, float* out, hipStream_t stream);
+
 /* ---- in-library profiler (bench.py roofline) ------------------------------------------------------------------
  * Measurement facility, OFF unless hific_prof_begin() was called, and the one exception to the contract above: it
  * keeps process-global state (an event pool created on demand with hipEventCreate, never freed), is not thread-safe
