@@ -240,8 +240,8 @@ def test_zz_model_compress_decompress(hific, dev, tmp_path):
     assert out.total_bits > 0 and abs(out.total_bpp - out.total_bits / (72 * 88)) < 1e-6
     assert 0.3 < out.total_bits / attained < 3.0, (out.total_bits, attained)
     # EVALUATION-mode forward (model.py:357-366): clamped reconstruction and the quantised rate
-    rec_f, q_bpp = model(x[:, :, :64, :80].contiguous())
-    assert tuple(rec_f.shape) == (1, 3, 64, 80) and float(rec_f.min()) >= 0.0 and float(rec_f.max()) <= 1.0
+    rec_f, q_bpp = model(O.make_image(10, 1, 128, 160).to(dev))
+    assert tuple(rec_f.shape) == (1, 3, 128, 160) and float(rec_f.min()) >= 0.0 and float(rec_f.max()) <= 1.0
     assert float(q_bpp) > 0
     path = str(tmp_path / "img.hfc")
     container.save_compressed_format(out, path)
