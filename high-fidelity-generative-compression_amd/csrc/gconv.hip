@@ -373,19 +373,26 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
 // or table-driven loads made the compiler drain with vmcnt(0): measured 1.3-2x slower) and the loads / ds_writes are
 // interleaved between the 16 MFMAs of a step.  One barrier per step, no separate staging phase.
 // ---------------------------------------------------------------------------------------------------
-template <int WM>
-__global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
+// KSP = 2: 8 waves; waves 4-7 mirror waves 0-3 on the same output tile but take the upper half of every 64-channel
+// chunk's reduction (two waves per SIMD hide each other's LDS/barrier latency at unchanged LDS bytes per MFMA); the
+// two partial accumulators are exchanged through LDS at the end and each half writes half of the tile.
+template <int WM, int KSP>
+__global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2))) void gconv_sp9_kernel(const GcParams p) {
     typedef bf16_t T;
     constexpr int BC = 64, KS = 16, PITCH = 144, PPR = 8, WGN = 2, WN = 2, NT = 9, QJ = 3;
     constexpr int BM = 2 * WM * 32;
-    constexpr int WBYTES = BM * PITCH, NWP = BM * PPR / 256;
+    constexpr int NTHR = 256 * KSP;
+    constexpr int WBYTES = BM * PITCH, NWP = BM * PPR / NTHR;
+    constexpr int PCOLS = 8 / KSP;             // dword columns of the patch each wave stages per chunk
+    static_assert(BM * PPR % NTHR == 0 && NWP >= 1, "weight pieces per thread");
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int kgrp = wave >> 2, tw = wave & 3;                  // reduction half, wave position inside the tile
+    const int wm = tw / WGN, wn = tw % WGN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     const GcPhase& ph = p.ph[0];
@@ -448,6 +455,7 @@ __global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
         pu[ni] = u0 + ty_; pv[ni] = v0 + tx_; pn[ni] = n0 + img;
     }
     const unsigned arow = (unsigned)((wm * WM * 32 + l31) * PITCH + lhi * 16);
+    const int kgrp_k0 = kgrp * (BC / KS / KSP);                 // first 16-deep reduction slice of this wave's half
 
     f32x16_t acc[WM][WN];
 #pragma unroll
@@ -467,16 +475,19 @@ __global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
     const unsigned char* wsrc[NWP];
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
-        const int piece = tid + i * 256;
+        const int piece = tid + i * NTHR;
         wdst[i] = (unsigned)((piece / PPR) * PITCH + (piece % PPR) * 16);
         wsrc[i] = wp_ph + (size_t)(m0 + piece / PPR) * wrow_bytes + (piece % PPR) * 16;
     }
 
+    constexpr int PD = 2 / KSP;                                 // patch dword columns issued per step (steps 0..3)
     u32x4_t wS[3][NWP];
-    unsigned short rlo[3][2 * QJ], rhi[3][2 * QJ];
+    unsigned short rlo[3][PD * QJ], rhi[3][PD * QJ];
 
-    // prologue: patch of chunk 0 staged synchronously, weight tiles 0..2 requested, tile 0 in ring slot 0
-    stage_T<T, 32, PITCH>(pbuf, p.in, 0, p.N, p.C, p.IH, p.IW, p.bmode, n0, p.NI, iy0, ix0, 0, PH, PW, 0, tid, 256);
+    // prologue: patch of chunk 0 staged synchronously (by the first four waves: stage_T's thread map is 4 waves wide),
+    // weight tiles 0..2 requested, tile 0 in ring slot 0
+    if (KSP == 1 || tid < 256)
+        stage_T<T, 32, PITCH>(pbuf, p.in, 0, p.N, p.C, p.IH, p.IW, p.bmode, n0, p.NI, iy0, ix0, 0, PH, PW, 0, tid, 256);
 
     // weight tile (chunk cc, tap tt); tiles past the end re-read the last chunk (never consumed)
 #define SP_WISSUE(SET, cc, tt)                                                                     \
@@ -486,11 +497,12 @@ __global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
 #define SP_WRETIRE(SET, SLOT)                                                                      \
     do { _Pragma("unroll") for (int i = 0; i < NWP; ++i)                                           \
              *(u32x4_t*)(wbuf + (SLOT) * WBYTES + wdst[i]) = wS[SET][i]; } while (0)
-    // dword columns 2*tt, 2*tt+1 (of 8) of the next chunk's patch: channel c = c0n + 2*(wave + 4*col) is wave-uniform
+    // dword columns of the next chunk's patch taken by this wave in step tt (PD per step, 32 columns per chunk over
+    // 4 * KSP waves and 4 steps): column = wave + 4*KSP*(PD*tt + d); channel c = c0n + 2*column is wave-uniform
 #define SP_PISSUE(SET, tt)                                                                                  \
     do {                                                                                                    \
-        _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                     \
-            const int c = c0n + 2 * (wave + 4 * (2 * (tt) + d));                                            \
+        _Pragma("unroll") for (int d = 0; d < PD; ++d) {                                                    \
+            const int c = c0n + 2 * (wave + 4 * KSP * (PD * (tt) + d));                                     \
             const bf16_t* pl0 = inb + (size_t)(c < p.C ? c : 0) * plane;                                    \
             const bf16_t* pl1 = inb + (size_t)(c + 1 < p.C ? c + 1 : 0) * plane;                            \
             _Pragma("unroll") for (int j = 0; j < QJ; ++j) {                                                \
@@ -501,13 +513,13 @@ __global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
     } while (0)
 #define SP_PRETIRE(SET, tt)                                                                                 \
     do {                                                                                                    \
-        _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                     \
-            const int c = c0n + 2 * (wave + 4 * (2 * (tt) + d));                                            \
+        _Pragma("unroll") for (int d = 0; d < PD; ++d) {                                                    \
+            const int c = c0n + 2 * (wave + 4 * KSP * (PD * (tt) + d));                                     \
             const bool c0ok = c < p.C, c1ok = c + 1 < p.C;                                                  \
             _Pragma("unroll") for (int j = 0; j < QJ; ++j) {                                                \
                 const unsigned lo_ = (qok[j] && c0ok) ? (unsigned)rlo[SET][d * QJ + j] : 0u;                \
                 const unsigned hi_ = (qok[j] && c1ok) ? (unsigned)rhi[SET][d * QJ + j] : 0u;                \
-                *(unsigned*)(pnext + pdst[j] + (2 * (tt) + d) * 16) = lo_ | (hi_ << 16);                    \
+                *(unsigned*)(pnext + pdst[j] + (PD * (tt) + d) * 16 * KSP) = lo_ | (hi_ << 16);             \
             }                                                                                               \
         }                                                                                                   \
     } while (0)
@@ -515,7 +527,8 @@ __global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
     do {                                                                                                        \
         const unsigned toff = (unsigned)toffs[tt];                                                              \
         const unsigned char* ab = wbuf + (SLOT) * WBYTES + arow;                                                \
-        _Pragma("unroll") for (int kk = 0; kk < BC / KS; ++kk) {                                                \
+        _Pragma("unroll") for (int kq = 0; kq < BC / KS / KSP; ++kq) {                                          \
+            const int kk = kq + kgrp_k0;                                                                        \
             bf16x8_t a[WM], b[WN];                                                                              \
             _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
                 a[mi] = *(const bf16x8_t*)(ab + mi * 32 * PITCH + kk * 32);                                     \
@@ -556,9 +569,43 @@ __global__ __launch_bounds__(256) void gconv_sp9_kernel(const GcParams p) {
 #undef SP_WRETIRE
 #undef SP_WISSUE
 
+    if constexpr (KSP == 2) {
+        // Each half keeps one pixel fragment (kgrp 0: ni = 0, kgrp 1: ni = 1): it sends its partial sums of the other
+        // fragment through LDS and adds the partner's partial sums of its own.  Region per tile wave: WM*16 floats x 64
+        // lanes per direction (operand buffers are free after the barrier).
+        float* xch = (float*)smem;
+        __syncthreads();
+        float* mine = xch + ((size_t)(tw * 2 + kgrp) * WM * 16) * 64 + lane;                // what this wave sends
+        const float* theirs = xch + ((size_t)(tw * 2 + (1 - kgrp)) * WM * 16) * 64 + lane;  // what the partner sent
+        // accumulator indices must stay compile-time constants (a runtime index would move acc[] to scratch)
+        if (kgrp == 0) {
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(mi * 16 + r) * 64] = acc[mi][1][r];
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(mi * 16 + r) * 64] = acc[mi][0][r];
+        }
+        __syncthreads();
+        if (kgrp == 0) {
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][0][r] += theirs[(mi * 16 + r) * 64];
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][1][r] += theirs[(mi * 16 + r) * 64];
+        }
+    }
     const bool out_f32 = p.out_f32;
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
+        if (KSP == 2 && ni != kgrp) continue;
         const int oy = pu[ni] * p.ost + ph.ooy, ox = pv[ni] * p.ost + ph.oox;
         const bool okp = pvalid[ni] && pn[ni] < p.N && pu[ni] < ph.OHt && pv[ni] < ph.OWt &&
                          (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
@@ -1200,6 +1247,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
     using Cfg = WgCfg<T>;
     constexpr int PITCH = Cfg::PITCH, KS = Cfg::KS, DWR = Cfg::DWR, NDW = DWR / 4;
+    constexpr int MAXCT = 4;                                   // 64-column tiles per workgroup (<= 256 virtual columns)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1207,38 +1255,38 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int wv = tid >> 6;
-    const int ctiles = p.Cpad / 64;
-    const int m0 = (blockIdx.x / ctiles) * 64;
-    const int c0 = (blockIdx.x % ctiles) * 64;       // first virtual column of this block
+    const int nct = p.Cpad / 64;
+    const int m0 = blockIdx.x * 64;
     const int split = blockIdx.z;
     const int npix = p.NI * p.TH * p.TW;
-    unsigned char* at = smem;                                  // [128][PITCH]  A^T image
-    unsigned char* bt = smem + (size_t)GC_NPIX * PITCH;        // [128][PITCH]  im2col image
+    int4* ctab = (int4*)smem;                                  // [256] per virtual column: (offset, dy, dx, channel | valid<<8)
+    unsigned char* at = smem + 4096;                           // [128][PITCH]  A^T image
+    unsigned char* bt = at + (size_t)GC_NPIX * PITCH;          // [128][PITCH]  im2col image of one 64-column tile
     const int thw = p.TH * p.TW;
     const float inv_thw = 1.0f / (float)thw, inv_tw = 1.0f / (float)p.TW;
     const unsigned bplane = (unsigned)(p.BH * p.BW);
 
-    f32x16_t acc;
+    // The workgroup owns ALL virtual columns (tap*4 + channel) of its 64 rows: the big operand's tile (A) is staged once
+    // per pixel tile and re-used by every 64-column tile (it used to be re-read by one workgroup per column tile: 4x the
+    // HBM traffic of the layer's dominant tensor).
+    if (tid < 256) {
+        const int col = tid;
+        const int t = col >> 2, cc = col & 3;
+        const bool v = col < p.Cpad && t < p.ntaps_real && cc < p.creal;
+        const int tt = t < p.ntaps_real ? t : 0;
+        const int dy = p.tsign * (int)p.tap_dy[tt], dx = p.tsign * (int)p.tap_dx[tt];
+        ctab[col] = make_int4(v ? (cc * (int)bplane + dy * p.BW + dx) : 0, dy, dx, (v ? cc : 0) | ((v ? 1 : 0) << 8));
+    }
+
+    f32x16_t acc[MAXCT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c = 0; c < MAXCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     const int tile_lo = split * p.tiles_per_split;
     int tile_hi = tile_lo + p.tiles_per_split;
     if (tile_hi > p.ntiles) tile_hi = p.ntiles;
-
-    // columns of this thread: k = i (f32) or 2*i + e (bf16) <-> virtual column c0 + ... = tap*4 + channel
     constexpr int NCOL = std::is_same<T, float>::value ? NDW : 2 * NDW;
-    int coff[NCOL], cdy[NCOL], cdx[NCOL], ccol[NCOL];
-    unsigned colv = 0;
-#pragma unroll
-    for (int k = 0; k < NCOL; ++k) {
-        const int col = c0 + (std::is_same<T, float>::value ? (wv + 4 * k) : 2 * (wv + 4 * (k >> 1)) + (k & 1));
-        const int t = col >> 2, cc = col & 3;
-        const bool v = t < p.ntaps_real && cc < p.creal;
-        const int tt = t < p.ntaps_real ? t : 0;
-        cdy[k] = p.tsign * (int)p.tap_dy[tt]; cdx[k] = p.tsign * (int)p.tap_dx[tt]; ccol[k] = v ? cc : 0;
-        coff[k] = v ? (cc * (int)bplane + cdy[k] * p.BW + cdx[k]) : 0;
-        colv |= (v ? 1u : 0u) << k;
-    }
     const int tdy_min = p.grp[0].dy_min, tdx_min = p.grp[0].dx_min, tdy_max = p.grp[0].PH, tdx_max = p.grp[0].PW;
 
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
@@ -1251,87 +1299,107 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
         // the tile that lie outside the (padded) domain must contribute nothing: they are zeroed via the B image.
         stage_T<T, DWR, PITCH>(at, p.a, p.a_f32, p.N, p.M, p.a_h, p.a_w, p.a_bmode, n0, p.NI, u0 + p.a_y0,
                                v0 + p.a_x0, 0, p.TH, p.TW, m0, tid, 256);
-        // im2col slice: rows = tile pixels, dword dw = wv + 4*i covers columns (c0 + 2*dw, c0 + 2*dw + 1).
-        // The thread's NCOL columns (tap, channel) are fixed for the whole kernel (colv / coff / cdy / cdx above).
         // Interior tiles (every tap of every pixel inside the B plane, every pixel inside the A domain: all but the
         // rim) take the fast path: one add per element, all NCOL loads of a pixel in flight together.
         const bool interior = (n0 + p.NI <= p.N) && (u0 + p.TH <= p.AH) && (v0 + p.TW <= p.AW) &&
                               (u0 + p.b_y0 + tdy_min >= 0) && (u0 + p.TH - 1 + p.b_y0 + tdy_max < p.BH) &&
                               (v0 + p.b_x0 + tdx_min >= 0) && (v0 + p.TW - 1 + p.b_x0 + tdx_max < p.BW);
-        for (int q = lane; q < npix; q += 64) {
-            const int img = (int)(((float)q + 0.5f) * inv_thw);
-            const int rem = q - img * thw;
-            const int tyy = (int)(((float)rem + 0.5f) * inv_tw);
-            const int txx = rem - tyy * p.TW;
-            const int n = n0 + img, ud = u0 + tyy, vd = v0 + txx;
-            unsigned raw[NCOL];
-            unsigned okm = 0;
-            if (interior) {
-                const unsigned pixbase = (unsigned)(n * p.creal) * bplane + (unsigned)((ud + p.b_y0) * p.BW + (vd + p.b_x0));
+#pragma unroll
+        for (int ct = 0; ct < MAXCT; ++ct) {
+            if (ct < nct) {
+                if (ct > 0) __syncthreads();                   // the previous column tile's MFMAs are done with `bt`
+                // im2col slice of column tile ct: rows = tile pixels, dword dw = wv + 4*i covers columns
+                // (64*ct + 2*dw, + 1); the thread's column descriptors come from the LDS table
+                int4 cd[NCOL];
 #pragma unroll
                 for (int k = 0; k < NCOL; ++k) {
-                    const unsigned off = pixbase + (unsigned)coff[k];
-                    if (std::is_same<T, float>::value || p.b_f32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
-                    else raw[k] = ((const bf16_t*)p.b)[off];
+                    const int col = ct * 64 + (std::is_same<T, float>::value ? (wv + 4 * k) : 2 * (wv + 4 * (k >> 1)) + (k & 1));
+                    cd[k] = ctab[col];
                 }
-                okm = colv;
-            } else {
-                const bool pix_ok = (n < p.N) && (ud < p.AH) && (vd < p.AW);
+                unsigned colv = 0;
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) {
-                    int yb = ud + p.b_y0 + cdy[k];
-                    int xb = vd + p.b_x0 + cdx[k];
-                    if (p.bmode == PAD_REFLECT) { yb = reflect_idx(yb, p.BH); xb = reflect_idx(xb, p.BW); }
-                    const bool ok = pix_ok && ((colv >> k) & 1u) && (unsigned)yb < (unsigned)p.BH && (unsigned)xb < (unsigned)p.BW;
-                    const unsigned off = ok ? ((unsigned)(n * p.creal + ccol[k]) * bplane + (unsigned)(yb * p.BW + xb)) : 0u;
-                    if (std::is_same<T, float>::value || p.b_f32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
-                    else raw[k] = ((const bf16_t*)p.b)[off];
-                    okm |= (ok ? 1u : 0u) << k;
-                }
-            }
-            unsigned char* row = bt + (size_t)q * PITCH + wv * 4;
+                for (int k = 0; k < NCOL; ++k) colv |= (unsigned)((cd[k].w >> 8) & 1) << k;
+                for (int q = lane; q < npix; q += 64) {
+                    const int img = (int)(((float)q + 0.5f) * inv_thw);
+                    const int rem = q - img * thw;
+                    const int tyy = (int)(((float)rem + 0.5f) * inv_tw);
+                    const int txx = rem - tyy * p.TW;
+                    const int n = n0 + img, ud = u0 + tyy, vd = v0 + txx;
+                    unsigned raw[NCOL];
+                    unsigned okm = 0;
+                    if (interior) {
+                        const unsigned pixbase = (unsigned)(n * p.creal) * bplane + (unsigned)((ud + p.b_y0) * p.BW + (vd + p.b_x0));
 #pragma unroll
-            for (int i = 0; i < NDW; ++i) {
-                unsigned w;
-                if constexpr (std::is_same<T, float>::value) {
-                    w = ((okm >> i) & 1u) ? raw[i] : 0u;
-                } else {
-                    unsigned l = raw[2 * i], h = raw[2 * i + 1];
-                    if (p.b_f32) { l = f2bf(__uint_as_float(l)); h = f2bf(__uint_as_float(h)); }
-                    w = (((okm >> (2 * i)) & 1u) ? l : 0u) | ((((okm >> (2 * i + 1)) & 1u) ? h : 0u) << 16);
+                        for (int k = 0; k < NCOL; ++k) {
+                            const unsigned off = pixbase + (unsigned)cd[k].x;
+                            if (std::is_same<T, float>::value || p.b_f32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
+                            else raw[k] = ((const bf16_t*)p.b)[off];
+                        }
+                        okm = colv;
+                    } else {
+                        const bool pix_ok = (n < p.N) && (ud < p.AH) && (vd < p.AW);
+#pragma unroll
+                        for (int k = 0; k < NCOL; ++k) {
+                            int yb = ud + p.b_y0 + cd[k].y;
+                            int xb = vd + p.b_x0 + cd[k].z;
+                            if (p.bmode == PAD_REFLECT) { yb = reflect_idx(yb, p.BH); xb = reflect_idx(xb, p.BW); }
+                            const bool ok = pix_ok && ((colv >> k) & 1u) && (unsigned)yb < (unsigned)p.BH && (unsigned)xb < (unsigned)p.BW;
+                            const unsigned off = ok ? ((unsigned)(n * p.creal + (cd[k].w & 0xff)) * bplane + (unsigned)(yb * p.BW + xb)) : 0u;
+                            if (std::is_same<T, float>::value || p.b_f32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
+                            else raw[k] = ((const bf16_t*)p.b)[off];
+                            okm |= (ok ? 1u : 0u) << k;
+                        }
+                    }
+                    unsigned char* row = bt + (size_t)q * PITCH + wv * 4;
+#pragma unroll
+                    for (int i = 0; i < NDW; ++i) {
+                        unsigned w;
+                        if constexpr (std::is_same<T, float>::value) {
+                            w = ((okm >> i) & 1u) ? raw[i] : 0u;
+                        } else {
+                            unsigned l = raw[2 * i], h = raw[2 * i + 1];
+                            if (p.b_f32) { l = f2bf(__uint_as_float(l)); h = f2bf(__uint_as_float(h)); }
+                            w = (((okm >> (2 * i)) & 1u) ? l : 0u) | ((((okm >> (2 * i + 1)) & 1u) ? h : 0u) << 16);
+                        }
+                        *(unsigned*)(row + i * 16) = w;
+                    }
                 }
-                *(unsigned*)(row + i * 16) = w;
-            }
-        }
-        __syncthreads();
-        for (int ks = 0; ks < npix / KS; ++ks) {
-            if constexpr (std::is_same<T, float>::value) {
-                const int r = ks * 2 + lhi;
-                const float a = *(const float*)(at + (size_t)r * PITCH + (wm * 32 + l31) * 4);
-                const float b = *(const float*)(bt + (size_t)r * PITCH + (wn * 32 + l31) * 4);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            } else {
-                const int g = lane >> 4, i16 = lane & 15;
-                const int rb = ks * 16 + (g >> 1) * 8 + (i16 >> 2);
-                const int colb = ((g & 1) * 16 + (i16 & 3) * 4) * 2;
-                typedef __attribute__((address_space(3))) short4_t* lds_s4;
-                typedef __attribute__((ext_vector_type(8))) short short8_t;
-                short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(at + (size_t)rb * PITCH + wm * 64 + colb));
-                short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(at + (size_t)(rb + 4) * PITCH + wm * 64 + colb));
-                short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(bt + (size_t)rb * PITCH + wn * 64 + colb));
-                short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(bt + (size_t)(rb + 4) * PITCH + wn * 64 + colb));
-                short8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                short8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av),
-                                                              __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
+                __syncthreads();
+                for (int ks = 0; ks < npix / KS; ++ks) {
+                    if constexpr (std::is_same<T, float>::value) {
+                        const int r = ks * 2 + lhi;
+                        const float a = *(const float*)(at + (size_t)r * PITCH + (wm * 32 + l31) * 4);
+                        const float b = *(const float*)(bt + (size_t)r * PITCH + (wn * 32 + l31) * 4);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ct], 0, 0, 0);
+                    } else {
+                        const int g = lane >> 4, i16 = lane & 15;
+                        const int rb = ks * 16 + (g >> 1) * 8 + (i16 >> 2);
+                        const int colb = ((g & 1) * 16 + (i16 & 3) * 4) * 2;
+                        typedef __attribute__((address_space(3))) short4_t* lds_s4;
+                        typedef __attribute__((ext_vector_type(8))) short short8_t;
+                        short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(at + (size_t)rb * PITCH + wm * 64 + colb));
+                        short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(at + (size_t)(rb + 4) * PITCH + wm * 64 + colb));
+                        short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(bt + (size_t)rb * PITCH + wn * 64 + colb));
+                        short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(bt + (size_t)(rb + 4) * PITCH + wn * 64 + colb));
+                        short8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                        short8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av),
+                                                                          __builtin_bit_cast(bf16x8_t, bv), acc[ct], 0, 0, 0);
+                    }
+                }
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const int c = c0 + wn * 32 + l31;
-        p.ws[((size_t)split * p.Mpad + m) * p.Cpad + c] = acc[r];
+    for (int ct = 0; ct < MAXCT; ++ct) {
+        if (ct < nct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int c = ct * 64 + wn * 32 + l31;
+                p.ws[((size_t)split * p.Mpad + m) * p.Cpad + c] = acc[ct][r];
+            }
+        }
     }
 }
 
@@ -1679,7 +1747,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                   64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(p.NI * p.ph[0].PH * p.ph[0].PW + 1) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
     }
     char kname[PROF_NAMELEN];
-    if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d>", bm / 64);
+    if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d>", bm / 64, env_int("HIFIC_SP9_KSPLIT", 2) == 2 ? 2 : 1);
     else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
                   bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
     const int pslot = prof_open(kname, aflops, st, ptag);
@@ -1697,13 +1765,15 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             const int npatch = p.NI * p.ph[0].PH * p.ph[0].PW;
             const size_t lds_sp = 64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(npatch + 1) * PITCH + 15) & ~(size_t)15);
             if (lds_sp <= (size_t)kLdsBudget) {
-                if (bm == 128) {
-                    hipFuncSetAttribute((const void*)gconv_sp9_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
-                    hipLaunchKernelGGL((gconv_sp9_kernel<2>), grid, dim3(256), lds_sp, st, p);
-                } else {
-                    hipFuncSetAttribute((const void*)gconv_sp9_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
-                    hipLaunchKernelGGL((gconv_sp9_kernel<1>), grid, dim3(256), lds_sp, st, p);
-                }
+                const bool ks2 = env_int("HIFIC_SP9_KSPLIT", 2) == 2;
+#define SP9_LAUNCH(WM_, KSP_)                                                                                       \
+    do {                                                                                                            \
+        hipFuncSetAttribute((const void*)gconv_sp9_kernel<WM_, KSP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp); \
+        hipLaunchKernelGGL((gconv_sp9_kernel<WM_, KSP_>), grid, dim3(256 * KSP_), lds_sp, st, p);                   \
+    } while (0)
+                if (bm == 128) { if (ks2) SP9_LAUNCH(2, 2); else SP9_LAUNCH(2, 1); }
+                else { if (ks2) SP9_LAUNCH(1, 2); else SP9_LAUNCH(1, 1); }
+#undef SP9_LAUNCH
                 sp_done = true;
             }
         }
@@ -2058,12 +2128,15 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
         }
         p.grp[0].dy_min = ymin; p.grp[0].dx_min = xmin; p.grp[0].PH = ymax; p.grp[0].PW = xmax;
     }
-    // pixel tile: 8 x 16 (whole 128-pixel K extent; multiple of 16 for the bf16 MFMA)
-    p.TW = p.AW < 16 ? p.AW : 16; p.TH = GC_NPIX / p.TW; if (p.TH > p.AH) p.TH = p.AH; p.NI = 1;
+    // pixel tile: 2 x 64 on wide planes (a 64-pixel bf16 row segment is a whole 128-byte line: 8x16 tiles made four
+    // neighbouring tiles share every line of the big operand and thrashed L2: FETCH_SIZE 1.14 GB per launch for a
+    // 126 MB tensor); 128 pixels = the whole K extent of a tile, multiple of 16 for the bf16 MFMA
+    p.TW = p.AW < 64 ? (p.AW < 16 ? p.AW : 16) : 64; p.TH = GC_NPIX / p.TW; if (p.TH > p.AH) p.TH = p.AH; p.NI = 1;
     while ((p.NI * p.TH * p.TW) % 16 != 0) ++p.TH;
     p.tiles_y = cdiv(p.AH, p.TH); p.tiles_x = cdiv(p.AW, p.TW); p.tiles_n = cdiv(p.N, p.NI);
     p.ntiles = p.tiles_n * p.tiles_y * p.tiles_x;
-    const int base_blocks = (p.Mpad / 64) * (p.Cpad / 64);
+    if (p.Cpad / 64 > 4) return HIFIC_ERR_UNSUPPORTED;             // one workgroup covers all (<= 256) virtual columns
+    const int base_blocks = p.Mpad / 64;
     int nsplit = cdiv(768, base_blocks);
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     p.tiles_per_split = cdiv(p.ntiles, nsplit);
@@ -2072,7 +2145,7 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     if (!p.ws) return HIFIC_ERR_WS;
     const long long RS = (long long)g.R * g.S;
     p.dw = dw; p.sm = (long long)g.C * RS; p.sc = RS; p.sr = g.S; p.ss = 1; p.accumulate = accumulate;
-    const size_t lds = 2 * (size_t)GC_NPIX * Cfg::PITCH;
+    const size_t lds = 4096 + 2 * (size_t)GC_NPIX * Cfg::PITCH;
     dim3 grid(base_blocks, 1, p.nsplit);
     auto kfn = wgrad_im2col_kernel<T>;
     if (lds > 48 * 1024)
