@@ -246,12 +246,40 @@ __global__ void upcat_bwd_ctx_kernel(const T* __restrict__ dout, T* __restrict__
 
 // ---- spectral norm (one power iteration, torch.nn.utils.spectral_norm semantics) --------------------
 // W: [K, M] row-major f32.  step 1: vraw[m] = sum_k W[k,m] u[k]
+// The K rows are cut into slices of SN_ROWS (blockIdx.y): all loads of a thread are independent and issued together,
+// and the grid has K/16 times more blocks (a per-column loop over all K rows was one latency chain per thread on
+// M/256 <= 32 blocks: 94-200 us for a 2-8 MB matrix).  part[slice][m]; sn_colsum_kernel adds the slices in order.
+#define SN_ROWS 16
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ W, const float* __restrict__ u,
-                                                     float* __restrict__ vraw, int K, int M) {
+                                                     float* __restrict__ part, int K, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int k0 = blockIdx.y * SN_ROWS;
+    float w[SN_ROWS];
+#pragma unroll
+    for (int j = 0; j < SN_ROWS; ++j) {
+        const int k = k0 + j < K ? k0 + j : K - 1;
+        w[j] = W[(size_t)k * M + m];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < SN_ROWS; ++j) s += (k0 + j < K) ? w[j] * u[k0 + j] : 0.f;
+    part[(size_t)blockIdx.y * M + m] = s;
+}
+__global__ __launch_bounds__(256) void sn_colsum_kernel(const float* __restrict__ part, float* __restrict__ vraw,
+                                                        int nslice, int M) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     float s = 0.f;
-    for (int k = 0; k < K; ++k) s += W[(size_t)k * M + m] * u[k];
+    int j = 0;
+    for (; j + 8 <= nslice; j += 8) {
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = part[(size_t)(j + q) * M + m];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += t[q];
+    }
+    for (; j < nslice; ++j) s += part[(size_t)j * M + m];
     vraw[m] = s;
 }
 // x <- x / max(||x||, eps)   (single block)
@@ -482,7 +510,11 @@ int hific_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma_out
     float* tmpM = (float*)ws;
     float* tmpK = tmpM + M;
     if (do_iter) {
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, W, u, tmpM, K, M);
+        const int nslice = cdiv(K, SN_ROWS);
+        float* part = tmpK + K;
+        if (((size_t)M + K + (size_t)nslice * M) * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(cdiv(M, 256), nslice), dim3(256), 0, st, W, u, part, K, M);
+        hipLaunchKernelGGL(sn_colsum_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, part, tmpM, nslice, M);
         hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, tmpM, v, M, eps);
         hipLaunchKernelGGL(sn_wv_kernel, dim3(K), dim3(256), 0, st, W, v, tmpK, K, M);
         hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, tmpK, u, K, eps);

@@ -133,6 +133,84 @@ __device__ __forceinline__ void stage_T(unsigned char* lds, const void* src, int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Epilogue shared by the forward-type kernels: bias + residual + activation, NCHW store (32 consecutive pixels per
+// store instruction).  Everything that needs a LOAD is issued unconditionally up front: a load inside a (even
+// wave-uniform) branch makes hipcc wait `vmcnt(0)` right behind it, and the per-element `if (p.bias) v += p.bias[m]`
+// this replaces was 16*WM*WN serialised L2 round trips at the end of every workgroup (~10 us on a 90 us launch).
+// NI_ONLY >= 0: this wave writes only that pixel fragment (K-split kernels).
+// ---------------------------------------------------------------------------------------------------
+template <bool TF32, int WM, int WN>
+__device__ __forceinline__ void gc_epilogue(const GcParams& p, const GcPhase& ph, f32x16_t (&acc)[WM][WN], int mbase,
+                                            int lhi, const int (&pu)[WN], const int (&pv)[WN], const int (&pn)[WN],
+                                            const bool (&pvalid)[WN], int ni_only) {
+    const bool out_f32 = TF32 || p.out_f32;
+    const bool hb = p.bias != nullptr;
+    const float* bp = hb ? p.bias : (const float*)p.in;          // always a readable address; masked below
+    float bv[WM][16];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            bv[mi][r] = bp[(hb && m < p.K) ? m : 0];
+        }
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            bv[mi][r] = (hb && m < p.K) ? bv[mi][r] : 0.f;
+        }
+    const float slope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LEAKY ? 0.2f : 1.f);
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        if (ni_only >= 0 && ni != ni_only) continue;
+        const int oy = pu[ni] * p.ost + ph.ooy, ox = pv[ni] * p.ost + ph.oox;
+        const bool okp = pvalid[ni] && pn[ni] < p.N && pu[ni] < ph.OHt && pv[ni] < ph.OWt &&
+                         (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
+        if (!okp) continue;
+        size_t plane = (size_t)p.OHf * p.OWf;
+        size_t pbase = (size_t)pn[ni] * p.K * plane + (size_t)oy * p.OWf + ox;
+        void* optr = p.out;
+        bool of32 = out_f32;
+        if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
+            const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
+            if ((unsigned)iy < (unsigned)p.fold_h && (unsigned)ix < (unsigned)p.fold_w) {
+                plane = (size_t)p.fold_h * p.fold_w;
+                pbase = (size_t)pn[ni] * p.K * plane + (size_t)iy * p.fold_w + ix;
+                optr = p.out2; of32 = TF32 || p.out2_f32;
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r] + bv[mi][r];
+            if (p.resid) {          // rare path (no caller on the HiFIC graph fuses a residual): loads batched per fragment
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const size_t idx = pbase + (size_t)(m < p.K ? m : 0) * plane;
+                    rv[r] = out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += rv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const float y = v[r] > 0.f ? v[r] : v[r] * slope;
+                if (m < p.K) {
+                    const size_t idx = pbase + (size_t)m * plane;
+                    if (of32) ((float*)optr)[idx] = y; else ((bf16_t*)optr)[idx] = f2bf(y);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Forward-type kernel
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int BC, int WGM, int WGN, int WM, int WN>
@@ -321,43 +399,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
 #undef GC_WSTORE
 #undef GC_WLOAD
 
-    // epilogue: bias + residual + activation, NCHW store (32 consecutive pixels per store instruction)
-    const bool out_f32 = std::is_same<T, float>::value || p.out_f32;
-#pragma unroll
-    for (int ni = 0; ni < WN; ++ni) {
-        const int oy = pu[ni] * p.ost + ph.ooy, ox = pv[ni] * p.ost + ph.oox;
-        const bool okp = pvalid[ni] && pn[ni] < p.N && pu[ni] < ph.OHt && pv[ni] < ph.OWt &&
-                         (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
-        if (!okp) continue;
-        size_t plane = (size_t)p.OHf * p.OWf;
-        size_t pbase = (size_t)pn[ni] * p.K * plane + (size_t)oy * p.OWf + ox;
-        void* optr = p.out;
-        bool of32 = out_f32;
-        if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
-            const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
-            if ((unsigned)iy < (unsigned)p.fold_h && (unsigned)ix < (unsigned)p.fold_w) {
-                plane = (size_t)p.fold_h * p.fold_w;
-                pbase = (size_t)pn[ni] * p.K * plane + (size_t)iy * p.fold_w + ix;
-                optr = p.out2; of32 = std::is_same<T, float>::value || p.out2_f32;
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < p.K) {
-                    float v = acc[mi][ni][r];
-                    if (p.bias) v += p.bias[m];
-                    const size_t idx = pbase + (size_t)m * plane;
-                    if (p.resid) v += out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
-                    if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-                    else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
-                    if (of32) ((float*)optr)[idx] = v; else ((bf16_t*)optr)[idx] = f2bf(v);
-                }
-            }
-        }
-    }
+    gc_epilogue<std::is_same<T, float>::value, WM, WN>(p, ph, acc, m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid, -1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -602,43 +644,7 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
                 for (int r = 0; r < 16; ++r) acc[mi][1][r] += theirs[(mi * 16 + r) * 64];
         }
     }
-    const bool out_f32 = p.out_f32;
-#pragma unroll
-    for (int ni = 0; ni < WN; ++ni) {
-        if (KSP == 2 && ni != kgrp) continue;
-        const int oy = pu[ni] * p.ost + ph.ooy, ox = pv[ni] * p.ost + ph.oox;
-        const bool okp = pvalid[ni] && pn[ni] < p.N && pu[ni] < ph.OHt && pv[ni] < ph.OWt &&
-                         (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
-        if (!okp) continue;
-        size_t plane = (size_t)p.OHf * p.OWf;
-        size_t pbase = (size_t)pn[ni] * p.K * plane + (size_t)oy * p.OWf + ox;
-        void* optr = p.out;
-        bool of32 = out_f32;
-        if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
-            const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
-            if ((unsigned)iy < (unsigned)p.fold_h && (unsigned)ix < (unsigned)p.fold_w) {
-                plane = (size_t)p.fold_h * p.fold_w;
-                pbase = (size_t)pn[ni] * p.K * plane + (size_t)iy * p.fold_w + ix;
-                optr = p.out2; of32 = p.out2_f32 != 0;
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < p.K) {
-                    float v = acc[mi][ni][r];
-                    if (p.bias) v += p.bias[m];
-                    const size_t idx = pbase + (size_t)m * plane;
-                    if (p.resid) v += out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
-                    if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-                    else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
-                    if (of32) ((float*)optr)[idx] = v; else ((bf16_t*)optr)[idx] = f2bf(v);
-                }
-            }
-        }
-    }
+    gc_epilogue<false, WM, WN>(p, ph, acc, m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid, KSP == 2 ? kgrp : -1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1243,7 +1249,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
 //   swapped : D[c][(t,m)]  = sum_pix' A'[c][pix'] * B'[m][pix' - tap_t]    (A' = padded x over the padded domain,
 //             B' = dY zero outside) -- used when dY is the small operand
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool BF32>
 __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
     using Cfg = WgCfg<T>;
     constexpr int PITCH = Cfg::PITCH, KS = Cfg::KS, DWR = Cfg::DWR, NDW = DWR / 4;
@@ -1332,7 +1338,7 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
 #pragma unroll
                         for (int k = 0; k < NCOL; ++k) {
                             const unsigned off = pixbase + (unsigned)cd[k].x;
-                            if (std::is_same<T, float>::value || p.b_f32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
+                            if constexpr (BF32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
                             else raw[k] = ((const bf16_t*)p.b)[off];
                         }
                         okm = colv;
@@ -1345,7 +1351,7 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
                             if (p.bmode == PAD_REFLECT) { yb = reflect_idx(yb, p.BH); xb = reflect_idx(xb, p.BW); }
                             const bool ok = pix_ok && ((colv >> k) & 1u) && (unsigned)yb < (unsigned)p.BH && (unsigned)xb < (unsigned)p.BW;
                             const unsigned off = ok ? ((unsigned)(n * p.creal + (cd[k].w & 0xff)) * bplane + (unsigned)(yb * p.BW + xb)) : 0u;
-                            if (std::is_same<T, float>::value || p.b_f32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
+                            if constexpr (BF32) raw[k] = __float_as_uint(((const float*)p.b)[off]);
                             else raw[k] = ((const bf16_t*)p.b)[off];
                             okm |= (ok ? 1u : 0u) << k;
                         }
@@ -1358,7 +1364,7 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
                             w = ((okm >> i) & 1u) ? raw[i] : 0u;
                         } else {
                             unsigned l = raw[2 * i], h = raw[2 * i + 1];
-                            if (p.b_f32) { l = f2bf(__uint_as_float(l)); h = f2bf(__uint_as_float(h)); }
+                            if constexpr (BF32) { l = f2bf(__uint_as_float(l)); h = f2bf(__uint_as_float(h)); }
                             w = (((okm >> (2 * i)) & 1u) ? l : 0u) | ((((okm >> (2 * i + 1)) & 1u) ? h : 0u) << 16);
                         }
                         *(unsigned*)(row + i * 16) = w;
@@ -1747,7 +1753,8 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                   64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(p.NI * p.ph[0].PH * p.ph[0].PW + 1) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
     }
     char kname[PROF_NAMELEN];
-    if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d>", bm / 64, env_int("HIFIC_SP9_KSPLIT", 2) == 2 ? 2 : 1);
+    if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d>", bm / 64,
+                          (env_int("HIFIC_SP9_KSPLIT", 2) == 2 && (bm == 128 || env_int("HIFIC_SP9_KSPLIT64", 0))) ? 2 : 1);
     else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
                   bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
     const int pslot = prof_open(kname, aflops, st, ptag);
@@ -1772,7 +1779,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         hipLaunchKernelGGL((gconv_sp9_kernel<WM_, KSP_>), grid, dim3(256 * KSP_), lds_sp, st, p);                   \
     } while (0)
                 if (bm == 128) { if (ks2) SP9_LAUNCH(2, 2); else SP9_LAUNCH(2, 1); }
-                else { if (ks2) SP9_LAUNCH(1, 2); else SP9_LAUNCH(1, 1); }
+                else { if (ks2 && env_int("HIFIC_SP9_KSPLIT64", 0)) SP9_LAUNCH(1, 2); else SP9_LAUNCH(1, 1); }
 #undef SP9_LAUNCH
                 sp_done = true;
             }
@@ -2147,7 +2154,8 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     p.dw = dw; p.sm = (long long)g.C * RS; p.sc = RS; p.sr = g.S; p.ss = 1; p.accumulate = accumulate;
     const size_t lds = 4096 + 2 * (size_t)GC_NPIX * Cfg::PITCH;
     dim3 grid(base_blocks, 1, p.nsplit);
-    auto kfn = wgrad_im2col_kernel<T>;
+    void (*kfn)(const WgParams) = (std::is_same<T, float>::value || p.b_f32) ? wgrad_im2col_kernel<T, true>
+                                                                              : wgrad_im2col_kernel<T, false>;
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     char ptag[112];
