@@ -97,7 +97,11 @@ __device__ __forceinline__ void px_decode(int q, int npatch, int npp, int PW, fl
     qoff = ok ? ((unsigned)n * (unsigned)C * (unsigned)(H * W) + (unsigned)iy * (unsigned)W + (unsigned)ix) : 0u;
 }
 
-template <typename T, int DWR, int PITCH, bool SF32>
+// QB = patch pixels per lane whose loads are issued back-to-back before the first LDS store.  QB = 1 is one memory
+// round trip per 64 pixels (a 645-pixel stride-2 halo patch = 11 serialised round trips per channel chunk: measured
+// 166 of the 198 us of the 60->120 stride-2 layer).  Kernels that run one workgroup per CU anyway (full-LDS tiles)
+// have 512 VGPRs per lane to spend and use QB = 12: up to 768 pixels x 16 loads in flight, one round trip per chunk.
+template <typename T, int DWR, int PITCH, bool SF32, int QB>
 __device__ __forceinline__ void stage_T_impl(unsigned char* lds, const void* src, int N, int C, int H, int W, int bmode,
                                              int n0, int NI, int y0, int x0, int PH, int PW, int c0, int tid, int PWs) {
     // Thread (lane, wave) handles patch pixels q = lane + 64*j and dwords dw = wave + 4*i: the pixel is decoded once
@@ -112,24 +116,30 @@ __device__ __forceinline__ void stage_T_impl(unsigned char* lds, const void* src
     const int lane = tid & 63, wv = tid >> 6;
     const float inv_npp = 1.0f / (float)npp, inv_pw = 1.0f / (float)PW;
     const bool full = c0 + BCH <= C;
-    for (int q = lane; q < npatch; q += 64) {
-        unsigned qoff; bool ok; int qs;
-        px_decode(q, npatch, npp, PW, inv_npp, inv_pw, n0, y0, x0, N, C, H, W, bmode, qoff, ok, PWs, qs);
-        unsigned lo[NDW], hi[NDW];
-        px_load<T, NDW, SF32>(lo, hi, src, qoff, plane, C, c0, wv, full);
-        px_store<T, NDW, SF32>(lds + (size_t)qs * PITCH + wv * 4, lo, hi, ok, C, c0, wv, full);
+    for (int q0 = lane; q0 < npatch; q0 += 64 * QB) {
+        unsigned qoff[QB]; bool ok[QB]; int qs[QB];
+        unsigned lo[QB][NDW], hi[QB][NDW];
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+            px_decode(q0 + 64 * b, npatch, npp, PW, inv_npp, inv_pw, n0, y0, x0, N, C, H, W, bmode, qoff[b], ok[b], PWs, qs[b]);
+#pragma unroll
+        for (int b = 0; b < QB; ++b) px_load<T, NDW, SF32>(lo[b], hi[b], src, qoff[b], plane, C, c0, wv, full);
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+            if (QB == 1 || q0 + 64 * b < npatch)
+                px_store<T, NDW, SF32>(lds + (size_t)qs[b] * PITCH + wv * 4, lo[b], hi[b], ok[b], C, c0, wv, full);
     }
 }
-template <typename T, int DWR, int PITCH>
+template <typename T, int DWR, int PITCH, int QB = 1>
 __device__ __forceinline__ void stage_T(unsigned char* lds, const void* src, int src_f32,
                                         int N, int C, int H, int W, int bmode,
                                         int n0, int NI, int y0, int x0, int PWs, int PH, int PW,
                                         int c0, int tid, int nthreads) {
     if (PWs < PW) PWs = PW;
     if (std::is_same<T, float>::value || src_f32)
-        stage_T_impl<T, DWR, PITCH, true>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
+        stage_T_impl<T, DWR, PITCH, true, QB>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
     else
-        stage_T_impl<T, DWR, PITCH, false>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
+        stage_T_impl<T, DWR, PITCH, false, QB>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -213,8 +223,9 @@ __device__ __forceinline__ void gc_epilogue(const GcParams& p, const GcPhase& ph
 // ---------------------------------------------------------------------------------------------------
 // Forward-type kernel
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int BC, int WGM, int WGN, int WM, int WN>
-__global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
+template <typename T, int BC, int WGM, int WGN, int WM, int WN, int QB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, QB > 1 ? 1 : 2)))
+void gconv_kernel(const GcParams p) {
     using Cfg = GcCfg<T>;
     constexpr int KS = Cfg::KS;
     constexpr int ROWB = BC * (int)sizeof(T);          // bytes of one LDS row (BC channels)
@@ -372,8 +383,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GcParams p) {
     do {                                                                                    \
         if (t == 0 && !((p.dbg & 1) && chunk > 0)) {                                        \
             __syncthreads();                                                                \
-            stage_T<T, DWR, PITCH>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode,    \
-                                   n0, p.NI, iy0, ix0, PWs, PH, PW, chunk * BC, tid, 256);    \
+            stage_T<T, DWR, PITCH, QB>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode, \
+                                       n0, p.NI, iy0, ix0, PWs, PH, PW, chunk * BC, tid, 256);  \
         }                                                                                   \
         if (!(p.dbg & 16)) __syncthreads();                                                 \
         if (!(p.dbg & 4)) GC_WLOAD(RL, (s) + 2);                                            \
@@ -834,8 +845,9 @@ template <typename T> struct WgCfg;
 template <> struct WgCfg<bf16_t> { static constexpr int DWR = 32, PITCH = 144, KS = 16; };
 template <> struct WgCfg<float>  { static constexpr int DWR = 64, PITCH = 260, KS = 2; };
 
-template <typename T>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
+template <typename T, int QB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, QB > 1 ? 1 : 2)))
+void wgrad_kernel(const WgParams p) {
     using Cfg = WgCfg<T>;
     constexpr int PITCH = Cfg::PITCH, KS = Cfg::KS, DWR = Cfg::DWR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -890,11 +902,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgParams p) {
         const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
         __syncthreads();
         if (!(p.dbg & 1))
-        stage_T<T, DWR, PITCH>(at, p.a, p.a_f32, p.N, p.M, p.AH, p.AW, PAD_ZERO,
-                               n0, p.NI, u0, v0, 0, p.TH, p.TW, m0, tid, 256);
+        stage_T<T, DWR, PITCH, QB>(at, p.a, p.a_f32, p.N, p.M, p.AH, p.AW, PAD_ZERO,
+                                   n0, p.NI, u0, v0, 0, p.TH, p.TW, m0, tid, 256);
         if (!(p.dbg & 2))
-        stage_T<T, DWR, PITCH>(patch, p.b, p.b_f32, p.N, p.C, p.BH, p.BW, p.bmode,
-                               n0, p.NI, u0 * p.ist + gp.dy_min, v0 * p.ist + gp.dx_min, 0, PH, PW, c0, tid, 256);
+        stage_T<T, DWR, PITCH, QB>(patch, p.b, p.b_f32, p.N, p.C, p.BH, p.BW, p.bmode,
+                                   n0, p.NI, u0 * p.ist + gp.dy_min, v0 * p.ist + gp.dx_min, 0, PH, PW, c0, tid, 256);
         __syncthreads();
         for (int ks = 0; ks < ((p.dbg & 4) ? 0 : npix / KS); ++ks) {
             if constexpr (std::is_same<T, float>::value) {
@@ -1758,9 +1770,13 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
                   bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
     const int pslot = prof_open(kname, aflops, st, ptag);
+    // full-LDS tiles run one workgroup per CU: the staging variant with all of a chunk's loads in flight (QB = 12)
+    constexpr bool kBigStage = std::is_same<T, bf16_t>::value && BC == 64;
+    const bool bigstage = kBigStage && tiled && lds > 80 * 1024 && !env_int("HIFIC_NO_BIGSTAGE", 0);
 #define GC_LAUNCH(WGM, WGN, WM, WN)                                                                      \
     do {                                                                                                 \
-        auto kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN>;                                                \
+        void (*kfn)(const GcParams) = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1>;                          \
+        if constexpr (kBigStage) { if (bigstage) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 12>; }      \
         if (lds > 48 * 1024)                                                                             \
             hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);                                            \
@@ -1991,8 +2007,12 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
         if (gp.PW > span_x) span_x = gp.PW;
     }
     const int fixed = 512 + GC_NPIX * Cfg::PITCH;
-    if (!choose_tile(p.N, p.AH, p.AW, p.ist, span_y, span_x, Cfg::PITCH, fixed, 72 * 1024, p.TH, p.TW, p.NI,
-                     p.ntaps < GC_TG ? p.ntaps : GC_TG, true)) {
+    // bf16: whole-LDS pixel tiles, one workgroup per CU, every load of a tile in flight at once (stage_T QB = 12); the
+    // alternative (two co-resident workgroups on half-size tiles, one round trip per 64 patch pixels) measured
+    // 170 of 274 us in staging on the 60->120 stride-2 layer
+    const bool bigstage = std::is_same<T, bf16_t>::value && !env_int("HIFIC_NO_BIGSTAGE", 0);
+    if (!choose_tile(p.N, p.AH, p.AW, p.ist, span_y, span_x, Cfg::PITCH, fixed, bigstage ? kLdsBudget : 72 * 1024,
+                     p.TH, p.TW, p.NI, p.ntaps < GC_TG ? p.ntaps : GC_TG, true)) {
         // tiny odd planes: fall back to a (masked) 16-pixel-multiple tile wider than the plane
         p.TW = 16; p.TH = p.AH < 8 ? p.AH : 8; p.NI = 1;
         while ((p.TH * p.TW) % 16 != 0) ++p.TH;
@@ -2053,7 +2073,8 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
         }
     }
     if (!pipe) {
-        auto kfn = wgrad_kernel<T>;
+        void (*kfn)(const WgParams) = wgrad_kernel<T, 1>;
+        if constexpr (std::is_same<T, bf16_t>::value) { if (bigstage) kfn = wgrad_kernel<T, 12>; }
         if (lds > 48 * 1024)
             hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
