@@ -224,7 +224,7 @@ __device__ __forceinline__ void gc_epilogue(const GcParams& p, const GcPhase& ph
 // Forward-type kernel
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int BC, int WGM, int WGN, int WM, int WN, int QB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, QB > 1 ? 1 : 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB > 1 ? 1 : 2, QB > 1 ? 1 : 8)))
 void gconv_kernel(const GcParams p) {
     using Cfg = GcCfg<T>;
     constexpr int KS = Cfg::KS;
@@ -381,7 +381,7 @@ void gconv_kernel(const GcParams p) {
     // step s: RL = register set that receives tile s+2, RS = register set holding tile s+1
 #define GC_STEP(s, RL, RS)                                                                  \
     do {                                                                                    \
-        if (t == 0 && !((p.dbg & 1) && chunk > 0)) {                                        \
+        if (t == 0 && !((p.dbg & 1) && chunk > 0) && !(p.dbg & 64)) {                       \
             __syncthreads();                                                                \
             stage_T<T, DWR, PITCH, QB>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode, \
                                        n0, p.NI, iy0, ix0, PWs, PH, PW, chunk * BC, tid, 256);  \
@@ -410,6 +410,10 @@ void gconv_kernel(const GcParams p) {
 #undef GC_WSTORE
 #undef GC_WLOAD
 
+    if (p.dbg & 32) {      // ablation: no epilogue (one never-taken store keeps the accumulators alive)
+        if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = acc[0][0][1];
+        return;
+    }
     gc_epilogue<std::is_same<T, float>::value, WM, WN>(p, ph, acc, m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid, -1);
 }
 
@@ -846,7 +850,7 @@ template <> struct WgCfg<bf16_t> { static constexpr int DWR = 32, PITCH = 144, K
 template <> struct WgCfg<float>  { static constexpr int DWR = 64, PITCH = 260, KS = 2; };
 
 template <typename T, int QB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, QB > 1 ? 1 : 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB > 1 ? 1 : 2, QB > 1 ? 1 : 8)))
 void wgrad_kernel(const WgParams p) {
     using Cfg = WgCfg<T>;
     constexpr int PITCH = Cfg::PITCH, KS = Cfg::KS, DWR = Cfg::DWR;
@@ -1772,7 +1776,9 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     const int pslot = prof_open(kname, aflops, st, ptag);
     // full-LDS tiles run one workgroup per CU: the staging variant with all of a chunk's loads in flight (QB = 12)
     constexpr bool kBigStage = std::is_same<T, bf16_t>::value && BC == 64;
-    const bool bigstage = kBigStage && tiled && lds > 80 * 1024 && !env_int("HIFIC_NO_BIGSTAGE", 0);
+    // measured (round 2): slower than two co-resident workgroups with one round trip per 64 pixels (the phases of one
+    // workgroup overlap the other's) - kept as an opt-in experiment
+    const bool bigstage = kBigStage && tiled && lds > 80 * 1024 && env_int("HIFIC_BIGSTAGE", 0);
 #define GC_LAUNCH(WGM, WGN, WM, WN)                                                                      \
     do {                                                                                                 \
         void (*kfn)(const GcParams) = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1>;                          \
@@ -2007,10 +2013,9 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
         if (gp.PW > span_x) span_x = gp.PW;
     }
     const int fixed = 512 + GC_NPIX * Cfg::PITCH;
-    // bf16: whole-LDS pixel tiles, one workgroup per CU, every load of a tile in flight at once (stage_T QB = 12); the
-    // alternative (two co-resident workgroups on half-size tiles, one round trip per 64 patch pixels) measured
-    // 170 of 274 us in staging on the 60->120 stride-2 layer
-    const bool bigstage = std::is_same<T, bf16_t>::value && !env_int("HIFIC_NO_BIGSTAGE", 0);
+    // Two co-resident workgroups on half-LDS tiles (the kernels are register-capped at 256 for it) beat whole-LDS
+    // tiles with every load of a tile in flight (stage_T QB = 12): 4.3 vs 6.3 ms per GAN cycle over the strided layers.
+    const bool bigstage = std::is_same<T, bf16_t>::value && env_int("HIFIC_BIGSTAGE", 0);       // opt-in: measured slower
     if (!choose_tile(p.N, p.AH, p.AW, p.ist, span_y, span_x, Cfg::PITCH, fixed, bigstage ? kLdsBudget : 72 * 1024,
                      p.TH, p.TW, p.NI, p.ntaps < GC_TG ? p.ntaps : GC_TG, true)) {
         // tiny odd planes: fall back to a (masked) 16-pixel-multiple tile wider than the plane
