@@ -433,7 +433,13 @@ void gconv_kernel(const GcParams p) {
 // KSP = 2: 8 waves; waves 4-7 mirror waves 0-3 on the same output tile but take the upper half of every 64-channel
 // chunk's reduction (two waves per SIMD hide each other's LDS/barrier latency at unchanged LDS bytes per MFMA); the
 // two partial accumulators are exchanged through LDS at the end and each half writes half of the tile.
-template <int WM, int KSP>
+// RFX = true: data gradient of a REFLECT-padded 3x3 stride-1 convolution in gather form, on the un-padded output
+// domain.  `in` is the extended gradient E[N,K,H+2,W+2] (reflect_extend_kernel: rows/columns 1..H are dY, row 0 =
+// dY[0]+dY[2], row H+1 = dY[H-3]+dY[H-1], likewise columns); tap (r,s) of output pixel (i,j) reads E[i+2-r][j+2-s],
+// except that the pixels of rows/columns 1 and H-2 take the summed border line for the outermost tap and the pixels
+// of rows/columns 0 and H-1 read zero there (the reflection's adjoint folded into per-lane tap offsets).  No padded
+// 18x18 domain (27 % extra MFMA work, 1.5 waves of workgroups), no rim buffer, no fold kernel.
+template <int WM, int KSP, bool RFX>
 __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2))) void gconv_sp9_kernel(const GcParams p) {
     typedef bf16_t T;
     constexpr int BC = 64, KS = 16, PITCH = 144, PPR = 8, WGN = 2, WN = 2, NT = 9, QJ = 3;
@@ -473,13 +479,15 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
     const int npp = PH * PW;
     const int npatch = p.NI * npp;
     const int iy0 = u0 * p.ist + ph.dy_min, ix0 = v0 * p.ist + ph.dx_min;
-    const unsigned patch_bytes = (unsigned)(((size_t)(npatch + 1) * PITCH + 15) & ~(size_t)15);   // + dump row
+    const unsigned patch_bytes = (unsigned)(((size_t)(npatch + 2) * PITCH + 15) & ~(size_t)15);   // + dump row + zero row
 
     int* toffs = (int*)smem;                                   // [16] byte offset of each tap inside the patch
     unsigned char* wbuf = smem + 64;                           // 3 x WBYTES
     unsigned char* pbuf = wbuf + 3 * WBYTES;                   // 2 x patch_bytes
     if (tid < NT)
         toffs[tid] = (((int)p.tap_dy[tid] - ph.dy_min) * PW + ((int)p.tap_dx[tid] - ph.dx_min)) * PITCH;
+    if (RFX && tid < 2 * (PITCH / 4))                          // the all-zero pixel row of both patch buffers
+        *(unsigned*)(pbuf + (tid / (PITCH / 4)) * patch_bytes + (size_t)(npatch + 1) * PITCH + (tid % (PITCH / 4)) * 4) = 0u;
 
     // static patch pixels of this thread
     unsigned qoff[QJ], pdst[QJ];
@@ -513,6 +521,20 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
     const unsigned arow = (unsigned)((wm * WM * 32 + l31) * PITCH + lhi * 16);
     const int kgrp_k0 = kgrp * (BC / KS / KSP);                 // first 16-deep reduction slice of this wave's half
+    // RFX: per-lane byte displacement of the patch row / column read by tap row r / tap column s (RFX_ZERO: reads 0)
+    constexpr int RFX_ZERO = -(1 << 28);
+    int rfx_r[WN][3], rfx_c[WN][3];
+    const unsigned rfx_zrow = (unsigned)((npatch + 1) * PITCH + lhi * 16);
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int i = pu[ni], j = pv[ni], H = p.OHf, W = p.OWf;
+        rfx_r[ni][0] = !RFX ? 0 : (i == 1 ? -3 * PW * PITCH : (i == H - 1 ? RFX_ZERO : 0));
+        rfx_r[ni][1] = 0;
+        rfx_r[ni][2] = !RFX ? 0 : (i == H - 2 ? 3 * PW * PITCH : (i == 0 ? RFX_ZERO : 0));
+        rfx_c[ni][0] = !RFX ? 0 : (j == 1 ? -3 * PITCH : (j == W - 1 ? RFX_ZERO : 0));
+        rfx_c[ni][1] = 0;
+        rfx_c[ni][2] = !RFX ? 0 : (j == W - 2 ? 3 * PITCH : (j == 0 ? RFX_ZERO : 0));
+    }
 
     f32x16_t acc[WM][WN];
 #pragma unroll
@@ -584,13 +606,20 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
     do {                                                                                                        \
         const unsigned toff = (unsigned)toffs[tt];                                                              \
         const unsigned char* ab = wbuf + (SLOT) * WBYTES + arow;                                                \
+        unsigned bo[WN];                                                                                        \
+        _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                                     \
+            if constexpr (RFX) {   /* taps are enumerated r-major: r = tt / 3, s = tt % 3 */                    \
+                const int d_ = rfx_r[ni][(tt) / 3] + rfx_c[ni][(tt) % 3];                                       \
+                bo[ni] = d_ < RFX_ZERO / 2 ? rfx_zrow : (unsigned)((int)(brow[ni] + toff) + d_);                \
+            } else bo[ni] = brow[ni] + toff;                                                                    \
+        }                                                                                                       \
         _Pragma("unroll") for (int kq = 0; kq < BC / KS / KSP; ++kq) {                                          \
             const int kk = kq + kgrp_k0;                                                                        \
             bf16x8_t a[WM], b[WN];                                                                              \
             _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
                 a[mi] = *(const bf16x8_t*)(ab + mi * 32 * PITCH + kk * 32);                                     \
             _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                                   \
-                b[ni] = *(const bf16x8_t*)(pcur + brow[ni] + toff + kk * 32);                                   \
+                b[ni] = *(const bf16x8_t*)(pcur + bo[ni] + kk * 32);                                            \
             _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
                 _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                               \
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);  \
@@ -1523,6 +1552,31 @@ __global__ void wgrad_finalize_kernel(const WgParams p, float* __restrict__ dw, 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Extended gradient for the gather-form reflect data gradient (gconv_sp9_kernel RFX): E[pc][e][f], e in [0, H+2),
+// f in [0, W+2); row sets {0,2}, {e-1}, {H-3,H-1}; column sets likewise; E = sum over the row set x column set.
+// ---------------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ void reflect_extend_kernel(const TI* __restrict__ dy, bf16_t* __restrict__ E, unsigned planes, int H, int W) {
+    const int He = H + 2, We = W + 2;
+    const unsigned total = planes * (unsigned)(He * We);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned pc = idx / (unsigned)(He * We);
+        const int rem = (int)(idx - pc * (unsigned)(He * We));
+        const int e = rem / We, f = rem - e * We;
+        const int y0 = e == 0 ? 0 : (e == H + 1 ? H - 3 : e - 1), y1 = e == 0 ? 2 : (e == H + 1 ? H - 1 : y0);
+        const int x0 = f == 0 ? 0 : (f == W + 1 ? W - 3 : f - 1), x1 = f == 0 ? 2 : (f == W + 1 ? W - 1 : x0);
+        const TI* s = dy + (size_t)pc * H * W;
+        // all four loads unconditional (duplicates where a set has one element), masked in the sum
+        const float a = DT<TI>::ld(s + y0 * W + x0), b = DT<TI>::ld(s + y0 * W + x1);
+        const float c = DT<TI>::ld(s + y1 * W + x0), d = DT<TI>::ld(s + y1 * W + x1);
+        float v = a;
+        if (x1 != x0) v += b;
+        if (y1 != y0) { v += c; if (x1 != x0) v += d; }
+        E[idx] = f2bf(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Optional in-library profiler: HIP event pairs around every GEMM-class launch (on the launch stream), keyed by
 // kernel kind, with the algorithmic FLOPs of each launch.  Used by bench.py for the live roofline figure.
 // ---------------------------------------------------------------------------------------------------
@@ -1720,6 +1774,19 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         if (b > lds) lds = b;
     }
     if (lds > (size_t)kLdsBudget) return HIFIC_ERR_UNSUPPORTED;
+    // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, bf16 input, halo patch <= 192 pixels
+    bool use_sp9 = false;
+    if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
+        use_sp9 = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 &&
+                  p.NI * p.ph[0].PH * p.ph[0].PW <= 192 && !env_int("HIFIC_NO_SP", 0) &&
+                  64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(p.NI * p.ph[0].PH * p.ph[0].PW + 2) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
+    }
+    if (p.rfx) {
+        // gather-form reflect gradient: only gconv_sp9_kernel implements the per-lane tap displacements, and the border
+        // lines a pixel needs must lie in its own tile's patch: rows/cols {0,1} and {H-2,H-1} never split across tiles
+        const bool ok = use_sp9 && p.NI == 1 && p.TH >= 2 && p.TW >= 2 && (p.OHf - 1) % p.TH != 0 && (p.OWf - 1) % p.TW != 0;
+        if (!ok) return HIFIC_ERR_UNSUPPORTED;
+    }
     void* wp = ws.take((size_t)(wp_elems > 0 ? wp_elems : 1) * sizeof(T));
     if (!wp) return HIFIC_ERR_WS;
     p.wp = wp;
@@ -1762,15 +1829,11 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     snprintf(ptag, sizeof(ptag), "gconv K%d C%d N%d in%dx%d out%dx%d ph%d taps%d ist%d ost%d tile%dx%dx%d bm%d grid%d",
              p.K, p.C, p.N, p.IH, p.IW, p.OHf, p.OWf, p.nphase, maxtaps, p.ist, p.ost, p.NI, p.TH, p.TW, bm,
              max_tiles * (p.Kpad / bm) * p.nphase);
-    bool use_sp9 = false;
-    if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
-        use_sp9 = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 &&
-                  p.NI * p.ph[0].PH * p.ph[0].PW <= 192 && !env_int("HIFIC_NO_SP", 0) &&
-                  64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(p.NI * p.ph[0].PH * p.ph[0].PW + 1) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
-    }
     char kname[PROF_NAMELEN];
-    if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d>", bm / 64,
-                          (env_int("HIFIC_SP9_KSPLIT", 2) == 2 && (bm == 128 || env_int("HIFIC_SP9_KSPLIT64", 0))) ? 2 : 1);
+    if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d%s>", bm / 64,
+                          p.rfx ? (bm == 128 ? 2 : 1)
+                                : ((env_int("HIFIC_SP9_KSPLIT", 2) == 2 && (bm == 128 || env_int("HIFIC_SP9_KSPLIT64", 0))) ? 2 : 1),
+                          p.rfx ? ",rfx" : "");
     else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
                   bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
     const int pslot = prof_open(kname, aflops, st, ptag);
@@ -1792,16 +1855,17 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, patch <= 192 pixels
         if (use_sp9) {
             const int npatch = p.NI * p.ph[0].PH * p.ph[0].PW;
-            const size_t lds_sp = 64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(npatch + 1) * PITCH + 15) & ~(size_t)15);
+            const size_t lds_sp = 64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(npatch + 2) * PITCH + 15) & ~(size_t)15);
             if (lds_sp <= (size_t)kLdsBudget) {
                 const bool ks2 = env_int("HIFIC_SP9_KSPLIT", 2) == 2;
-#define SP9_LAUNCH(WM_, KSP_)                                                                                       \
+#define SP9_LAUNCH(WM_, KSP_, RFX_)                                                                                 \
     do {                                                                                                            \
-        hipFuncSetAttribute((const void*)gconv_sp9_kernel<WM_, KSP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp); \
-        hipLaunchKernelGGL((gconv_sp9_kernel<WM_, KSP_>), grid, dim3(256 * KSP_), lds_sp, st, p);                   \
+        hipFuncSetAttribute((const void*)gconv_sp9_kernel<WM_, KSP_, RFX_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp); \
+        hipLaunchKernelGGL((gconv_sp9_kernel<WM_, KSP_, RFX_>), grid, dim3(256 * KSP_), lds_sp, st, p);             \
     } while (0)
-                if (bm == 128) { if (ks2) SP9_LAUNCH(2, 2); else SP9_LAUNCH(2, 1); }
-                else { if (ks2 && env_int("HIFIC_SP9_KSPLIT64", 0)) SP9_LAUNCH(1, 2); else SP9_LAUNCH(1, 1); }
+                if (p.rfx) { if (bm == 128) SP9_LAUNCH(2, 2, true); else SP9_LAUNCH(1, 1, true); }
+                else if (bm == 128) { if (ks2) SP9_LAUNCH(2, 2, false); else SP9_LAUNCH(2, 1, false); }
+                else { if (ks2 && env_int("HIFIC_SP9_KSPLIT64", 0)) SP9_LAUNCH(1, 2, false); else SP9_LAUNCH(1, 1, false); }
 #undef SP9_LAUNCH
                 sp_done = true;
             }
@@ -1865,6 +1929,35 @@ int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const fl
     const bool has_pad = (g.pt | g.pl | g.pb | g.pr) != 0;
     const bool fold = has_pad && g.pad_mode == PAD_REFLECT;
     const int Hp = g.H + g.pt + g.pb, Wp = g.W + g.pl + g.pr;
+    // Reflect-padded 3x3 stride-1 layers (the residual blocks: 69 % of the model's MACs): gather form on the un-padded
+    // domain through the software-pipelined kernel (see gconv_sp9_kernel RFX).  Falls through to the padded-domain
+    // route when the plan cannot use that kernel.
+    if (fold && dtype == HIFIC_BF16 && g.R == 3 && g.S == 3 && stv == 1 && g.pt == 1 && g.pl == 1 && g.pb == 1 && g.pr == 1 &&
+        g.H >= 4 && g.W >= 4 && g.C > 32 && g.K > 16 && !env_int("HIFIC_NO_RFX", 0)) {
+        const size_t ws_mark = ws.off;
+        const size_t e_elems = (size_t)g.N * g.K * (g.H + 2) * (g.W + 2);
+        bf16_t* E = (bf16_t*)ws.take(e_elems * sizeof(bf16_t));
+        if (E) {
+            const unsigned planes = (unsigned)(g.N * g.K);
+            int gx = (int)((e_elems + 255) / 256); if (gx > 16384) gx = 16384;
+            if (in_f32) hipLaunchKernelGGL(reflect_extend_kernel<float>, dim3(gx), dim3(256), 0, st, (const float*)dy, E, planes, g.H, g.W);
+            else hipLaunchKernelGGL(reflect_extend_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, (const bf16_t*)dy, E, planes, g.H, g.W);
+            GcParams q; memset(&q, 0, sizeof(q));
+            q.in = E; q.out = dx; q.rfx = 1;
+            q.N = g.N; q.C = g.K; q.IH = g.H + 2; q.IW = g.W + 2; q.K = g.C; q.OHf = g.H; q.OWf = g.W;
+            q.ist = 1; q.ost = 1; q.bmode = PAD_ZERO; q.act = ACT_NONE; q.in_f32 = 0; q.out_f32 = out_f32;
+            q.nphase = 1;
+            int nt = 0;
+            for (int r = 0; r < 3; ++r) for (int s2 = 0; s2 < 3; ++s2) add_tap(q, nt, 2 - r, 2 - s2, r, s2);   // r-major: the kernel decodes r = t/3, s = t%3
+            GcPhase& ph = q.ph[0];
+            ph.ntaps = nt; ph.tap0 = 0; ph.ooy = 0; ph.oox = 0; ph.OHt = g.H; ph.OWt = g.W;
+            finish_phase(ph, q);
+            q.aflops = 2.0 * g.K * g.C * 9.0 * g.N * g.H * g.W;
+            const int rc = launch_gconv(q, dtype, w, w_scale, 9, (long long)g.C * 9, 3, 1, ws, st);
+            if (rc != HIFIC_ERR_UNSUPPORTED) return rc;
+        }
+        ws.off = ws_mark;
+    }
     GcParams p; memset(&p, 0, sizeof(p));
     p.in = dy; p.bias = nullptr; p.resid = nullptr;
     p.N = g.N; p.C = g.K; p.IH = g.OH(); p.IW = g.OW(); p.K = g.C;

@@ -27,6 +27,12 @@ CONV_CASES = {
     "L2_5x5":               (2, 64, 31, 31, 192, 5, 1, (2, 2, 2, 2), "zeros"),
     "L3_3x3_15":            (2, 192, 15, 15, 384, 3, 1, (1, 1, 1, 1), "zeros"),
     "odd_sizes":            (1, 5, 13, 17, 7, 3, 1, (1, 1, 1, 1), "reflect"),
+    # gather-form reflect data gradient (gconv_sp9_kernel RFX): non-square, multi-tile, and shapes whose tiling forces
+    # the padded-domain fall-back ((H-1) % TH == 0)
+    "RFX_rect_12x20":       (3, 96, 12, 20, 64, 3, 1, (1, 1, 1, 1), "reflect"),
+    "RFX_24x24_multi":      (1, 160, 24, 24, 128, 3, 1, (1, 1, 1, 1), "reflect"),
+    "RFX_17x9":             (2, 64, 17, 9, 64, 3, 1, (1, 1, 1, 1), "reflect"),
+    "RFX_4x4_min":          (5, 64, 4, 4, 96, 3, 1, (1, 1, 1, 1), "reflect"),
     "odd_s2":               (3, 9, 11, 10, 33, 3, 2, (1, 1, 1, 1), "zeros"),
 }
 # name: (N, Ci, H, W, Co, R, stride, pad, outpad)
