@@ -343,6 +343,7 @@ def main():
     }
     extras = world == 1 and not args.no_extras
     if extras:
+        from hific_amd import ops as hific_ops
         # ---- roofline of the dominant kernel function of the headline step (live HIP events) --------------------
         prof = profile_kernels(step, max(1, min(args.steps, 4)))
         dom = max(prof, key=lambda k: prof[k]["ms_per_step"])
@@ -358,6 +359,7 @@ def main():
             "gemm_class_ms_per_step": round(sum(v["ms_per_step"] for v in prof.values()), 3),
         }
         del model, opts, reducers, step
+        hific_ops.pack_cache.clear()
         torch.cuda.empty_cache()
         # ---- configs[1]: compression (no GAN) training step ---------------------------------------------------
         if cfg == "gan":
@@ -370,6 +372,7 @@ def main():
                                   "whole_step_tflops": round(GFLOP_PER_IMAGE["compression"] * args.batch *
                                                              (args.size / 256.0) ** 2 / 1e3 / (e2 / args.steps), 1)}
             del m2, o2, r2, s2
+            hific_ops.pack_cache.clear()
             torch.cuda.empty_cache()
         # ---- forward ms/image: EVALUATION-mode forward (model.py:357-366) ---------------------------------------
         import hific_amd

@@ -41,20 +41,24 @@ static bool geomT_ok(const ConvTGeom& g) {
 // flags: bit0 = x is f32 although dtype is bf16, bit1 = y (and resid) are f32 although dtype is bf16
 int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const float* bias, const void* resid, void* y,
                      int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb, int pr,
-                     int pad_mode, int act, int dtype, int flags, void* ws, size_t ws_bytes, hipStream_t stream) {
+                     int pad_mode, int act, int dtype, int flags, void* ws, size_t ws_bytes, void* wcache,
+                     size_t wcache_bytes, int wcache_state, hipStream_t stream) {
     ConvGeom g{N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode};
     if (!geom_ok(g) || !x || !w || !y) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
+    a.wcache = wcache; a.wcache_bytes = wcache_bytes; a.wcache_state = wcache_state;
     return gc_conv_fwd(g, x, w, w_scale, bias, y, resid, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 
 // dx = adjoint of the (padded, strided) convolution applied to dy.  flags: bit0 dy is f32, bit1 dx is f32
 int hific_conv2d_bwd_data(const void* dy, const float* w, const float* w_scale, void* dx, int N, int C, int H, int W,
                           int K, int R, int S, int stride, int pt, int pl, int pb, int pr, int pad_mode, int dtype,
-                          int flags, void* ws, size_t ws_bytes, hipStream_t stream) {
+                          int flags, void* ws, size_t ws_bytes, void* wcache, size_t wcache_bytes, int wcache_state,
+                          hipStream_t stream) {
     ConvGeom g{N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode};
     if (!geom_ok(g) || !dy || !w || !dx) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
+    a.wcache = wcache; a.wcache_bytes = wcache_bytes; a.wcache_state = wcache_state;
     return gc_conv_bwd_data(g, dy, w, w_scale, dx, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 
@@ -71,18 +75,22 @@ int hific_conv2d_bwd_weight(const void* x, const void* dy, float* dw, int N, int
 // nn.ConvTranspose2d: x [N,Ci,H,W], w f32 [Ci,Co,R,S], y [N,Co,OH,OW]
 int hific_conv_transpose2d_fwd(const void* x, const float* w, const float* bias, void* y, int N, int Ci, int H, int W,
                                int Co, int R, int S, int stride, int pad, int outpad, int act, int dtype, int flags,
-                               void* ws, size_t ws_bytes, hipStream_t stream) {
+                               void* ws, size_t ws_bytes, void* wcache, size_t wcache_bytes, int wcache_state,
+                               hipStream_t stream) {
     ConvTGeom g{N, Ci, H, W, Co, R, S, stride, pad, outpad};
     if (!geomT_ok(g) || !x || !w || !y) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
+    a.wcache = wcache; a.wcache_bytes = wcache_bytes; a.wcache_state = wcache_state;
     return gc_convT_fwd(g, x, w, bias, y, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 int hific_conv_transpose2d_bwd_data(const void* dy, const float* w, void* dx, int N, int Ci, int H, int W, int Co,
                                     int R, int S, int stride, int pad, int outpad, int dtype, int flags, void* ws,
-                                    size_t ws_bytes, hipStream_t stream) {
+                                    size_t ws_bytes, void* wcache, size_t wcache_bytes, int wcache_state,
+                                    hipStream_t stream) {
     ConvTGeom g{N, Ci, H, W, Co, R, S, stride, pad, outpad};
     if (!geomT_ok(g) || !dy || !w || !dx) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
+    a.wcache = wcache; a.wcache_bytes = wcache_bytes; a.wcache_state = wcache_state;
     return gc_convT_bwd_data(g, dy, w, dx, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 int hific_conv_transpose2d_bwd_weight(const void* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co,
@@ -92,6 +100,46 @@ int hific_conv_transpose2d_bwd_weight(const void* x, const void* dy, float* dw, 
     if (!geomT_ok(g) || !x || !dy || !dw) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
     return gc_convT_bwd_weight(g, x, dy, dw, accumulate, dtype, flags & 1, (flags >> 1) & 1, a, stream);
+}
+
+// ---- persistent packed-weight cache: plan / batched re-pack (see include/hific_hip.h) ---------------------------
+size_t hific_pack_job_bytes(void) { return sizeof(PackJob); }
+
+// kind 0: the packing hific_conv2d_fwd uses, 1: hific_conv2d_bwd_data.  Fills *job (host memory, hific_pack_job_bytes()).
+int hific_conv2d_pack_plan(int kind, int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb,
+                           int pr, int pad_mode, int dtype, int flags, void* job, size_t job_bytes) {
+    ConvGeom g{N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode};
+    if (!geom_ok(g) || !job || job_bytes < sizeof(PackJob) || (kind != 0 && kind != 1)) return HIFIC_ERR_ARG;
+    WsAlloc a{(char*)0x100000, (size_t)1 << 60, 0};            // plan-only: nothing is dereferenced or launched
+    a.plan_out = (PackJob*)job;
+    const float* fake_w = (const float*)job;       // never dereferenced in a plan-only call
+    if (kind == 0) return gc_conv_fwd(g, job, fake_w, nullptr, nullptr, job, nullptr, ACT_NONE, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
+    return gc_conv_bwd_data(g, job, fake_w, nullptr, job, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
+}
+int hific_conv_transpose2d_pack_plan(int kind, int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad,
+                                     int outpad, int dtype, int flags, void* job, size_t job_bytes) {
+    ConvTGeom g{N, Ci, H, W, Co, R, S, stride, pad, outpad};
+    if (!geomT_ok(g) || !job || job_bytes < sizeof(PackJob) || (kind != 0 && kind != 1)) return HIFIC_ERR_ARG;
+    WsAlloc a{(char*)0x100000, (size_t)1 << 60, 0};            // plan-only: nothing is dereferenced or launched
+    a.plan_out = (PackJob*)job;
+    const float* fake_w = (const float*)job;
+    if (kind == 0) return gc_convT_fwd(g, job, fake_w, nullptr, job, ACT_NONE, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
+    return gc_convT_bwd_data(g, job, fake_w, job, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
+}
+int hific_pack_job_set_ptrs(void* job, void* wpack, const float* w, const float* w_scale) {
+    if (!job) return HIFIC_ERR_ARG;
+    PackJob* j = (PackJob*)job;
+    j->p.wp = wpack; j->w = w; j->scale = w_scale;
+    return HIFIC_OK;
+}
+int hific_pack_job_info(const void* job, int* nblocks, int* lds_bytes, long long* wpack_bytes, int* dtype) {
+    if (!job) return HIFIC_ERR_ARG;
+    const PackJob* j = (const PackJob*)job;
+    if (nblocks) *nblocks = j->gx * j->gy;
+    if (lds_bytes) *lds_bytes = j->lds_bytes;
+    if (wpack_bytes) *wpack_bytes = j->wp_bytes;
+    if (dtype) *dtype = j->dtype;
+    return HIFIC_OK;
 }
 
 }  // extern "C"

@@ -80,8 +80,27 @@ struct ConvTGeom {
     int OW() const { return (W - 1) * stride - 2 * pad + S + outpad; }
 };
 
-struct WsAlloc {   // bump allocator over the caller-provided workspace
+// One weight-packing job of the batched pack kernel (hific_pack_batch): the conv plan (phases, taps, padded sizes,
+// destination `p.wp`) plus the source tensor and the tiling of the pack grid.  Built on the host by
+// hific_conv_pack_plan(), pointers set by hific_pack_job_set_ptrs(), uploaded to the device by the caller.
+struct PackJob {
+    GcParams p;
+    const float* w;
+    const float* scale;
+    long long sm, sc, sr, ss;
+    int RS, MB, mode;        // mode 0 / 1: pack_w2 tilings (c adjacent / m adjacent), 2: generic element-wise pack
+    int gx, gy;              // pack grid of this job (blocks = gx * gy)
+    int lds_bytes;
+    int dtype;
+    long long wp_bytes;      // size of the packed image
+};
+
+struct WsAlloc {   // bump allocator over the caller-provided workspace (+ the per-call weight-cache controls)
     char* base; size_t cap; size_t off;
+    // persistent packed-weight cache of the caller (hific_hip.h: `wcache`): state 0 = none (pack into the workspace),
+    // 1 = pack into wcache now, 2 = wcache already holds the packed image of the current weights (skip the pack)
+    void* wcache = nullptr; size_t wcache_bytes = 0; int wcache_state = 0;
+    PackJob* plan_out = nullptr;     // plan-only call: fill the job, launch nothing
     void* take(size_t bytes) {
         size_t a = (off + 255) & ~(size_t)255;
         if (a + bytes > cap) return nullptr;

@@ -722,24 +722,45 @@ __global__ void pack_w_kernel(const GcParams p, const float* __restrict__ w, con
 //   MODE 1 (m adjacent: conv bwd-data, conv-transpose fwd): block = (MB m, 64 c)    -> 64 runs of MB*RS floats
 // Output rows wp[phase][m][t][c0..c0+63] are 128-byte (bf16) contiguous stores.  One launch covers all phases.
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void pack_w2_kernel(const GcParams p, const float* __restrict__ w,
-                                                      const float* scale, long long sm, long long sc, int RS, int MB) {
+__device__ __forceinline__ void pack_w2_body(const GcParams& p, const float* __restrict__ w, const float* scale,
+                                             long long sm, long long sc, int RS, int MB, int bx, int by) {
     extern __shared__ float pk_lds[];
     const float sc_ = scale ? *scale : 1.f;
-    const int c0 = blockIdx.x * 64;
-    const int mb = MODE == 0 ? 1 : MB;
-    const int m0 = blockIdx.y * mb;
-    const int run = mb * RS;                 // contiguous floats per c row
+    const int c0 = bx * 64;
+    const int mb = MB;
+    const int m0 = by * mb;
+    const int run = mb * RS;                 // floats per c row of the LDS image: [c][ml][rs]
     const int pitch = (run | 1);             // odd pitch: conflict-free column reads
     if (MODE == 0) {
-        // 64*RS contiguous floats starting at (m0, c0); LDS index c*pitch + rs
+        // MB chunks (one per m row) of 64*RS contiguous floats starting at (m0 + ml, c0); LDS index c*pitch + ml*RS + rs.
+        // (One m row per block was 2.3 KB of work per block: 300k blocks per step and 1.7 TB/s; 16 rows per block with
+        // four independent loads per trip.)
         const int n = 64 * RS;
-        const int nvalid = (m0 < p.K) ? ((p.C - c0 < 64 ? p.C - c0 : 64) * RS) : 0;
-        const float* src = w + (long long)m0 * sm + (long long)c0 * sc;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const float v = i < nvalid ? src[i] * sc_ : 0.f;
-            const int li = (pitch == RS) ? i : i + i / RS;
-            pk_lds[li] = v;
+        const int cvalid = (p.C - c0 < 64 ? p.C - c0 : 64) * RS;
+        const float inv_rs = 1.0f / (float)RS, inv_n = 1.0f / (float)n;
+        const int total = mb * n;
+        const float* wrow = w + (long long)c0 * sc;
+        for (int j0 = threadIdx.x; j0 < total; j0 += 256 * 8) {       // 8 independent loads per trip
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 256 * u;
+                const int ml = (int)(((float)j + 0.5f) * inv_n);          // exact for j < 2^22
+                const int i = j - ml * n;
+                const bool ok = j < total && m0 + ml < p.K && i < cvalid;
+                v[u] = wrow[ok ? (long long)(m0 + ml) * sm + i : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 256 * u;
+                if (j < total) {
+                    const int ml = (int)(((float)j + 0.5f) * inv_n);
+                    const int i = j - ml * n;
+                    const int c = (int)(((float)i + 0.5f) * inv_rs);
+                    const bool ok = m0 + ml < p.K && i < cvalid;
+                    pk_lds[c * pitch + ml * RS + (i - c * RS)] = ok ? v[u] * sc_ : 0.f;
+                }
+            }
         }
     } else {
         // 64 rows (c) of `run` contiguous floats each: wave w takes rows w, w+4, ...
@@ -789,6 +810,47 @@ __global__ __launch_bounds__(256) void pack_w2_kernel(const GcParams p, const fl
                 o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
                 *(uint2*)d = o;
             }
+        }
+    }
+}
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pack_w2_kernel(const GcParams p, const float* __restrict__ w,
+                                                      const float* scale, long long sm, long long sc, int RS, int MB) {
+    pack_w2_body<T, MODE>(p, w, scale, sm, sc, RS, MB, blockIdx.x, blockIdx.y);
+}
+
+// Batched packing: ONE launch re-packs every (layer, direction) whose weights changed (after an optimizer step), instead
+// of one ~14 us launch per use of every layer (87 launches / 1.25 ms per compression step, 150 / 2.1 ms per GAN cycle).
+// Block b serves job j = last job with prefix[j] <= b; jobs and prefix live in device memory.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ prefix,
+                                                         int njobs) {
+    int lo = 0, hi = njobs - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= b) lo = mid; else hi = mid - 1; }
+    const PackJob& J = jobs[lo];
+    const int lb = b - prefix[lo];
+    if (J.mode == 0) pack_w2_body<T, 0>(J.p, J.w, J.scale, J.sm, J.sc, J.RS, J.MB, lb % J.gx, lb / J.gx);
+    else if (J.mode == 1) pack_w2_body<T, 1>(J.p, J.w, J.scale, J.sm, J.sc, J.RS, J.MB, lb % J.gx, lb / J.gx);
+    else {
+        // generic element-wise pack of phase lb / gx (rare layouts), grid-stride over the phase's elements
+        const GcParams& p = J.p;
+        const int phi = lb / J.gx, bxx = lb % J.gx;
+        const GcPhase& ph = p.ph[phi];
+        const long long total = (long long)p.Kpad * ph.ntaps * p.Cpad;
+        const float sc_ = J.scale ? *J.scale : 1.f;
+        T* dst = (T*)p.wp + ph.wp_off;
+        for (long long i = (long long)bxx * 256 + threadIdx.x; i < total; i += (long long)J.gx * 256) {
+            const int c = (int)(i % p.Cpad);
+            const long long j2 = i / p.Cpad;
+            const int t = (int)(j2 % ph.ntaps);
+            const int m = (int)(j2 / ph.ntaps);
+            float v = 0.f;
+            if (m < p.K && c < p.C) {
+                const int r = p.tap_r[ph.tap0 + t], s2 = p.tap_s[ph.tap0 + t];
+                v = J.w[m * J.sm + c * J.sc + r * J.sr + s2 * J.ss] * sc_;
+            }
+            DT<T>::st(dst + i, v);
         }
     }
 }
@@ -1638,6 +1700,21 @@ extern "C" int hific_prof_end(int max_kinds, double* ms, double* flops, int* cou
     return nk;
 }
 
+extern "C" int hific_pack_batch(const void* jobs_dev, const int* prefix_dev, int njobs, int total_blocks, size_t lds_bytes,
+                                int dtype, hipStream_t st) {
+    if (!jobs_dev || !prefix_dev || njobs <= 0 || total_blocks <= 0) return HIFIC_ERR_ARG;
+    if (dtype == HIFIC_BF16) {
+        if (lds_bytes > 48 * 1024)
+            hipFuncSetAttribute((const void*)pack_batch_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, dim3(total_blocks), dim3(256), lds_bytes, st, (const PackJob*)jobs_dev, prefix_dev, njobs);
+    } else if (dtype == HIFIC_F32) {
+        if (lds_bytes > 48 * 1024)
+            hipFuncSetAttribute((const void*)pack_batch_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(pack_batch_kernel<float>, dim3(total_blocks), dim3(256), lds_bytes, st, (const PackJob*)jobs_dev, prefix_dev, njobs);
+    } else return HIFIC_ERR_ARG;
+    return hific_launch_status();
+}
+
 // ===================================================================================================
 // Host-side planning
 // ===================================================================================================
@@ -1787,37 +1864,58 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         const bool ok = use_sp9 && p.NI == 1 && p.TH >= 2 && p.TW >= 2 && (p.OHf - 1) % p.TH != 0 && (p.OWf - 1) % p.TW != 0;
         if (!ok) return HIFIC_ERR_UNSUPPORTED;
     }
-    void* wp = ws.take((size_t)(wp_elems > 0 ? wp_elems : 1) * sizeof(T));
-    if (!wp) return HIFIC_ERR_WS;
-    p.wp = wp;
-    // pack (coalesced LDS-transposing kernel when the taps of a (m,c) pair are contiguous and one of m/c is adjacent)
+    const size_t wp_bytes = (size_t)(wp_elems > 0 ? wp_elems : 1) * sizeof(T);
+    // pack tiling (coalesced LDS-transposing kernel when the taps of a (m,c) pair are contiguous and one of m/c is adjacent)
+    PackJob job; memset(&job, 0, sizeof(job));
     {
         int RS = 0;
         for (int i = 0; i < p.nphase; ++i) RS += p.ph[i].ntaps;       // phases partition the R*S taps
         const bool contiguous = (sr == p.tap_sw && ss == 1 && RS > 0);
-        const bool full = (sr * 0 + RS) == RS;
-        (void)full;
+        job.sm = sm; job.sc = sc; job.sr = sr; job.ss = ss; job.RS = RS; job.MB = 1; job.dtype = DT<T>::code;
+        job.wp_bytes = (long long)wp_bytes;
         if (contiguous && sc == RS && !env_int("HIFIC_OLD_PACK", 0)) {
-            dim3 pg(p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0), p.Kpad);
-            const size_t lb = (size_t)64 * (RS | 1) * sizeof(float);
-            hipLaunchKernelGGL((pack_w2_kernel<T, 0>), pg, dim3(256), lb, st, p, w, w_scale, sm, sc, RS, 1);
+            int MB = 40960 / (64 * RS * 4); if (MB > 16) MB = 16; if (MB < 1) MB = 1;
+            job.mode = 0; job.MB = MB; job.gx = p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0); job.gy = cdiv(p.Kpad, MB);
+            job.lds_bytes = (int)((size_t)64 * ((MB * RS) | 1) * sizeof(float));
         } else if (contiguous && sm == RS && !env_int("HIFIC_OLD_PACK", 0)) {
             int MB = env_int("HIFIC_PACK_MB", 144) / RS; if (MB > 32) MB = 32; if (MB < 1) MB = 1;
-            dim3 pg(p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0), cdiv(p.Kpad, MB));
-            const size_t lb = (size_t)64 * ((MB * RS) | 1) * sizeof(float);
-            if (lb > 48 * 1024)
-                hipFuncSetAttribute((const void*)pack_w2_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-            hipLaunchKernelGGL((pack_w2_kernel<T, 1>), pg, dim3(256), lb, st, p, w, w_scale, sm, sc, RS, MB);
+            job.mode = 1; job.MB = MB; job.gx = p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0); job.gy = cdiv(p.Kpad, MB);
+            job.lds_bytes = (int)((size_t)64 * ((MB * RS) | 1) * sizeof(float));
         } else {
             long long mx = 0;
             for (int i = 0; i < p.nphase; ++i) {
                 long long e = (long long)p.Kpad * p.ph[i].ntaps * p.Cpad;
                 if (e > mx) mx = e;
             }
-            if (mx > 0) {
-                int gx = (int)((mx + 255) / 256); if (gx > 4096) gx = 4096;
-                hipLaunchKernelGGL(pack_w_kernel<T>, dim3(gx, p.nphase), dim3(256), 0, st, p, w, w_scale, sm, sc, sr, ss);
-            }
+            int gx = (int)((mx + 255) / 256); if (gx > 4096) gx = 4096; if (gx < 1) gx = 1;
+            job.mode = 2; job.gx = gx; job.gy = p.nphase; job.lds_bytes = 0;
+        }
+    }
+    if (ws.plan_out) {          // plan-only call (hific_conv_pack_plan): hand the job to the caller, launch nothing
+        job.p = p; job.p.wp = nullptr;
+        *ws.plan_out = job;
+        return HIFIC_OK;
+    }
+    void* wp;
+    if (ws.wcache_state != 0) {
+        if (!ws.wcache || ws.wcache_bytes < wp_bytes) return HIFIC_ERR_WS;
+        wp = ws.wcache;
+    } else {
+        wp = ws.take(wp_bytes);
+        if (!wp) return HIFIC_ERR_WS;
+    }
+    p.wp = wp;
+    if (ws.wcache_state != 2) {
+        if (job.mode == 0) {
+            if (job.lds_bytes > 48 * 1024)
+                hipFuncSetAttribute((const void*)pack_w2_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, job.lds_bytes);
+            hipLaunchKernelGGL((pack_w2_kernel<T, 0>), dim3(job.gx, job.gy), dim3(256), job.lds_bytes, st, p, w, w_scale, sm, sc, job.RS, job.MB);
+        } else if (job.mode == 1) {
+            if (job.lds_bytes > 48 * 1024)
+                hipFuncSetAttribute((const void*)pack_w2_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, job.lds_bytes);
+            hipLaunchKernelGGL((pack_w2_kernel<T, 1>), dim3(job.gx, job.gy), dim3(256), job.lds_bytes, st, p, w, w_scale, sm, sc, job.RS, job.MB);
+        } else {
+            hipLaunchKernelGGL(pack_w_kernel<T>, dim3(job.gx, p.nphase), dim3(256), 0, st, p, w, w_scale, sm, sc, sr, ss);
         }
     }
     p.max_tiles = max_tiles;
@@ -1940,7 +2038,8 @@ int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const fl
         if (E) {
             const unsigned planes = (unsigned)(g.N * g.K);
             int gx = (int)((e_elems + 255) / 256); if (gx > 16384) gx = 16384;
-            if (in_f32) hipLaunchKernelGGL(reflect_extend_kernel<float>, dim3(gx), dim3(256), 0, st, (const float*)dy, E, planes, g.H, g.W);
+            if (ws.plan_out) { /* plan-only: nothing is launched */ }
+            else if (in_f32) hipLaunchKernelGGL(reflect_extend_kernel<float>, dim3(gx), dim3(256), 0, st, (const float*)dy, E, planes, g.H, g.W);
             else hipLaunchKernelGGL(reflect_extend_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, (const bf16_t*)dy, E, planes, g.H, g.W);
             GcParams q; memset(&q, 0, sizeof(q));
             q.in = E; q.out = dx; q.rfx = 1;
@@ -1997,7 +2096,7 @@ int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const fl
     p.aflops = 2.0 * g.K * g.C * (double)RS * g.N * g.OH() * g.OW();       // same MACs as the forward op
     // out-channel m = c (stride RS), reduction channel = k (stride C*RS)
     int rc = launch_gconv(p, dtype, w, w_scale, RS, (long long)g.C * RS, g.S, 1, ws, st);
-    if (rc != HIFIC_OK) return rc;
+    if (rc != HIFIC_OK || ws.plan_out) return rc;
     if (fold) {
         const long long planes = (long long)g.N * g.C;
         long long total = planes * g.H * g.W;

@@ -25,11 +25,11 @@ SIGNATURES = {
     "hific_device_info": (I, [I, c_char_p, POINTER(c_int), POINTER(c_int)]),
     "hific_conv2d_ws_bytes": (Z, [I] * 13),
     "hific_conv_transpose2d_ws_bytes": (Z, [I] * 11),
-    "hific_conv2d_fwd": (I, [P, P, P, P, P, P] + [I] * 16 + [P, Z, P]),
-    "hific_conv2d_bwd_data": (I, [P, P, P, P] + [I] * 15 + [P, Z, P]),
+    "hific_conv2d_fwd": (I, [P, P, P, P, P, P] + [I] * 16 + [P, Z, P, Z, I, P]),
+    "hific_conv2d_bwd_data": (I, [P, P, P, P] + [I] * 15 + [P, Z, P, Z, I, P]),
     "hific_conv2d_bwd_weight": (I, [P, P, P] + [I] * 16 + [P, Z, P]),
-    "hific_conv_transpose2d_fwd": (I, [P, P, P, P] + [I] * 13 + [P, Z, P]),
-    "hific_conv_transpose2d_bwd_data": (I, [P, P, P] + [I] * 12 + [P, Z, P]),
+    "hific_conv_transpose2d_fwd": (I, [P, P, P, P] + [I] * 13 + [P, Z, P, Z, I, P]),
+    "hific_conv_transpose2d_bwd_data": (I, [P, P, P] + [I] * 12 + [P, Z, P, Z, I, P]),
     "hific_conv_transpose2d_bwd_weight": (I, [P, P, P] + [I] * 13 + [P, Z, P]),
     "hific_channelnorm_fwd": (I, [P, P, P, P, P, P, I, I, I, F, I, I, P]),
     "hific_channelnorm_bwd_ws_bytes": (Z, [I, I, I]),
@@ -68,6 +68,12 @@ SIGNATURES = {
     "hific_lpips_prep_bwd": (I, [P, P, I, I, I, I, I, P]),
     "hific_lpips_tap_fwd": (I, [P, P, P, I, I, I, I, I, P, Z, P]),
     "hific_lpips_tap_bwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "hific_pack_job_bytes": (Z, []),
+    "hific_conv2d_pack_plan": (I, [I] * 16 + [P, Z]),
+    "hific_conv_transpose2d_pack_plan": (I, [I] * 13 + [P, Z]),
+    "hific_pack_job_set_ptrs": (I, [P, P, P, P]),
+    "hific_pack_job_info": (I, [P, POINTER(c_int), POINTER(c_int), POINTER(c_longlong), POINTER(c_int)]),
+    "hific_pack_batch": (I, [P, P, I, I, Z, I, P]),
     "hific_augment_crop": (I, [P, P, P, P, P, I, I, I, I, P, P]),
     "hific_prof_begin": (I, []),
     "hific_prof_end": (I, [I, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int), c_char_p]),

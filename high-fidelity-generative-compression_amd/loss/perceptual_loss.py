@@ -37,8 +37,10 @@ def _conv_fwd(x, w, b, stride, pad, cd):
     OW = (W + 2 * pad - S) // stride + 1
     y = torch.empty((N, K, OH, OW), dtype=x.dtype, device=x.device)
     ws = lib.workspace(x.device)
-    call("hific_conv2d_fwd", ptr(x), ptr(w), None, ptr(b), None, ptr(y), N, C, H, W, K, R, S, stride, pad, pad, pad,
-         pad, lib.PAD_ZERO, lib.ACT_RELU, cd, 0, ws.data_ptr(), ws.numel(), stream())
+    geom = (N, C, H, W, K, R, S, stride, pad, pad, pad, pad, lib.PAD_ZERO)
+    wc = ops._wcache(w, 0, geom, cd, 0)                      # frozen backbone: packed once
+    call("hific_conv2d_fwd", ptr(x), ptr(w), None, ptr(b), None, ptr(y), *geom, lib.ACT_RELU, cd, 0, ws.data_ptr(),
+         ws.numel(), *wc, stream())
     return y
 
 
@@ -47,8 +49,9 @@ def _conv_bwd_data(dy, w, xshape, stride, pad, cd):
     K, _, R, S = w.shape
     dx = torch.empty(xshape, dtype=dy.dtype, device=dy.device)
     ws = lib.workspace(dy.device)
-    call("hific_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(dx), N, C, H, W, K, R, S, stride, pad, pad, pad, pad,
-         lib.PAD_ZERO, cd, 0, ws.data_ptr(), ws.numel(), stream())
+    geom = (N, C, H, W, K, R, S, stride, pad, pad, pad, pad, lib.PAD_ZERO)
+    wc = ops._wcache(w, 1, geom, cd, 0)
+    call("hific_conv2d_bwd_data", ptr(dy), ptr(w), None, ptr(dx), *geom, cd, 0, ws.data_ptr(), ws.numel(), *wc, stream())
     return dx
 
 

@@ -7,6 +7,8 @@ Conventions
   * nothing here computes with torch ops: torch allocates outputs and records the graph
 """
 import ctypes
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -40,6 +42,110 @@ def note_weights_changed():
 
 def weights_epoch():
     return _weights_epoch
+
+
+# ------------------------------------------------------------------------------------------------------
+# Persistent packed-weight cache (include/hific_hip.h "persistent packed-weight cache").
+#   key   = (weight storage address, direction, geometry, compute dtype), valid for ONE tensor object (weak reference)
+#   token = (weight._version, epoch of the optim.ParamArena holding it) - what the packed image was made from.
+#           Everything that updates parameters through torch (optimizers, load_state_dict, p.copy_/add_ ...) bumps
+#           `_version`; optim.FusedAdam bumps the arena epoch.  NOT seen: in-place writes through an alias that has
+#           its own version counter (`p.data.mul_(..)`): call ops.pack_cache.clear() after such edits, or run with
+#           HIFIC_PACK_CACHE=0.
+# A forward-type conv call whose entry is current passes wcache_state 2 and launches no pack kernel.  The first call
+# that finds a stale entry re-packs EVERY stale entry in ONE launch (hific_pack_batch): after an optimizer step that is
+# "all layers of that parameter group, both directions".  Inference never re-packs.
+_PACK_CACHE_ON = __import__("os").environ.get("HIFIC_PACK_CACHE", "1") != "0"
+
+
+class _PackEntry:
+    __slots__ = ("weight", "buf", "job", "token", "nblocks", "lds", "dtype")
+
+
+class WeightPackCache:
+    def __init__(self):
+        self.entries = {}
+        self.prepared = {}          # tuple(entry keys) -> (jobs_dev, prefix_dev, total_blocks, lds, dtype)
+        self.job_bytes = None
+
+    @staticmethod
+    def _token(w):
+        sl = getattr(w, "_hific_slot", None)
+        return (w._version, sl.arena.epoch if sl is not None else -1)
+
+    def clear(self):
+        self.entries.clear(); self.prepared.clear()
+
+    def lookup(self, weight, kind, geom, cd, flags, transposed):
+        """-> (wcache ptr, bytes, state) for the C-ABI call."""
+        if not _PACK_CACHE_ON:
+            return None, 0, 0
+        if self.job_bytes is None:
+            self.job_bytes = int(lib.raw("hific_pack_job_bytes")())
+        key = (weight.data_ptr(), kind, geom, cd, flags, weight.device.index)
+        e = self.entries.get(key)
+        tok = self._token(weight)
+        if e is not None and e.weight() is not weight:
+            # another tensor object at this address (the old one died, or an alias whose version counter we cannot
+            # relate to the packed image): start over for this key
+            e = None
+            self.prepared.clear()
+        if e is None:
+            e = _PackEntry()
+            e.job = ctypes.create_string_buffer(self.job_bytes)
+            fn = "hific_conv_transpose2d_pack_plan" if transposed else "hific_conv2d_pack_plan"
+            call(fn, kind, *geom, cd, flags, e.job, self.job_bytes)
+            nb, ld, wb, dt = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_int()
+            call("hific_pack_job_info", e.job, ctypes.byref(nb), ctypes.byref(ld), ctypes.byref(wb), ctypes.byref(dt))
+            e.nblocks, e.lds, e.dtype = nb.value, ld.value, dt.value
+            e.buf = torch.empty(int(wb.value), dtype=torch.uint8, device=weight.device)
+            e.weight = weakref.ref(weight)
+            call("hific_pack_job_set_ptrs", e.job, e.buf.data_ptr(), weight.data_ptr(), None)
+            e.token = tok
+            self.entries[key] = e
+            self.prepared.clear()
+            return e.buf.data_ptr(), e.buf.numel(), 1        # packed by this call, into the cache
+        if e.token != tok:
+            self.refresh_stale()
+        return e.buf.data_ptr(), e.buf.numel(), 2
+
+    def refresh_stale(self):
+        dead = [k for k, e in self.entries.items() if e.weight() is None]
+        for k in dead:
+            del self.entries[k]
+        if dead:
+            self.prepared.clear()
+        stale = [(k, e) for k, e in self.entries.items() if e.token != self._token(e.weight())]
+        for dt in (HIFIC_BF16, HIFIC_F32):
+            group = [(k, e) for k, e in stale if e.dtype == dt]
+            if not group:
+                continue
+            sig = tuple(k for k, _ in group)
+            prep = self.prepared.get(sig)
+            if prep is None:
+                dev = group[0][1].buf.device
+                raw = b"".join(bytes(e.job.raw) for _, e in group)
+                jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+                pref, tot = [], 0
+                for _, e in group:
+                    pref.append(tot); tot += e.nblocks
+                prefix_dev = torch.tensor(pref, dtype=torch.int32, device=dev)
+                prep = (jobs_dev, prefix_dev, tot, max(e.lds for _, e in group))
+                self.prepared[sig] = prep
+            jobs_dev, prefix_dev, tot, lds_b = prep
+            call("hific_pack_batch", jobs_dev.data_ptr(), prefix_dev.data_ptr(), len(group), tot, lds_b, dt, stream())
+            for _, e in group:
+                e.token = self._token(e.weight())
+
+
+pack_cache = WeightPackCache()
+
+
+def _wcache(weight, kind, geom, cd, flags, w_scale=None, transposed=False):
+    """Cache arguments of a forward-type conv call; spectral-norm convs (w_scale changes every forward) bypass it."""
+    if w_scale is not None or not weight.is_cuda:
+        return None, 0, 0
+    return pack_cache.lookup(weight, kind, geom, cd, flags, transposed)
 
 
 def _cd():
@@ -98,8 +204,9 @@ class Conv2dFn(Function):
         y = torch.empty((N, K, OH, OW), dtype=ydt, device=x.device)
         flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | ((1 if ydt == torch.float32 else 0) << 1 if cd == HIFIC_BF16 else 0)
         wsp, wsb = _ws(x)
+        wc = _wcache(weight, 0, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, w_scale)
         call("hific_conv2d_fwd", ptr(x), ptr(weight), ptr(w_scale), ptr(bias), None, ptr(y),
-             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, stream())
+             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
         ctx.geom = geom
         ctx.act = act
         ctx.cd = cd
@@ -127,8 +234,9 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
+            wc = _wcache(weight, 1, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, w_scale)
             call("hific_conv2d_bwd_data", ptr(dy), ptr(weight), ptr(w_scale), ptr(dx), N, C, H, W, K, R, S, stride,
-                 pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, stream())
+                 pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, *wc, stream())
         if ctx.needs_input_grad[1]:
             dwt, acc, dw = _grad_target(ctx.w_slot, weight)
             flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
@@ -169,8 +277,9 @@ class ConvTranspose2dFn(Function):
         if cd == HIFIC_BF16:
             flags = _is_f32(x) | (_is_f32(y) << 1)
         wsp, wsb = _ws(x)
+        wc = _wcache(weight, 0, (N, Ci, H, W, Co, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
         call("hific_conv_transpose2d_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), N, Ci, H, W, Co, R, S, stride, pad,
-             outpad, _act_code(act), cd, flags, wsp, wsb, stream())
+             outpad, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
         ctx.geom, ctx.act, ctx.cd, ctx.has_bias = geom, act, cd, bias is not None
         ctx.w_slot, ctx.b_slot = _slot(weight), _slot(bias)
         ctx.save_for_backward(x, weight, y if act not in (None, "none") else None)
@@ -195,8 +304,9 @@ class ConvTranspose2dFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
+            wc = _wcache(weight, 1, (N, Ci, H, W, Co, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
             call("hific_conv_transpose2d_bwd_data", ptr(dy), ptr(weight), ptr(dx), N, Ci, H, W, Co, R, S, stride, pad,
-                 outpad, cd, flags, wsp, wsb, stream())
+                 outpad, cd, flags, wsp, wsb, *wc, stream())
         if ctx.needs_input_grad[1]:
             dwt, acc, dw = _grad_target(ctx.w_slot, weight)
             flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
@@ -616,7 +726,8 @@ class SNConv2dFn(Function):
         wsp, wsb = _ws(x)
         inv_sigma = sig[1:]
         call("hific_conv2d_fwd", ptr(x), ptr(weight_orig), ptr(inv_sigma), ptr(bias), None, ptr(y),
-             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, stream())
+             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, None, 0, 0,
+             stream())
         ctx.geom, ctx.act, ctx.cd = geom, act, cd
         ctx.w_slot, ctx.b_slot = _slot(weight_orig), _slot(bias)
         ctx.save_for_backward(x, weight_orig, u.clone(), v.clone(), sig, y if act not in (None, "none") else None)
@@ -643,7 +754,7 @@ class SNConv2dFn(Function):
             dx = torch.empty_like(x)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
             call("hific_conv2d_bwd_data", ptr(dy), ptr(weight_orig), ptr(inv_sigma), ptr(dx), N, C, H, W, K, R, S,
-                 stride, pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, stream())
+                 stride, pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, None, 0, 0, stream())
         if ctx.needs_input_grad[1]:
             dws = torch.empty_like(weight_orig)       # gradient w.r.t. the normalised weight
             flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)

@@ -53,6 +53,7 @@ class ParamArena:
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
         self.slots = []
         self.on_write = None
+        self.epoch = 0          # bumped by every optimizer step over this arena (ops.WeightPackCache tokens)
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(params, offs)):
                 n = p.numel()
@@ -146,6 +147,7 @@ class FusedAdam:
         g = self.param_groups[0]
         ops.adam_step(self.arena.flat, self.arena.flat_grad, self.exp_avg, self.exp_avg_sq,
                       g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count, self.grad_scale)
+        self.arena.epoch += 1
         ops.note_weights_changed()
 
     def zero_grad(self, set_to_none=False):

@@ -51,11 +51,11 @@ size_t hific_conv2d_ws_bytes(int N, int C, int H, int W, int K, int R, int S, in
 int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const float* bias, const void* resid,
                      void* y, int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb,
                      int pr, int pad_mode, int act, int dtype, int flags, void* ws, size_t ws_bytes,
-                     hipStream_t stream);
+                     void* wcache, size_t wcache_bytes, int wcache_state, hipStream_t stream);
 /* adjoint w.r.t. x (autograd of the above; includes the reflection-pad adjoint). flags: bit0 dy f32, bit1 dx f32 */
 int hific_conv2d_bwd_data(const void* dy, const float* w, const float* w_scale, void* dx, int N, int C, int H,
                           int W, int K, int R, int S, int stride, int pt, int pl, int pb, int pr, int pad_mode,
-                          int dtype, int flags, void* ws, size_t ws_bytes, hipStream_t stream);
+                          int dtype, int flags, void* ws, size_t ws_bytes, void* wcache, size_t wcache_bytes, int wcache_state, hipStream_t stream);
 /* dw f32 [K,C,R,S] (= or += when accumulate). flags: bit0 x f32, bit1 dy f32 */
 int hific_conv2d_bwd_weight(const void* x, const void* dy, float* dw, int N, int C, int H, int W, int K, int R,
                             int S, int stride, int pt, int pl, int pb, int pr, int pad_mode, int accumulate,
@@ -67,10 +67,10 @@ size_t hific_conv_transpose2d_ws_bytes(int N, int Ci, int H, int W, int Co, int 
                                        int outpad, int dtype);
 int hific_conv_transpose2d_fwd(const void* x, const float* w, const float* bias, void* y, int N, int Ci, int H,
                                int W, int Co, int R, int S, int stride, int pad, int outpad, int act, int dtype,
-                               int flags, void* ws, size_t ws_bytes, hipStream_t stream);
+                               int flags, void* ws, size_t ws_bytes, void* wcache, size_t wcache_bytes, int wcache_state, hipStream_t stream);
 int hific_conv_transpose2d_bwd_data(const void* dy, const float* w, void* dx, int N, int Ci, int H, int W, int Co,
                                     int R, int S, int stride, int pad, int outpad, int dtype, int flags, void* ws,
-                                    size_t ws_bytes, hipStream_t stream);
+                                    size_t ws_bytes, void* wcache, size_t wcache_bytes, int wcache_state, hipStream_t stream);
 int hific_conv_transpose2d_bwd_weight(const void* x, const void* dy, float* dw, int N, int Ci, int H, int W,
                                       int Co, int R, int S, int stride, int pad, int outpad, int accumulate,
                                       int dtype, int flags, void* ws, size_t ws_bytes, hipStream_t stream);
@@ -171,6 +171,26 @@ int hific_lpips_tap_fwd(const void* f, const float* w, float* val, int B, int C,
                         void* ws, size_t ws_bytes, hipStream_t stream);
 int hific_lpips_tap_bwd(const void* f, const float* w, const float* gval, void* df1, int B, int C, int HW,
                         int accumulate, int dtype, hipStream_t stream);
+
+/* ---- persistent packed-weight cache ---------------------------------------------------------------------------
+ * The MFMA kernels read weights from a packed bf16/f32 image [K_pad][tap][C_pad] (per stride phase).  Without a cache
+ * every forward-type call re-packs its f32 weights into the workspace first.  With one, the caller owns a buffer per
+ * (weight tensor, direction, geometry) and passes it as `wcache`:
+ *   wcache_state 0: no cache (pack into the workspace);  1: pack into wcache now;  2: wcache is current - skip the pack.
+ * hific_*_pack_plan fills an opaque host-side job (hific_pack_job_bytes() bytes) describing exactly the packing that
+ * the matching entry point (kind 0 = forward, 1 = data gradient) would do for that geometry; after
+ * hific_pack_job_set_ptrs (destination = the cache buffer, source = the f32 weights, optional device scalar scale)
+ * the jobs are copied to device memory and hific_pack_batch re-packs ALL of them in one launch (after an optimizer
+ * step): prefix_dev[j] = first block of job j (prefix of hific_pack_job_info's nblocks), lds_bytes = max over jobs. */
+size_t hific_pack_job_bytes(void);
+int hific_conv2d_pack_plan(int kind, int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb,
+                           int pr, int pad_mode, int dtype, int flags, void* job, size_t job_bytes);
+int hific_conv_transpose2d_pack_plan(int kind, int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad,
+                                     int outpad, int dtype, int flags, void* job, size_t job_bytes);
+int hific_pack_job_set_ptrs(void* job, void* wpack, const float* w, const float* w_scale);
+int hific_pack_job_info(const void* job, int* nblocks, int* lds_bytes, long long* wpack_bytes, int* dtype);
+int hific_pack_batch(const void* jobs_dev, const int* prefix_dev, int njobs, int total_blocks, size_t lds_bytes, int dtype,
+                     hipStream_t stream);
 
 /* ---- training-time augmentation (csrc/augment.hip) - src/helpers/datasets.py:206-216 ----------------------------
  * RandomHorizontalFlip -> Resize((ceil(s H), ceil(s W)), PIL bilinear) -> RandomCrop(crop) -> ToTensor [-> Normalize]

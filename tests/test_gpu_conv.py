@@ -152,3 +152,57 @@ def test_conv_fused_activation_and_mixed_io(hific, dev, act):
     assert _relerr(y.detach().cpu(), yr.detach()) < 2e-2
     assert _relerr(xd.grad.cpu(), xr.grad) < 3e-2
     assert _relerr(wd.grad.cpu(), wr.grad) < 3e-2
+
+
+def test_weight_pack_cache_tracks_weight_updates(hific, dev):
+    """Persistent packed-weight cache (ops.WeightPackCache): cached calls equal un-cached ones bit for bit - after the
+    first (filling) call, after an in-place torch update (version counter) and after a FusedAdam step (arena epoch);
+    stale entries of several layers/directions are re-packed by ONE batched launch."""
+    from hific_amd import ops, lib, optim
+    hific.set_compute_dtype(torch.bfloat16)
+    ops.pack_cache.clear()
+    torch.manual_seed(0)
+    w1 = torch.nn.Parameter((torch.rand(96, 64, 3, 3) * 2 - 1).div(24).to(dev))      # 3x3 reflect (RFX data gradient)
+    w2 = torch.nn.Parameter((torch.rand(96, 48, 3, 3) * 2 - 1).div(24).to(dev))      # conv-transpose 96 -> 48
+    opt = optim.FusedAdam([w1, w2], lr=1e-2)
+    x = (torch.rand(2, 64, 12, 12, device=dev) * 2 - 1).bfloat16().requires_grad_(True)
+
+    def run():
+        x.grad = None
+        h = ops.conv2d(x, w1, None, stride=1, pads=(1, 1, 1, 1), pad_mode=lib.PAD_REFLECT)
+        y = ops.conv_transpose2d(h, w2, None, 2, 1, 1)
+        y.float().square().sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), x.grad.detach().clone()
+
+    def run_uncached():
+        on = ops._PACK_CACHE_ON
+        ops._PACK_CACHE_ON = False
+        try:
+            return run()
+        finally:
+            ops._PACK_CACHE_ON = on
+
+    def same(a, b):
+        return torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+    ref = run_uncached()
+    assert same(run(), ref)                     # filling call (state 1)
+    assert len(ops.pack_cache.entries) == 4     # two layers x two directions
+    assert same(run(), ref)                     # cached (state 2)
+    with torch.no_grad():
+        w1.mul_(1.5)                            # in-place torch update: version counter
+    opt.zero_grad()
+    ref2 = run_uncached()
+    assert not torch.equal(ref2[0], ref[0])
+    opt.zero_grad()
+    assert same(run(), ref2)                    # one batched re-pack of the stale entries
+    opt.zero_grad()
+    run()                                       # gradients for the optimizer
+    opt.step()                                  # raw-kernel update: arena epoch
+    opt.zero_grad()
+    ref3 = run_uncached()
+    assert not torch.equal(ref3[0], ref2[0])
+    opt.zero_grad()
+    assert same(run(), ref3)
+    ops.pack_cache.clear()

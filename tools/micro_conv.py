@@ -32,8 +32,8 @@ y = torch.empty(N, K, OH, OH, device=dev, dtype=torch.bfloat16)
 dx = torch.empty_like(x)
 dw = torch.empty_like(w)
 if which in ("fwd", "all"):
-    run("fwd", lambda: lib.call("hific_conv2d_fwd", x.data_ptr(), w.data_ptr(), None, b.data_ptr(), None, y.data_ptr(), *geom, 0, 1, 0, ws.data_ptr(), ws.numel(), lib.stream()))
+    run("fwd", lambda: lib.call("hific_conv2d_fwd", x.data_ptr(), w.data_ptr(), None, b.data_ptr(), None, y.data_ptr(), *geom, 0, 1, 0, ws.data_ptr(), ws.numel(), None, 0, 0, lib.stream()))
 if which in ("bwd", "all"):
-    run("bwd_data", lambda: lib.call("hific_conv2d_bwd_data", gy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), *geom, 1, 0, ws.data_ptr(), ws.numel(), lib.stream()))
+    run("bwd_data", lambda: lib.call("hific_conv2d_bwd_data", gy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), *geom, 1, 0, ws.data_ptr(), ws.numel(), None, 0, 0, lib.stream()))
 if which in ("wgrad", "all"):
     run("bwd_weight", lambda: lib.call("hific_conv2d_bwd_weight", x.data_ptr(), gy.data_ptr(), dw.data_ptr(), *geom, 0, 1, 0, ws.data_ptr(), ws.numel(), lib.stream()))
