@@ -223,7 +223,11 @@ __device__ __forceinline__ void gc_epilogue(const GcParams& p, const GcPhase& ph
 // ---------------------------------------------------------------------------------------------------
 // Forward-type kernel
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int BC, int WGM, int WGN, int WM, int WN, int QB>
+// TPS = taps per barrier step.  Layers with few channels and many taps (7x7 / 11x11 with 3 channels, 5x5 hyperprior
+// convs, 3-channel outputs) run 2-4 MFMAs per wave per tap: with one tap per step the kernel is bound by the barrier and
+// the weight-tile latency of 49-121 steps (measured 610 us for the 60->3 7x7 layer whose MFMA time is ~80 us).  TPS
+// weight tiles are fetched, stored and consumed per step instead.
+template <typename T, int BC, int WGM, int WGN, int WM, int WN, int QB, int TPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB > 1 ? 1 : 2, QB > 1 ? 1 : 8)))
 void gconv_kernel(const GcParams p) {
     using Cfg = GcCfg<T>;
@@ -274,8 +278,8 @@ void gconv_kernel(const GcParams p) {
     const int iy0 = u0 * p.ist + ph.dy_min, ix0 = v0 * p.ist + ph.dx_min;
 
     int* toffs = (int*)smem;                          // [GC_MAXTAPS] tap -> patch row offset
-    unsigned char* wbuf = smem + 512;                 // 2 x WBYTES
-    unsigned char* patch = wbuf + 2 * WBYTES;         // npatch x PITCH
+    unsigned char* wbuf = smem + 512;                 // 2 x TPS x WBYTES
+    unsigned char* patch = wbuf + 2 * TPS * WBYTES;   // npatch x PITCH
     if (tid < ph.ntaps)
         toffs[tid] = ((int)p.tap_dy[ph.tap0 + tid] - ph.dy_min) * PWs + ((int)p.tap_dx[ph.tap0 + tid] - ph.dx_min);
 
@@ -305,16 +309,17 @@ void gconv_kernel(const GcParams p) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int nt = ph.ntaps;
+    const int ng = (nt + TPS - 1) / TPS;               // tap groups (steps) per channel chunk
     const int nchunks = p.Cpad / BC;
-    const int nsteps = nchunks * nt;
+    const int nsteps = nchunks * ng;
     const unsigned char* wp_ph = (const unsigned char*)p.wp + (size_t)ph.wp_off * sizeof(T);
     const size_t wrow_bytes = (size_t)nt * p.Cpad * sizeof(T);   // one m-row of this phase
 
-    // Weight tiles stream through a 2-deep LDS ring with a distance-2 register prefetch: at step s the loads of tile
-    // s+2 are issued right after the barrier and tile s+1 (loaded during step s-1) is written to the other LDS
-    // buffer after the MFMAs of step s, so every weight load has two full steps (~1000 MFMA cycles) to land.
+    // Weight tiles stream through a 2-deep LDS ring with a distance-2 register prefetch: at step s the loads of the
+    // tiles of step s+2 are issued right after the barrier and those of step s+1 (loaded during step s-1) are written to
+    // the other LDS buffer after the MFMAs of step s, so every weight load has two full steps to land.
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t wA[NWP], wB[NWP];
+    u32x4_t wA[TPS][NWP], wB[TPS][NWP];
     int wrow[NWP], wpart[NWP];
     const unsigned char* wsrc[NWP];
 #pragma unroll
@@ -322,27 +327,36 @@ void gconv_kernel(const GcParams p) {
         int piece = tid + i * 256;
         if (piece >= BM * PPR) piece = BM * PPR - 1;          // clamp (duplicate load) instead of a divergent branch
         wrow[i] = piece / PPR; wpart[i] = piece % PPR;
-        wsrc[i] = wp_ph + (size_t)(m0 + wrow[i]) * wrow_bytes + wpart[i] * 16;
+        // rows past K (zero padding of the M tile) re-read row K-1 instead: same cache line for every such lane, no L2
+        // traffic, and their outputs are never stored.  (K = 3 padded to 32 rows made every workgroup of the 60->3 7x7
+        // layer stream 200 KB of zeros: 349 of its 640 us.)
+        const int mrow = m0 + wrow[i] < p.K ? m0 + wrow[i] : p.K - 1;
+        wsrc[i] = wp_ph + (size_t)mrow * wrow_bytes + wpart[i] * 16;
     }
-    // byte offset of tile s = (tap s % nt, chunk s / nt); s clamped to the last tile
-    auto tile_off = [&](int s_) -> size_t {
+    // byte offset of tile j of step s = (tap (s % ng) * TPS + j, chunk s / ng); clamped to the last step / last tap
+    auto tile_off = [&](int s_, int j_) -> size_t {
         if (s_ >= nsteps) s_ = nsteps - 1;
-        const int c_ = s_ / nt, t_ = s_ - c_ * nt;
+        const int c_ = s_ / ng;
+        int t_ = (s_ - c_ * ng) * TPS + j_;
+        if (t_ >= nt) t_ = nt - 1;
         return ((size_t)t_ * p.Cpad + (size_t)c_ * BC) * sizeof(T);
     };
 #define GC_WLOAD(R, S_)                                                                     \
     do {                                                                                    \
-        const size_t off_ = tile_off(S_);                                                   \
-        _Pragma("unroll") for (int i = 0; i < NWP; ++i) R[i] = *(const u32x4_t*)(wsrc[i] + off_); \
+        _Pragma("unroll") for (int j = 0; j < TPS; ++j) {                                   \
+            const size_t off_ = tile_off(S_, j);                                            \
+            _Pragma("unroll") for (int i = 0; i < NWP; ++i) R[j][i] = *(const u32x4_t*)(wsrc[i] + off_); \
+        }                                                                                   \
     } while (0)
 #define GC_WSTORE(R, BUF)                                                                   \
     do {                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < TPS; ++j)                                     \
         _Pragma("unroll") for (int i = 0; i < NWP; ++i) {                                   \
             if (tid + i * 256 < BM * PPR) {                                                 \
-                unsigned char* d = (BUF) + wrow[i] * PITCH + wpart[i] * 16;                 \
-                if constexpr (PITCH % 16 == 0) { *(u32x4_t*)d = R[i]; }                     \
-                else { ((unsigned*)d)[0] = R[i].x; ((unsigned*)d)[1] = R[i].y;              \
-                       ((unsigned*)d)[2] = R[i].z; ((unsigned*)d)[3] = R[i].w; }            \
+                unsigned char* d = (BUF) + j * WBYTES + wrow[i] * PITCH + wpart[i] * 16;    \
+                if constexpr (PITCH % 16 == 0) { *(u32x4_t*)d = R[j][i]; }                  \
+                else { ((unsigned*)d)[0] = R[j][i].x; ((unsigned*)d)[1] = R[j][i].y;        \
+                       ((unsigned*)d)[2] = R[j][i].z; ((unsigned*)d)[3] = R[j][i].w; }      \
             }                                                                               \
         }                                                                                   \
     } while (0)
@@ -378,19 +392,24 @@ void gconv_kernel(const GcParams p) {
             }                                                                                                   \
         }                                                                                                       \
     } while (0)
-    // step s: RL = register set that receives tile s+2, RS = register set holding tile s+1
+    // step s: RL = register set that receives the tiles of step s+2, RS = register set holding those of step s+1
 #define GC_STEP(s, RL, RS)                                                                  \
     do {                                                                                    \
-        if (t == 0 && !((p.dbg & 1) && chunk > 0) && !(p.dbg & 64)) {                       \
+        if (g == 0 && !((p.dbg & 1) && chunk > 0) && !(p.dbg & 64)) {                       \
             __syncthreads();                                                                \
             stage_T<T, DWR, PITCH, QB>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode, \
                                        n0, p.NI, iy0, ix0, PWs, PH, PW, chunk * BC, tid, 256);  \
         }                                                                                   \
         if (!(p.dbg & 16)) __syncthreads();                                                 \
         if (!(p.dbg & 4)) GC_WLOAD(RL, (s) + 2);                                            \
-        if (!(p.dbg & 2)) GC_COMPUTE(wbuf + ((s) & 1) * WBYTES, t);                         \
-        if (!(p.dbg & 4)) GC_WSTORE(RS, wbuf + (((s) + 1) & 1) * WBYTES);                   \
-        if (++t == nt) { t = 0; ++chunk; }                                                  \
+        if (!(p.dbg & 2)) {                                                                 \
+            _Pragma("unroll") for (int j = 0; j < TPS; ++j) {                               \
+                const int t = g * TPS + j;                                                  \
+                if (TPS == 1 || t < nt) GC_COMPUTE(wbuf + (((s) & 1) * TPS + j) * WBYTES, t); \
+            }                                                                               \
+        }                                                                                   \
+        if (!(p.dbg & 4)) GC_WSTORE(RS, wbuf + (((s) + 1) & 1) * TPS * WBYTES);             \
+        if (++g == ng) { g = 0; ++chunk; }                                                  \
     } while (0)
 
     const u32x4_t dbgv = {(unsigned)tid, 1u, 2u, 3u};
@@ -398,7 +417,7 @@ void gconv_kernel(const GcParams p) {
         GC_WLOAD(wA, 0);
         GC_WLOAD(wB, 1);
         GC_WSTORE(wA, wbuf);
-        int chunk = 0, t = 0, s = 0;
+        int chunk = 0, g = 0, s = 0;
         for (; s + 1 < nsteps; s += 2) {
             GC_STEP(s, wA, wB);
             GC_STEP(s + 1, wB, wA);
@@ -556,7 +575,8 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
     for (int i = 0; i < NWP; ++i) {
         const int piece = tid + i * NTHR;
         wdst[i] = (unsigned)((piece / PPR) * PITCH + (piece % PPR) * 16);
-        wsrc[i] = wp_ph + (size_t)(m0 + piece / PPR) * wrow_bytes + (piece % PPR) * 16;
+        const int mrow = m0 + piece / PPR < p.K ? m0 + piece / PPR : p.K - 1;      // padded rows: see gconv_kernel
+        wsrc[i] = wp_ph + (size_t)mrow * wrow_bytes + (piece % PPR) * 16;
     }
 
     constexpr int PD = 2 / KSP;                                 // patch dword columns issued per step (steps 0..3)
@@ -1801,9 +1821,20 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         if (p.ph[i].OHt > OHt) OHt = p.ph[i].OHt;
         if (p.ph[i].OWt > OWt) OWt = p.ph[i].OWt;
     }
-    int wbytes = 512 + 2 * bm * PITCH;
     int maxtaps = 1;
     for (int i = 0; i < p.nphase; ++i) if (p.ph[i].ntaps > maxtaps) maxtaps = p.ph[i].ntaps;
+    // taps per barrier step (gconv_kernel TPS): 7 for >= 49 taps, 4 for >= 16, when the per-thread weight prefetch stays
+    // within 8 x 16 bytes per register set (few-row / few-channel tiles: exactly the layers that are barrier-bound)
+    auto pick_tps = [&](int bm_) -> int {
+        if (!std::is_same<T, bf16_t>::value || env_int("HIFIC_NO_TPS", 0)) return 1;
+        const int nwp = cdiv(bm_ * (BC * (int)sizeof(T) / 16), 256);
+        const int cand = maxtaps >= 49 ? 7 : (maxtaps >= 16 ? 4 : 1);
+        // ... and the weight ring must leave room for two co-resident workgroups (7 taps x 4.6 KB x 2 next to a 55 KB patch
+        // put the 60->3 layer at one workgroup per CU: 640 -> 790 us)
+        return (cand > 1 && nwp * cand <= 8 && 2 * cand * bm_ * PITCH <= 44 * 1024) ? cand : 1;
+    };
+    int tps = pick_tps(bm);
+    int wbytes = 512 + 2 * tps * bm * PITCH;
     // Full-LDS tiles (1 workgroup per CU, fewer halo re-reads) when they still give >= one workgroup per CU;
     // otherwise tiles small enough for two co-resident workgroups.
     bool tiled = false;
@@ -1825,7 +1856,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         const double eff128 = (double)p.K / (cdiv(p.K, 128) * 128.0) * (double)g128 / (double)(cdivl(g128, 256) * 256);
         const double eff64 = (double)p.K / (cdiv(p.K, 64) * 64.0) * (double)g64 / (double)(cdivl(g64, 512) * 512);
         if (g128 > 256 && g128 <= 512 && eff64 >= eff128 - 0.02 && eff128 < 0.8) {
-            bm = 64; p.Kpad = cdiv(p.K, bm) * bm; wbytes = 512 + 2 * bm * PITCH;
+            bm = 64; p.Kpad = cdiv(p.K, bm) * bm; tps = pick_tps(bm); wbytes = 512 + 2 * tps * bm * PITCH;
         }
     }
     long long wp_elems = 0;
@@ -1924,8 +1955,8 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     // computes on the padded plane, which is extra work, not extra useful FLOPs)
     const double aflops = p.aflops;
     char ptag[112];
-    snprintf(ptag, sizeof(ptag), "gconv K%d C%d N%d in%dx%d out%dx%d ph%d taps%d ist%d ost%d tile%dx%dx%d bm%d grid%d",
-             p.K, p.C, p.N, p.IH, p.IW, p.OHf, p.OWf, p.nphase, maxtaps, p.ist, p.ost, p.NI, p.TH, p.TW, bm,
+    snprintf(ptag, sizeof(ptag), "gconv K%d C%d N%d in%dx%d out%dx%d ph%d taps%d ist%d ost%d tile%dx%dx%d bm%d tps%d grid%d",
+             p.K, p.C, p.N, p.IH, p.IW, p.OHf, p.OWf, p.nphase, maxtaps, p.ist, p.ost, p.NI, p.TH, p.TW, bm, tps,
              max_tiles * (p.Kpad / bm) * p.nphase);
     char kname[PROF_NAMELEN];
     if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d%s>", bm / 64,
@@ -1942,8 +1973,13 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     const bool bigstage = kBigStage && tiled && lds > 80 * 1024 && env_int("HIFIC_BIGSTAGE", 0);
 #define GC_LAUNCH(WGM, WGN, WM, WN)                                                                      \
     do {                                                                                                 \
-        void (*kfn)(const GcParams) = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1>;                          \
-        if constexpr (kBigStage) { if (bigstage) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 12>; }      \
+        void (*kfn)(const GcParams) = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 1>;                       \
+        if constexpr (kBigStage) { if (bigstage) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 12, 1>; }   \
+        if constexpr (std::is_same<T, bf16_t>::value) {                                                  \
+            constexpr int nwp_ = (WGM * WM * 32 * (BC * (int)sizeof(T) / 16) + 255) / 256;               \
+            if constexpr (nwp_ * 4 <= 8) { if (tps == 4) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 4>; } \
+            if constexpr (nwp_ * 7 <= 8) { if (tps == 7) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 7>; } \
+        }                                                                                                \
         if (lds > 48 * 1024)                                                                             \
             hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);                                            \
