@@ -458,9 +458,24 @@ void gconv_kernel(const GcParams p) {
 // except that the pixels of rows/columns 1 and H-2 take the summed border line for the outermost tap and the pixels
 // of rows/columns 0 and H-1 read zero there (the reflection's adjoint folded into per-lane tap offsets).  No padded
 // 18x18 domain (27 % extra MFMA work, 1.5 waves of workgroups), no rim buffer, no fold kernel.
-template <int WM, int KSP, bool RFX>
-__global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2))) void gconv_sp9_kernel(const GcParams p) {
+// PHS != 0: the 9 (phase, tap) pairs of a kernel-3 stride-2 TRANSPOSED structure - conv-transpose forward (PHS = 1:
+// phases hold 1,2,2,4 taps) and the data gradient of a stride-2 conv (PHS = 2: 4,2,2,1) - in one pass over the INPUT
+// domain: all four sub-pixel phases read the same halo patch, so it is staged once per channel chunk (the phase-per-
+// launch-slice form staged it four times, 3 memory round trips for as little as ONE MFMA step) and each tap's MFMAs
+// accumulate into the accumulator set of its phase.  Four accumulator sets => 64-row tiles, one workgroup per CU.
+__host__ __device__ constexpr int sp9_phase(int phs, int t) {
+    return phs == 1 ? (t < 1 ? 0 : t < 3 ? 1 : t < 5 ? 2 : 3) : phs == 2 ? (t < 4 ? 0 : t < 6 ? 1 : t < 8 ? 2 : 3) : 0;
+}
+__host__ __device__ constexpr int sp9_tap_in_phase(int phs, int t) {
+    return phs == 1 ? (t < 1 ? t : t < 3 ? t - 1 : t < 5 ? t - 3 : t - 5)
+                    : phs == 2 ? (t < 4 ? t : t < 6 ? t - 4 : t < 8 ? t - 6 : t - 8) : t;
+}
+template <int WM, int KSP, bool RFX, int PHS>
+__global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(PHS ? 1 : 2, PHS ? 1 : 2)))
+void gconv_sp9_kernel(const GcParams p) {
     typedef bf16_t T;
+    static_assert(!(PHS && (RFX || KSP != 1)), "phase-merged mode: 4 waves, no reflect gather");
+    constexpr int NPH = PHS ? 4 : 1;
     constexpr int BC = 64, KS = 16, PITCH = 144, PPR = 8, WGN = 2, WN = 2, NT = 9, QJ = 3;
     constexpr int BM = 2 * WM * 32;
     constexpr int NTHR = 256 * KSP;
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
     const int wm = tw / WGN, wn = tw % WGN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    const GcPhase& ph = p.ph[0];
+    const GcPhase& ph = p.ph[PHS ? 4 : 0];            // PHS: slot 4 = the union of the four phases (plan: merged patch)
     const int ntile_ph = p.tiles_n * ph.tiles_y * ph.tiles_x;
     int tile, mtile;
     {
@@ -555,28 +570,35 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
         rfx_c[ni][2] = !RFX ? 0 : (j == W - 2 ? 3 * PITCH : (j == 0 ? RFX_ZERO : 0));
     }
 
-    f32x16_t acc[WM][WN];
+    f32x16_t acc[NPH][WM][WN];
 #pragma unroll
-    for (int mi = 0; mi < WM; ++mi)
+    for (int f = 0; f < NPH; ++f)
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni)
+        for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][mi][ni][r] = 0.f;
 
     const int nchunks = p.Cpad / BC;
-    const unsigned char* wp_ph = (const unsigned char*)p.wp + (size_t)ph.wp_off * sizeof(T);
-    const size_t wrow_bytes = (size_t)NT * p.Cpad * sizeof(T);
     const unsigned plane = (unsigned)(p.IH * p.IW);
     const bf16_t* inb = (const bf16_t*)p.in;
 
+    // packed weights are per phase [Kpad][taps of the phase][Cpad]: one source pointer set per phase
     unsigned wdst[NWP];
-    const unsigned char* wsrc[NWP];
+    const unsigned char* wsrc[NPH][NWP];
 #pragma unroll
-    for (int i = 0; i < NWP; ++i) {
-        const int piece = tid + i * NTHR;
-        wdst[i] = (unsigned)((piece / PPR) * PITCH + (piece % PPR) * 16);
-        const int mrow = m0 + piece / PPR < p.K ? m0 + piece / PPR : p.K - 1;      // padded rows: see gconv_kernel
-        wsrc[i] = wp_ph + (size_t)mrow * wrow_bytes + (piece % PPR) * 16;
+    for (int f = 0; f < NPH; ++f) {
+        const GcPhase& pf = p.ph[f];
+        const unsigned char* wp_ph = (const unsigned char*)p.wp + (size_t)pf.wp_off * sizeof(T);
+        const size_t wrow_bytes = (size_t)pf.ntaps * p.Cpad * sizeof(T);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int piece = tid + i * NTHR;
+            wdst[i] = (unsigned)((piece / PPR) * PITCH + (piece % PPR) * 16);
+            const int mrow = m0 + piece / PPR < p.K ? m0 + piece / PPR : p.K - 1;      // padded rows: see gconv_kernel
+            wsrc[f][i] = wp_ph + (size_t)mrow * wrow_bytes + (piece % PPR) * 16;
+        }
     }
 
     constexpr int PD = 2 / KSP;                                 // patch dword columns issued per step (steps 0..3)
@@ -591,8 +613,9 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
     // weight tile (chunk cc, tap tt); tiles past the end re-read the last chunk (never consumed)
 #define SP_WISSUE(SET, cc, tt)                                                                     \
     do { const int c_ = (cc) < nchunks ? (cc) : nchunks - 1;                                       \
-         const size_t off_ = ((size_t)(tt) * p.Cpad + (size_t)c_ * BC) * sizeof(T);                \
-         _Pragma("unroll") for (int i = 0; i < NWP; ++i) wS[SET][i] = *(const u32x4_t*)(wsrc[i] + off_); } while (0)
+         const size_t off_ = ((size_t)sp9_tap_in_phase(PHS, tt) * p.Cpad + (size_t)c_ * BC) * sizeof(T); \
+         _Pragma("unroll") for (int i = 0; i < NWP; ++i)                                           \
+             wS[SET][i] = *(const u32x4_t*)(wsrc[sp9_phase(PHS, tt)][i] + off_); } while (0)
 #define SP_WRETIRE(SET, SLOT)                                                                      \
     do { _Pragma("unroll") for (int i = 0; i < NWP; ++i)                                           \
              *(u32x4_t*)(wbuf + (SLOT) * WBYTES + wdst[i]) = wS[SET][i]; } while (0)
@@ -642,7 +665,8 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
                 b[ni] = *(const bf16x8_t*)(pcur + bo[ni] + kk * 32);                                            \
             _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
                 _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                               \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);  \
+                    acc[sp9_phase(PHS, tt)][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                 \
+                        a[mi], b[ni], acc[sp9_phase(PHS, tt)][mi][ni], 0, 0, 0);                                \
         }                                                                                                       \
     } while (0)
     // step tt of the current chunk: tile (chunk, tt) sits in ring slot tt%3; issue into register set tt%3,
@@ -688,27 +712,33 @@ __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mine[(mi * 16 + r) * 64] = acc[mi][1][r];
+                for (int r = 0; r < 16; ++r) mine[(mi * 16 + r) * 64] = acc[0][mi][1][r];
         } else {
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mine[(mi * 16 + r) * 64] = acc[mi][0][r];
+                for (int r = 0; r < 16; ++r) mine[(mi * 16 + r) * 64] = acc[0][mi][0][r];
         }
         __syncthreads();
         if (kgrp == 0) {
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][0][r] += theirs[(mi * 16 + r) * 64];
+                for (int r = 0; r < 16; ++r) acc[0][mi][0][r] += theirs[(mi * 16 + r) * 64];
         } else {
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][1][r] += theirs[(mi * 16 + r) * 64];
+                for (int r = 0; r < 16; ++r) acc[0][mi][1][r] += theirs[(mi * 16 + r) * 64];
         }
     }
-    gc_epilogue<false, WM, WN>(p, ph, acc, m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid, KSP == 2 ? kgrp : -1);
+    if constexpr (PHS != 0) {
+#pragma unroll
+        for (int f = 0; f < NPH; ++f)
+            gc_epilogue<false, WM, WN>(p, p.ph[f], acc[f], m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid, -1);
+    } else {
+        gc_epilogue<false, WM, WN>(p, ph, acc[0], m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid, KSP == 2 ? kgrp : -1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1799,6 +1829,30 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                            long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
     using Cfg = GcCfg<T>;
     constexpr int PITCH = BC * (int)sizeof(T) + Cfg::PAD;
+    // Phase-merged software-pipelined kernel (gconv_sp9_kernel PHS) for the kernel-3 stride-2 transposed structure:
+    // four phases with 1,2,2,4 (conv-transpose forward) or 4,2,2,1 (stride-2 conv data gradient) taps over a stride-1
+    // bf16 input.  Decided here because it fixes the M tile (four accumulator sets => 64 rows).
+    int phs = 0;
+    int u_dymin = 0, u_dymax = 0, u_dxmin = 0, u_dxmax = 0;
+    if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
+        // >= 4 channel chunks: the software pipeline needs chunks to overlap; single-chunk large-plane layers are
+        // HBM/epilogue-bound and did better with two co-resident generic workgroups (K60 C120 @128x128: 205 -> 230 us,
+        // K480 C960 @16x16: 134 -> 89 us)
+        if (p.nphase == 4 && p.ist == 1 && !p.in_f32 && p.K > 32 && p.C >= 256 && !p.rfx && !env_int("HIFIC_NO_PHS", 0)) {
+            const int n0_ = p.ph[0].ntaps, n1_ = p.ph[1].ntaps, n2_ = p.ph[2].ntaps, n3_ = p.ph[3].ntaps;
+            if (n0_ == 1 && n1_ == 2 && n2_ == 2 && n3_ == 4) phs = 1;
+            else if (n0_ == 4 && n1_ == 2 && n2_ == 2 && n3_ == 1) phs = 2;
+            if (phs) {
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = p.tap_dy[t], dx = p.tap_dx[t];
+                    if (t == 0) { u_dymin = u_dymax = dy; u_dxmin = u_dxmax = dx; }
+                    if (dy < u_dymin) u_dymin = dy; if (dy > u_dymax) u_dymax = dy;
+                    if (dx < u_dxmin) u_dxmin = dx; if (dx > u_dxmax) u_dxmax = dx;
+                }
+                for (int i = 0; i < 4; ++i) if (p.ph[i].tap0 != (i == 0 ? 0 : p.ph[i - 1].tap0 + p.ph[i - 1].ntaps)) phs = 0;
+            }
+        }
+    }
     // M tile
     int bm;
     {
@@ -1808,6 +1862,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         else bm = 128;
         int e = env_int("HIFIC_BM", 0);
         if ((e == 64 || e == 128) && p.K > 32) bm = e;
+        if (phs) bm = 64;
     }
     p.Kpad = cdiv(p.K, bm) * bm;
     p.Cpad = cdiv(p.C, BC) * BC;
@@ -1838,14 +1893,25 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     // Full-LDS tiles (1 workgroup per CU, fewer halo re-reads) when they still give >= one workgroup per CU;
     // otherwise tiles small enough for two co-resident workgroups.
     bool tiled = false;
-    if (choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, kLdsBudget, p.TH, p.TW, p.NI, maxtaps)) {
+    if (phs) {
+        // one merged patch for the four phases: union of the tap offsets, at most 192 pixels (3 per lane)
+        span_y = u_dymax - u_dymin + 1; span_x = u_dxmax - u_dxmin + 1;
+        if (choose_tile(p.N, OHt, OWt, 1, span_y, span_x, PITCH, 0, 192 * PITCH, p.TH, p.TW, p.NI, 9) && p.NI == 1) {
+            tiled = true; tps = 1; wbytes = 512 + 2 * bm * PITCH;
+        } else {
+            phs = 0;      // no tile fits: the generic kernel with the 64-row tiles already chosen
+            span_y = 1; span_x = 1;
+            for (int i = 0; i < p.nphase; ++i) { if (p.ph[i].PH > span_y) span_y = p.ph[i].PH; if (p.ph[i].PW > span_x) span_x = p.ph[i].PW; }
+        }
+    }
+    if (!phs && choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, kLdsBudget, p.TH, p.TW, p.NI, maxtaps)) {
         const long long g = (long long)cdiv(OHt, p.TH) * cdiv(OWt, p.TW) * cdiv(p.N, p.NI) * (p.Kpad / bm) * p.nphase;
         tiled = g >= env_int("HIFIC_GC_BIGTILE_MIN_GRID", 256);
     }
     if (!tiled && !choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, 72 * 1024, p.TH, p.TW, p.NI, maxtaps))
         return HIFIC_ERR_UNSUPPORTED;
     p.tiles_n = cdiv(p.N, p.NI);
-    if (bm == 128 && !env_int("HIFIC_NO_BM_TAIL", 0)) {
+    if (bm == 128 && !phs && !env_int("HIFIC_NO_BM_TAIL", 0)) {
         // 128-row tiles run one workgroup per CU: a grid of e.g. 1.5 x 256 workgroups (18x18 padded-gradient
         // domain of the 16x16x960 layers) leaves half the chip idle in its second wave.  64-row tiles co-reside two
         // per CU, so the same launch quantises at 512 slots.
@@ -1888,6 +1954,23 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         use_sp9 = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 &&
                   p.NI * p.ph[0].PH * p.ph[0].PW <= 192 && !env_int("HIFIC_NO_SP", 0) &&
                   64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(p.NI * p.ph[0].PH * p.ph[0].PW + 2) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
+    }
+    if (phs) {
+        GcPhase& u = p.ph[4];
+        memset(&u, 0, sizeof(u));
+        u.ntaps = 9; u.tap0 = 0; u.dy_min = u_dymin; u.dx_min = u_dxmin;
+        u.PH = (p.TH - 1) + (u_dymax - u_dymin + 1); u.PW = (p.TW - 1) + (u_dxmax - u_dxmin + 1); u.PWs = u.PW;
+        for (int i = 0; i < 4; ++i) {
+            if (p.ph[i].tiles_y > u.tiles_y) u.tiles_y = p.ph[i].tiles_y;
+            if (p.ph[i].tiles_x > u.tiles_x) u.tiles_x = p.ph[i].tiles_x;
+            if (p.ph[i].OHt > u.OHt) u.OHt = p.ph[i].OHt;
+            if (p.ph[i].OWt > u.OWt) u.OWt = p.ph[i].OWt;
+        }
+        max_tiles = p.tiles_n * u.tiles_y * u.tiles_x;
+        const int npatch = p.NI * u.PH * u.PW;
+        use_sp9 = npatch <= 192 &&
+                  64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(npatch + 2) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
+        if (!use_sp9) phs = 0;
     }
     if (p.rfx) {
         // gather-form reflect gradient: only gconv_sp9_kernel implements the per-lane tap displacements, and the border
@@ -1950,7 +2033,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         }
     }
     p.max_tiles = max_tiles;
-    dim3 grid(max_tiles * (p.Kpad / bm), 1, p.nphase);
+    dim3 grid(max_tiles * (p.Kpad / bm), 1, phs ? 1 : p.nphase);
     // algorithmic FLOPs of the op (set by the caller on the op's REAL output domain: a reflect-padded data gradient
     // computes on the padded plane, which is extra work, not extra useful FLOPs)
     const double aflops = p.aflops;
@@ -1960,9 +2043,9 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
              max_tiles * (p.Kpad / bm) * p.nphase);
     char kname[PROF_NAMELEN];
     if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d%s>", bm / 64,
-                          p.rfx ? (bm == 128 ? 2 : 1)
+                          phs ? 1 : p.rfx ? (bm == 128 ? 2 : 1)
                                 : ((env_int("HIFIC_SP9_KSPLIT", 2) == 2 && (bm == 128 || env_int("HIFIC_SP9_KSPLIT64", 0))) ? 2 : 1),
-                          p.rfx ? ",rfx" : "");
+                          phs ? (phs == 1 ? ",phs1" : ",phs2") : (p.rfx ? ",rfx" : ""));
     else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
                   bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
     const int pslot = prof_open(kname, aflops, st, ptag);
@@ -1988,18 +2071,20 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
         // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, patch <= 192 pixels
         if (use_sp9) {
-            const int npatch = p.NI * p.ph[0].PH * p.ph[0].PW;
+            const int npatch = phs ? p.NI * p.ph[4].PH * p.ph[4].PW : p.NI * p.ph[0].PH * p.ph[0].PW;
             const size_t lds_sp = 64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(npatch + 2) * PITCH + 15) & ~(size_t)15);
             if (lds_sp <= (size_t)kLdsBudget) {
                 const bool ks2 = env_int("HIFIC_SP9_KSPLIT", 2) == 2;
-#define SP9_LAUNCH(WM_, KSP_, RFX_)                                                                                 \
+#define SP9_LAUNCH(WM_, KSP_, RFX_, PHS_)                                                                           \
     do {                                                                                                            \
-        hipFuncSetAttribute((const void*)gconv_sp9_kernel<WM_, KSP_, RFX_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp); \
-        hipLaunchKernelGGL((gconv_sp9_kernel<WM_, KSP_, RFX_>), grid, dim3(256 * KSP_), lds_sp, st, p);             \
+        hipFuncSetAttribute((const void*)gconv_sp9_kernel<WM_, KSP_, RFX_, PHS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp); \
+        hipLaunchKernelGGL((gconv_sp9_kernel<WM_, KSP_, RFX_, PHS_>), grid, dim3(256 * KSP_), lds_sp, st, p);       \
     } while (0)
-                if (p.rfx) { if (bm == 128) SP9_LAUNCH(2, 2, true); else SP9_LAUNCH(1, 1, true); }
-                else if (bm == 128) { if (ks2) SP9_LAUNCH(2, 2, false); else SP9_LAUNCH(2, 1, false); }
-                else { if (ks2 && env_int("HIFIC_SP9_KSPLIT64", 0)) SP9_LAUNCH(1, 2, false); else SP9_LAUNCH(1, 1, false); }
+                if (phs == 1) SP9_LAUNCH(1, 1, false, 1);
+                else if (phs == 2) SP9_LAUNCH(1, 1, false, 2);
+                else if (p.rfx) { if (bm == 128) SP9_LAUNCH(2, 2, true, 0); else SP9_LAUNCH(1, 1, true, 0); }
+                else if (bm == 128) { if (ks2) SP9_LAUNCH(2, 2, false, 0); else SP9_LAUNCH(2, 1, false, 0); }
+                else { if (ks2 && env_int("HIFIC_SP9_KSPLIT64", 0)) SP9_LAUNCH(1, 2, false, 0); else SP9_LAUNCH(1, 1, false, 0); }
 #undef SP9_LAUNCH
                 sp_done = true;
             }
