@@ -38,6 +38,7 @@ struct GcParams {
     int tap_sw;          // kernel width S (weight tap index = r*S + s)
     int dbg;             // ablation flags for micro-benchmarks (HIFIC_DBG; 0 in production)
     double aflops;       // algorithmic FLOPs of the op on its real output domain (profiler only)
+    int epi_wide;        // wide-store epilogue through LDS (gc_epilogue_wide): legality checked by the plan
     int rfx;             // gather-form reflect data gradient (gconv_sp9_kernel RFX): `in` is the extended gradient
     // reflect-padded data gradient: `out` is the f32 padded plane buffer (only its rim is written); pixels inside
     // [fold_pt, fold_pt+fold_h) x [fold_pl, fold_pl+fold_w) go straight to out2 = dx[N,K,fold_h,fold_w]

@@ -147,75 +147,161 @@ __device__ __forceinline__ void stage_T(unsigned char* lds, const void* src, int
 // store instruction).  Everything that needs a LOAD is issued unconditionally up front: a load inside a (even
 // wave-uniform) branch makes hipcc wait `vmcnt(0)` right behind it, and the per-element `if (p.bias) v += p.bias[m]`
 // this replaces was 16*WM*WN serialised L2 round trips at the end of every workgroup (~10 us on a 90 us launch).
-// NI_ONLY >= 0: this wave writes only that pixel fragment (K-split kernels).
 // ---------------------------------------------------------------------------------------------------
-template <bool TF32, int WM, int WN>
-__device__ __forceinline__ void gc_epilogue(const GcParams& p, const GcPhase& ph, f32x16_t (&acc)[WM][WN], int mbase,
-                                            int lhi, const int (&pu)[WN], const int (&pv)[WN], const int (&pn)[WN],
-                                            const bool (&pvalid)[WN], int ni_only) {
+// One (32-row block mi, pixel fragment ni) of the tile; the accumulator vector arrives BY VALUE and every index is a
+// compile-time constant (references to the accumulator array / runtime fragment indices made hipcc keep the whole
+// accumulator array in scratch on some instantiations).
+template <bool TF32>
+__device__ __forceinline__ void gc_store_block(const GcParams& p, const GcPhase& ph, const f32x16_t a, int mi, int mbase,
+                                               int lhi, int pu_, int pv_, int pn_, bool pvalid_, bool hb, const float* bp,
+                                               float slope) {
     const bool out_f32 = TF32 || p.out_f32;
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        bv[r] = bp[(hb && m < p.K) ? m : 0];
+    }
+    const int oy = pu_ * p.ost + ph.ooy, ox = pv_ * p.ost + ph.oox;
+    const bool okp = pvalid_ && pn_ < p.N && pu_ < ph.OHt && pv_ < ph.OWt &&
+                     (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
+    if (!okp) return;
+    size_t plane = (size_t)p.OHf * p.OWf;
+    size_t pbase = (size_t)pn_ * p.K * plane + (size_t)oy * p.OWf + ox;
+    void* optr = p.out;
+    bool of32 = out_f32;
+    if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
+        const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
+        if ((unsigned)iy < (unsigned)p.fold_h && (unsigned)ix < (unsigned)p.fold_w) {
+            plane = (size_t)p.fold_h * p.fold_w;
+            pbase = (size_t)pn_ * p.K * plane + (size_t)iy * p.fold_w + ix;
+            optr = p.out2; of32 = TF32 || p.out2_f32;
+        }
+    }
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        v[r] = a[r] + ((hb && m < p.K) ? bv[r] : 0.f);
+    }
+    if (p.resid) {          // rare path (no caller on the HiFIC graph fuses a residual): loads batched per fragment
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const size_t idx = pbase + (size_t)(m < p.K ? m : 0) * plane;
+            rv[r] = out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += rv[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float y = v[r] > 0.f ? v[r] : v[r] * slope;
+        if (m < p.K) {
+            const size_t idx = pbase + (size_t)m * plane;
+            if (of32) ((float*)optr)[idx] = y; else ((bf16_t*)optr)[idx] = f2bf(y);
+        }
+    }
+}
+// NI_ONLY >= 0: this wave writes only that pixel fragment (K-split kernels); -1: all.
+template <bool TF32, int WM, int WN, int NI_ONLY>
+__device__ __forceinline__ void gc_epilogue(const GcParams& p, const GcPhase& ph, const f32x16_t a00, const f32x16_t a01,
+                                            const f32x16_t a10, const f32x16_t a11, int mbase, int lhi,
+                                            const int (&pu)[WN], const int (&pv)[WN], const int (&pn)[WN],
+                                            const bool (&pvalid)[WN]) {
     const bool hb = p.bias != nullptr;
-    const float* bp = hb ? p.bias : (const float*)p.in;          // always a readable address; masked below
-    float bv[WM][16];
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            bv[mi][r] = bp[(hb && m < p.K) ? m : 0];
-        }
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            bv[mi][r] = (hb && m < p.K) ? bv[mi][r] : 0.f;
-        }
+    const float* bp = hb ? p.bias : (const float*)p.in;          // always a readable address; masked in the block
     const float slope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LEAKY ? 0.2f : 1.f);
-#pragma unroll
-    for (int ni = 0; ni < WN; ++ni) {
-        if (ni_only >= 0 && ni != ni_only) continue;
-        const int oy = pu[ni] * p.ost + ph.ooy, ox = pv[ni] * p.ost + ph.oox;
-        const bool okp = pvalid[ni] && pn[ni] < p.N && pu[ni] < ph.OHt && pv[ni] < ph.OWt &&
-                         (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
-        if (!okp) continue;
-        size_t plane = (size_t)p.OHf * p.OWf;
-        size_t pbase = (size_t)pn[ni] * p.K * plane + (size_t)oy * p.OWf + ox;
-        void* optr = p.out;
-        bool of32 = out_f32;
-        if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
-            const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
-            if ((unsigned)iy < (unsigned)p.fold_h && (unsigned)ix < (unsigned)p.fold_w) {
-                plane = (size_t)p.fold_h * p.fold_w;
-                pbase = (size_t)pn[ni] * p.K * plane + (size_t)iy * p.fold_w + ix;
-                optr = p.out2; of32 = TF32 || p.out2_f32;
-            }
+    if constexpr (NI_ONLY < 0 || NI_ONLY == 0) {
+        gc_store_block<TF32>(p, ph, a00, 0, mbase, lhi, pu[0], pv[0], pn[0], pvalid[0], hb, bp, slope);
+        if constexpr (WM == 2) gc_store_block<TF32>(p, ph, a10, 1, mbase, lhi, pu[0], pv[0], pn[0], pvalid[0], hb, bp, slope);
+    }
+    if constexpr (WN == 2 && (NI_ONLY < 0 || NI_ONLY == 1)) {
+        gc_store_block<TF32>(p, ph, a01, 0, mbase, lhi, pu[WN - 1], pv[WN - 1], pn[WN - 1], pvalid[WN - 1], hb, bp, slope);
+        if constexpr (WM == 2) gc_store_block<TF32>(p, ph, a11, 1, mbase, lhi, pu[WN - 1], pv[WN - 1], pn[WN - 1], pvalid[WN - 1], hb, bp, slope);
+    }
+}
+
+// Wide-store epilogue (p.epi_wide, set by the plan when it is legal): the per-element NCHW stores above are 2 bytes
+// per lane - 16*WM*WN store instructions per thread, store-ISSUE bound (58 of the 216 us of the 60->120 stride-2
+// layer, 1.1 TB/s).  Here each wave transposes its (WM*32 rows) x (NIW*32 pixels) bf16 tile through a private LDS
+// region and writes it back as 16-byte pieces (8 consecutive pixels of one row): 8x fewer store instructions.
+// Requirements checked on the host: output stride 1, bf16 output, no fold / residual, TW % 8 == 0, OWf % 8 == 0,
+// OWt % 8 == 0 (a piece is entirely inside or entirely outside the image).
+template <int WN, int NI_ONLY>
+__device__ __forceinline__ void gc_wide_rows(const GcParams& p, const f32x16_t a0, const f32x16_t a1, int mi, int mbase,
+                                             int lhi, int l31, bool hb, const float* bp, float slope, int ni0, int rowb,
+                                             unsigned char* wave_lds) {
+    float bv[16];                                           // the 16 bias loads of a row block in flight together
+#pragma unroll 16
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        bv[r] = bp[(hb && m < p.K) ? m : 0];
+    }
+    float va[16], vb[16];
+#pragma unroll 16
+    for (int r = 0; r < 16; ++r) {
+        const int ml = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float b_ = (hb && mbase + ml < p.K) ? bv[r] : 0.f;
+        const float x0 = a0[r] + b_, x1 = a1[r] + b_;
+        va[r] = x0 > 0.f ? x0 : x0 * slope;
+        vb[r] = x1 > 0.f ? x1 : x1 * slope;
+    }
+    if constexpr (NI_ONLY < 0 || NI_ONLY == 0) {
+#pragma unroll 16
+        for (int r = 0; r < 16; ++r) {
+            const int ml = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            *(bf16_t*)(wave_lds + ml * rowb + ((0 - ni0) * 32 + l31) * 2) = f2bf(va[r]);
         }
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi) {
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r] + bv[mi][r];
-            if (p.resid) {          // rare path (no caller on the HiFIC graph fuses a residual): loads batched per fragment
-                float rv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const size_t idx = pbase + (size_t)(m < p.K ? m : 0) * plane;
-                    rv[r] = out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += rv[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const float y = v[r] > 0.f ? v[r] : v[r] * slope;
-                if (m < p.K) {
-                    const size_t idx = pbase + (size_t)m * plane;
-                    if (of32) ((float*)optr)[idx] = y; else ((bf16_t*)optr)[idx] = f2bf(y);
-                }
-            }
+    }
+    if constexpr (WN >= 2 && (NI_ONLY < 0 || NI_ONLY == 1)) {
+#pragma unroll 16
+        for (int r = 0; r < 16; ++r) {
+            const int ml = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            *(bf16_t*)(wave_lds + ml * rowb + ((1 - ni0) * 32 + l31) * 2) = f2bf(vb[r]);
+        }
+    }
+}
+
+// NI_ONLY is a template parameter on purpose: with a runtime fragment index hipcc turns `for ni: if (ni == k)` into a
+// dynamically indexed accumulator access and moves the whole accumulator array to scratch (seen: 320 B/lane, every
+// MFMA step re-loading its accumulators).
+// The accumulators arrive BY VALUE, one vector per (row block, pixel fragment): a reference to the accumulator array
+// kept it in scratch on the WM = 2 kernels.
+template <int WM, int WN, int NI_ONLY>
+__device__ __forceinline__ void gc_epilogue_wide(const GcParams& p, const GcPhase& ph, const f32x16_t a00, const f32x16_t a01,
+                                                 const f32x16_t a10, const f32x16_t a11, int mbase,
+                                                 int lane, int wn, int u0, int v0, int n0, unsigned char* wave_lds) {
+    constexpr int ni_only = NI_ONLY;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const bool hb = p.bias != nullptr;
+    const float* bp = hb ? p.bias : (const float*)p.in;
+    const float slope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LEAKY ? 0.2f : 1.f);
+    const int niw = ni_only >= 0 ? 1 : WN;                  // pixel fragments written by this wave
+    const int ni0 = ni_only >= 0 ? ni_only : 0;
+    const int rowb = niw * 64 + 16;                         // bytes per LDS row (padding: conflict-free 16-byte reads)
+    // one 32-row block at a time through a helper with compile-time accumulator indices (an `mi` loop left the
+    // accumulators dynamically indexed on the WM = 2 kernels)
+    gc_wide_rows<WN, NI_ONLY>(p, a00, a01, 0, mbase, lhi, l31, hb, bp, slope, ni0, rowb, wave_lds);
+    if constexpr (WM == 2) gc_wide_rows<WN, NI_ONLY>(p, a10, a11, 1, mbase, lhi, l31, hb, bp, slope, ni0, rowb, wave_lds);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's LDS writes landed (private region)
+    const int gpr = niw * 4;                                // 16-byte pieces per row
+    const int npieces = WM * 32 * gpr;
+    const int thw = p.TH * p.TW;
+    const size_t plane = (size_t)p.OHf * p.OWf;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    for (int q = lane; q < npieces; q += 64) {
+        const int ml = q / gpr, g = q - ml * gpr;
+        const int pt = (wn * WN + ni0) * 32 + g * 8;        // first pixel of the piece inside the 128-pixel tile
+        const int img = pt / thw;
+        const int rem = pt - img * thw;
+        const int ty_ = rem / p.TW, tx_ = rem - ty_ * p.TW;
+        const int m = mbase + ml, n = n0 + img, oy = u0 + ty_ + ph.ooy, ox = v0 + tx_ + ph.oox;
+        if (m < p.K && img < p.NI && n < p.N && u0 + ty_ < ph.OHt && v0 + tx_ < ph.OWt) {
+            const u32x4_t v = *(const u32x4_t*)(wave_lds + ml * rowb + g * 16);
+            *(u32x4_t*)((bf16_t*)p.out + ((size_t)n * p.K + m) * plane + (size_t)oy * p.OWf + ox) = v;
         }
     }
 }
@@ -433,7 +519,17 @@ void gconv_kernel(const GcParams p) {
         if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = acc[0][0][1];
         return;
     }
-    gc_epilogue<std::is_same<T, float>::value, WM, WN>(p, ph, acc, m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid, -1);
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (p.epi_wide) {
+            __syncthreads();                       // every wave is done with the operand buffers
+            gc_epilogue_wide<WM, WN, -1>(p, ph, acc[0][0], acc[0][WN - 1], acc[WM - 1][0], acc[WM - 1][WN - 1],
+                                         m0 + wm * WM * 32, lane, wn, u0, v0, n0,
+                                         smem + (size_t)wave * (WM * 32) * (WN * 64 + 16));
+            return;
+        }
+    }
+    gc_epilogue<std::is_same<T, float>::value, WM, WN, -1>(p, ph, acc[0][0], acc[0][WN - 1], acc[WM - 1][0], acc[WM - 1][WN - 1],
+                                                        m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -735,9 +831,34 @@ void gconv_sp9_kernel(const GcParams p) {
     if constexpr (PHS != 0) {
 #pragma unroll
         for (int f = 0; f < NPH; ++f)
-            gc_epilogue<false, WM, WN>(p, p.ph[f], acc[f], m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid, -1);
+            gc_epilogue<false, WM, WN, -1>(p, p.ph[f], acc[f][0][0], acc[f][0][WN - 1], acc[f][WM - 1][0], acc[f][WM - 1][WN - 1],
+                                           m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid);
     } else {
-        gc_epilogue<false, WM, WN>(p, ph, acc[0], m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid, KSP == 2 ? kgrp : -1);
+        // (WM == 2 instantiations sit at the 256-register cap: with this path compiled in, the allocator spilled the
+        //  accumulators across the chunk loop - 320 B/lane of scratch; their 7.8 MB outputs are not store-bound anyway)
+        if (WM == 1 && p.epi_wide) {
+            __syncthreads();                       // operand buffers / exchange slots are free
+            unsigned char* wl = smem + (size_t)wave * (WM * 32) * ((KSP == 2 ? 1 : WN) * 64 + 16);
+            if constexpr (KSP == 2) {
+                if (kgrp == 0) gc_epilogue_wide<WM, WN, 0>(p, ph, acc[0][0][0], acc[0][0][1], acc[0][WM - 1][0], acc[0][WM - 1][1],
+                                                           m0 + wm * WM * 32, lane, wn, u0, v0, n0, wl);
+                else gc_epilogue_wide<WM, WN, 1>(p, ph, acc[0][0][0], acc[0][0][1], acc[0][WM - 1][0], acc[0][WM - 1][1],
+                                                 m0 + wm * WM * 32, lane, wn, u0, v0, n0, wl);
+            } else {
+                gc_epilogue_wide<WM, WN, -1>(p, ph, acc[0][0][0], acc[0][0][1], acc[0][WM - 1][0], acc[0][WM - 1][1],
+                                             m0 + wm * WM * 32, lane, wn, u0, v0, n0, wl);
+            }
+            return;
+        }
+        if constexpr (KSP == 2) {
+            if (kgrp == 0) gc_epilogue<false, WM, WN, 0>(p, ph, acc[0][0][0], acc[0][0][1], acc[0][WM - 1][0], acc[0][WM - 1][1],
+                                                         m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid);
+            else gc_epilogue<false, WM, WN, 1>(p, ph, acc[0][0][0], acc[0][0][1], acc[0][WM - 1][0], acc[0][WM - 1][1],
+                                               m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid);
+        } else {
+            gc_epilogue<false, WM, WN, -1>(p, ph, acc[0][0][0], acc[0][0][1], acc[0][WM - 1][0], acc[0][WM - 1][1],
+                                           m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid);
+        }
     }
 }
 
@@ -1948,6 +2069,17 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         if (b > lds) lds = b;
     }
     if (lds > (size_t)kLdsBudget) return HIFIC_ERR_UNSUPPORTED;
+    // wide-store epilogue (gc_epilogue_wide): one phase, output stride 1, bf16 output written straight to `out`, pieces of
+    // 8 pixels never straddle a tile row / the image edge, no residual
+    p.epi_wide = 0;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (p.nphase == 1 && p.ost == 1 && !p.out_f32 && !p.fold_h && !p.resid && p.TW % 8 == 0 && p.OWf % 8 == 0 &&
+            p.ph[0].OWt % 8 == 0 && p.ph[0].ooy == 0 && p.ph[0].oox == 0 && !env_int("HIFIC_NO_WIDE_EPI", 0)) {
+            p.epi_wide = 1;
+            const size_t need = (size_t)4 * (bm / 2 < 32 ? 32 : bm / 2) * (2 * 64 + 16);     // 4 waves x rows x row bytes
+            if (need > lds) lds = need;
+        }
+    }
     // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, bf16 input, halo patch <= 192 pixels
     bool use_sp9 = false;
     if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
