@@ -38,6 +38,10 @@ struct GcParams {
     int tap_sw;          // kernel width S (weight tap index = r*S + s)
     int dbg;             // ablation flags for micro-benchmarks (HIFIC_DBG; 0 in production)
     double aflops;       // algorithmic FLOPs of the op on its real output domain (profiler only)
+    // virtual channels (few-channel layers, see launch_gconv_fewc): reduction channel cc = c * csplit + j reads weight
+    // column vcol_s[j]; output row mm = k * msplit + j reads weight column vrow_s[j] (0: off)
+    int csplit, msplit;
+    short vcol_s[16];
     int epi_wide;        // wide-store epilogue through LDS (gc_epilogue_wide): legality checked by the plan
     int rfx;             // gather-form reflect data gradient (gconv_sp9_kernel RFX): `in` is the extended gradient
     // reflect-padded data gradient: `out` is the f32 padded plane buffer (only its rim is written); pixels inside

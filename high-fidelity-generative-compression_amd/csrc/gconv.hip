@@ -865,6 +865,15 @@ void gconv_sp9_kernel(const GcParams p) {
 // ---------------------------------------------------------------------------------------------------
 // Weight packing: wp[phase][m][t][c] = w[m*sm + c*sc + r_t*sr + s_t*ss] * scale   (zero padded)
 // ---------------------------------------------------------------------------------------------------
+// Source index of packed element (row m, reduction channel c, tap (r, s)).  With virtual channels (csplit) the packed
+// channel cc = c * csplit + j stands for channel c at kernel column vcol_s[j]; with virtual rows (msplit) the packed row
+// mm = k * msplit + j stands for output channel k at kernel column vcol_s[j] (the tap then only carries the kernel row).
+__host__ __device__ __forceinline__ long long gc_weight_index(const GcParams& p, int m, int c, int r, int s, long long sm,
+                                                              long long sc, long long sr, long long ss) {
+    if (p.csplit) { s = p.vcol_s[c % p.csplit]; c = c / p.csplit; }
+    if (p.msplit) { s = p.vcol_s[m % p.msplit]; m = m / p.msplit; }
+    return m * sm + c * sc + r * sr + s * ss;
+}
 template <typename T>
 __global__ void pack_w_kernel(const GcParams p, const float* __restrict__ w, const float* scale,
                               long long sm, long long sc, long long sr, long long ss) {
@@ -881,7 +890,7 @@ __global__ void pack_w_kernel(const GcParams p, const float* __restrict__ w, con
         float v = 0.f;
         if (m < p.K && c < p.C) {
             const int r = p.tap_r[ph.tap0 + t], s = p.tap_s[ph.tap0 + t];
-            v = w[m * sm + c * sc + r * sr + s * ss] * sc_;
+            v = w[gc_weight_index(p, m, c, r, s, sm, sc, sr, ss)] * sc_;
         }
         DT<T>::st(dst + i, v);
     }
@@ -1019,7 +1028,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
             float v = 0.f;
             if (m < p.K && c < p.C) {
                 const int r = p.tap_r[ph.tap0 + t], s2 = p.tap_s[ph.tap0 + t];
-                v = J.w[m * J.sm + c * J.sc + r * J.sr + s2 * J.ss] * sc_;
+                v = J.w[gc_weight_index(p, m, c, r, s2, J.sm, J.sc, J.sr, J.ss)] * sc_;
             }
             DT<T>::st(dst + i, v);
         }
@@ -2119,11 +2128,11 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         const bool contiguous = (sr == p.tap_sw && ss == 1 && RS > 0);
         job.sm = sm; job.sc = sc; job.sr = sr; job.ss = ss; job.RS = RS; job.MB = 1; job.dtype = DT<T>::code;
         job.wp_bytes = (long long)wp_bytes;
-        if (contiguous && sc == RS && !env_int("HIFIC_OLD_PACK", 0)) {
+        if (contiguous && sc == RS && !p.csplit && !p.msplit && !env_int("HIFIC_OLD_PACK", 0)) {
             int MB = 40960 / (64 * RS * 4); if (MB > 16) MB = 16; if (MB < 1) MB = 1;
             job.mode = 0; job.MB = MB; job.gx = p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0); job.gy = cdiv(p.Kpad, MB);
             job.lds_bytes = (int)((size_t)64 * ((MB * RS) | 1) * sizeof(float));
-        } else if (contiguous && sm == RS && !env_int("HIFIC_OLD_PACK", 0)) {
+        } else if (contiguous && sm == RS && !p.csplit && !p.msplit && !env_int("HIFIC_OLD_PACK", 0)) {
             int MB = env_int("HIFIC_PACK_MB", 144) / RS; if (MB > 32) MB = 32; if (MB < 1) MB = 1;
             job.mode = 1; job.MB = MB; job.gx = p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0); job.gy = cdiv(p.Kpad, MB);
             job.lds_bytes = (int)((size_t)64 * ((MB * RS) | 1) * sizeof(float));
@@ -2237,13 +2246,192 @@ static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, lon
     if constexpr (std::is_same<T, float>::value) {
         return launch_gconv_tb<float, 16>(p, w, w_scale, sm, sc, sr, ss, ws, st);
     } else {
-        if (p.C <= 16) return launch_gconv_tb<bf16_t, 16>(p, w, w_scale, sm, sc, sr, ss, ws, st);
+        if (p.C <= 16 || (p.csplit && p.C <= 32)) return launch_gconv_tb<bf16_t, 16>(p, w, w_scale, sm, sc, sr, ss, ws, st);
         return launch_gconv_tb<bf16_t, 64>(p, w, w_scale, sm, sc, sr, ss, ws, st);
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Few input channels with many taps (the 7x7 convs on 3-channel tensors): an implicit GEMM spends one MFMA K-slice
+// (16 deep) per TAP on 3 useful channels.  The horizontal taps are folded into VIRTUAL CHANNELS instead:
+//   X'[n][c*nd + j][iy][v] = in[n][c][iy][v + dx_j]     (horizontal pad rule applied here; bf16)
+// and the conv runs over X' with one tap per kernel ROW (dy_i, dx = 0): 7 taps x 21 channels instead of 49 taps x 3.
+// The expansion costs one pass (44 MB written for a 16 x 3 x 256 x 256 input).
+// ---------------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ void vchan_expand_kernel(const TI* __restrict__ in, bf16_t* __restrict__ X, unsigned N, int C, int IH, int IW,
+                                    int OW, int nd, int dx0, int dxs /* dx_j = dx0 + j*dxs */, int bmode) {
+    const unsigned total = N * (unsigned)(C * nd * IH * OW);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int v = (int)(idx % (unsigned)OW);
+        unsigned t = idx / (unsigned)OW;
+        const int iy = (int)(t % (unsigned)IH); t /= (unsigned)IH;
+        const int j = (int)(t % (unsigned)nd); t /= (unsigned)nd;
+        const int c = (int)(t % (unsigned)C);
+        const unsigned n = t / (unsigned)C;
+        int ix = v + dx0 + j * dxs;
+        if (bmode == PAD_REFLECT) ix = reflect_idx(ix, IW);
+        const bool ok = (unsigned)ix < (unsigned)IW;
+        const float val = DT<TI>::ld(in + ((size_t)(n * C + c) * IH + iy) * IW + (ok ? ix : 0));
+        X[idx] = f2bf(ok ? val : 0.f);
+    }
+}
+
+static int launch_gconv_t_bf16(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
+                               long long sr, long long ss, WsAlloc& ws, hipStream_t st);
+
+// returns HIFIC_ERR_UNSUPPORTED when the layer does not qualify (caller continues with the plain plan)
+static int launch_gconv_fewc(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
+                             long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+    const GcPhase& ph = p.ph[0];
+    if (p.C > 4 || p.nphase != 1 || p.ist != 1 || ph.ntaps < 25 || p.csplit || p.msplit || env_int("HIFIC_NO_FEWC", 0))
+        return HIFIC_ERR_UNSUPPORTED;
+    // the taps must form a full (dy_i) x (dx_j) grid with equally spaced dx
+    int dys[16], dxv[16], rs_[16], ss_[16], ny = 0, nx = 0;
+    for (int t = 0; t < ph.ntaps; ++t) {
+        const int dy = p.tap_dy[t], dx = p.tap_dx[t];
+        int i = 0; while (i < ny && dys[i] != dy) ++i;
+        if (i == ny) { if (ny == 16) return HIFIC_ERR_UNSUPPORTED; dys[ny] = dy; rs_[ny] = p.tap_r[t]; ++ny; }
+        int j = 0; while (j < nx && dxv[j] != dx) ++j;
+        if (j == nx) { if (nx == 16) return HIFIC_ERR_UNSUPPORTED; dxv[nx] = dx; ss_[nx] = p.tap_s[t]; ++nx; }
+    }
+    if (ny * nx != ph.ntaps || p.C * nx > 32 || nx < 2) return HIFIC_ERR_UNSUPPORTED;
+    // every (dy_i, dx_j) present with consistent (r, s)
+    for (int t = 0; t < ph.ntaps; ++t) {
+        int i = 0; while (dys[i] != p.tap_dy[t]) ++i;
+        int j = 0; while (dxv[j] != p.tap_dx[t]) ++j;
+        if (p.tap_r[t] != rs_[i] || p.tap_s[t] != ss_[j]) return HIFIC_ERR_UNSUPPORTED;
+    }
+    // sort dx ascending (with their kernel columns) and require a constant step
+    for (int a = 0; a < nx; ++a) for (int b = a + 1; b < nx; ++b)
+        if (dxv[b] < dxv[a]) { int t1 = dxv[a]; dxv[a] = dxv[b]; dxv[b] = t1; t1 = ss_[a]; ss_[a] = ss_[b]; ss_[b] = t1; }
+    const int step = dxv[1] - dxv[0];
+    for (int j = 2; j < nx; ++j) if (dxv[j] - dxv[j - 1] != step) return HIFIC_ERR_UNSUPPORTED;
+    const int OWv = ph.OWt;                                  // width of the (u, v) output domain
+    const size_t xe = (size_t)p.N * p.C * nx * p.IH * OWv;
+    const size_t mark = ws.off;
+    bf16_t* X = (bf16_t*)ws.take(xe * sizeof(bf16_t));
+    if (!X) { ws.off = mark; return HIFIC_ERR_UNSUPPORTED; }
+    if (xe >= ((size_t)1 << 31)) { ws.off = mark; return HIFIC_ERR_UNSUPPORTED; }
+    if (!ws.plan_out) {
+        int gx = (int)((xe + 255) / 256); if (gx > 32768) gx = 32768;
+        if (p.in_f32) hipLaunchKernelGGL(vchan_expand_kernel<float>, dim3(gx), dim3(256), 0, st, (const float*)p.in, X, (unsigned)p.N,
+                                         p.C, p.IH, p.IW, OWv, nx, dxv[0], step, p.bmode);
+        else hipLaunchKernelGGL(vchan_expand_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, (const bf16_t*)p.in, X, (unsigned)p.N,
+                                p.C, p.IH, p.IW, OWv, nx, dxv[0], step, p.bmode);
+    }
+    GcParams q = p;
+    q.in = X; q.in_f32 = 0; q.C = p.C * nx; q.IW = OWv; q.csplit = nx;
+    for (int j = 0; j < nx; ++j) q.vcol_s[j] = (short)ss_[j];
+    int nt = 0;
+    for (int i = 0; i < ny; ++i) { q.tap_dy[nt] = (short)dys[i]; q.tap_dx[nt] = 0; q.tap_r[nt] = (short)rs_[i]; q.tap_s[nt] = 0; ++nt; }
+    GcPhase& qh = q.ph[0];
+    qh.ntaps = nt; qh.tap0 = 0;
+    {   // spans of the new tap set (finish_phase semantics)
+        int dymin = dys[0], dymax = dys[0];
+        for (int i = 1; i < ny; ++i) { if (dys[i] < dymin) dymin = dys[i]; if (dys[i] > dymax) dymax = dys[i]; }
+        qh.dy_min = dymin; qh.dx_min = 0; qh.PH = dymax - dymin + 1; qh.PW = 1;
+    }
+    const int rc = launch_gconv_t_bf16(q, w, w_scale, sm, sc, sr, ss, ws, st);
+    if (rc == HIFIC_ERR_UNSUPPORTED) ws.off = mark;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Few OUTPUT channels with many taps (the 60->3 7x7 output conv): 3 of the 32 MFMA rows carry work.  The horizontal taps
+// become VIRTUAL OUTPUT ROWS: P[n][k*nd + j][u][v'] = sum_{c, i} w[k,c,r_i,s_j] in[c][u + dy_i][v' + dx_0]  (7 taps, 21
+// rows, on a domain nd-1 columns wider), then out[n][k][u][v] = act(bias[k] + sum_j P[n][k*nd + j][u][v + j]).
+// ---------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void vrow_shift_add_kernel(const float* __restrict__ P, const float* __restrict__ bias, TO* __restrict__ out,
+                                      unsigned N, int K, int OH, int OW, int nd, int act) {
+    const int PW = OW + nd - 1;
+    const unsigned total = N * (unsigned)(K * OH * OW);
+    const float slope = act == ACT_RELU ? 0.f : (act == ACT_LEAKY ? 0.2f : 1.f);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int v = (int)(idx % (unsigned)OW);
+        unsigned t = idx / (unsigned)OW;
+        const int u = (int)(t % (unsigned)OH); t /= (unsigned)OH;
+        const int k = (int)(t % (unsigned)K);
+        const unsigned n = t / (unsigned)K;
+        const float* src = P + (((size_t)n * K + k) * nd * OH + u) * PW + v;
+        float vals[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vals[j] = src[j < nd ? (size_t)j * OH * PW + j : 0];
+        float s = bias ? bias[k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += j < nd ? vals[j] : 0.f;
+        s = s > 0.f ? s : s * slope;
+        DT<TO>::st(out + idx, s);
+    }
+}
+
+static int launch_gconv_fewk(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
+                             long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+    const GcPhase& ph = p.ph[0];
+    if (p.K > 4 || p.C < 16 || p.nphase != 1 || p.ist != 1 || p.ost != 1 || ph.ntaps < 25 || p.csplit || p.msplit ||
+        p.fold_h || p.resid || ph.ooy || ph.oox || ph.OHt != p.OHf || ph.OWt != p.OWf || env_int("HIFIC_NO_FEWK", 0))
+        return HIFIC_ERR_UNSUPPORTED;
+    int dys[16], dxv[16], rs_[16], ss_[16], ny = 0, nx = 0;
+    for (int t = 0; t < ph.ntaps; ++t) {
+        const int dy = p.tap_dy[t], dx = p.tap_dx[t];
+        int i = 0; while (i < ny && dys[i] != dy) ++i;
+        if (i == ny) { if (ny == 16) return HIFIC_ERR_UNSUPPORTED; dys[ny] = dy; rs_[ny] = p.tap_r[t]; ++ny; }
+        int j = 0; while (j < nx && dxv[j] != dx) ++j;
+        if (j == nx) { if (nx == 16) return HIFIC_ERR_UNSUPPORTED; dxv[nx] = dx; ss_[nx] = p.tap_s[t]; ++nx; }
+    }
+    if (ny * nx != ph.ntaps || p.K * nx > 32 || nx < 2) return HIFIC_ERR_UNSUPPORTED;
+    for (int t = 0; t < ph.ntaps; ++t) {
+        int i = 0; while (dys[i] != p.tap_dy[t]) ++i;
+        int j = 0; while (dxv[j] != p.tap_dx[t]) ++j;
+        if (p.tap_r[t] != rs_[i] || p.tap_s[t] != ss_[j]) return HIFIC_ERR_UNSUPPORTED;
+    }
+    for (int a = 0; a < nx; ++a) for (int b = a + 1; b < nx; ++b)
+        if (dxv[b] < dxv[a]) { int t1 = dxv[a]; dxv[a] = dxv[b]; dxv[b] = t1; t1 = ss_[a]; ss_[a] = ss_[b]; ss_[b] = t1; }
+    for (int j = 1; j < nx; ++j) if (dxv[j] - dxv[j - 1] != 1) return HIFIC_ERR_UNSUPPORTED;
+    const int PWd = p.OWf + nx - 1;
+    const size_t pe = (size_t)p.N * p.K * nx * p.OHf * PWd;
+    const size_t mark = ws.off;
+    float* P = (float*)ws.take(pe * sizeof(float));
+    if (!P || pe >= ((size_t)1 << 31)) { ws.off = mark; return HIFIC_ERR_UNSUPPORTED; }
+    GcParams q = p;
+    q.K = p.K * nx; q.msplit = nx; q.out = P; q.out_f32 = 1; q.bias = nullptr; q.act = ACT_NONE;
+    q.OWf = PWd;
+    for (int j = 0; j < nx; ++j) q.vcol_s[j] = (short)ss_[j];
+    int nt = 0;
+    for (int i = 0; i < ny; ++i) { q.tap_dy[nt] = (short)dys[i]; q.tap_dx[nt] = (short)dxv[0]; q.tap_r[nt] = (short)rs_[i]; q.tap_s[nt] = 0; ++nt; }
+    GcPhase& qh = q.ph[0];
+    qh.ntaps = nt; qh.tap0 = 0; qh.OWt = PWd;
+    {
+        int dymin = dys[0], dymax = dys[0];
+        for (int i = 1; i < ny; ++i) { if (dys[i] < dymin) dymin = dys[i]; if (dys[i] > dymax) dymax = dys[i]; }
+        qh.dy_min = dymin; qh.dx_min = dxv[0]; qh.PH = dymax - dymin + 1; qh.PW = 1;
+    }
+    const int rc = launch_gconv_t_bf16(q, w, w_scale, sm, sc, sr, ss, ws, st);
+    if (rc != HIFIC_OK) { if (rc == HIFIC_ERR_UNSUPPORTED) ws.off = mark; return rc; }
+    if (ws.plan_out) return rc;
+    const size_t total = (size_t)p.N * p.K * p.OHf * p.OWf;
+    int gx = (int)((total + 255) / 256); if (gx > 32768) gx = 32768;
+    if (p.out_f32) hipLaunchKernelGGL(vrow_shift_add_kernel<float>, dim3(gx), dim3(256), 0, st, P, p.bias, (float*)p.out, (unsigned)p.N,
+                                      p.K, p.OHf, p.OWf, nx, p.act);
+    else hipLaunchKernelGGL(vrow_shift_add_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, P, p.bias, (bf16_t*)p.out, (unsigned)p.N,
+                            p.K, p.OHf, p.OWf, nx, p.act);
+    return hific_launch_status();
+}
+
+static int launch_gconv_t_bf16(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
+                               long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+    return launch_gconv_t<bf16_t>(p, w, w_scale, sm, sc, sr, ss, ws, st);
+}
+
 static int launch_gconv(GcParams& p, int dtype, const float* w, const float* w_scale, long long sm, long long sc,
                         long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+    if (dtype == HIFIC_BF16) {
+        int rc = launch_gconv_fewc(p, w, w_scale, sm, sc, sr, ss, ws, st);
+        if (rc != HIFIC_ERR_UNSUPPORTED) return rc;
+        rc = launch_gconv_fewk(p, w, w_scale, sm, sc, sr, ss, ws, st);
+        if (rc != HIFIC_ERR_UNSUPPORTED) return rc;
+    }
     if (dtype == HIFIC_F32) { p.in_f32 = 1; p.out_f32 = 1; return launch_gconv_t<float>(p, w, w_scale, sm, sc, sr, ss, ws, st); }
     if (dtype == HIFIC_BF16) return launch_gconv_t<bf16_t>(p, w, w_scale, sm, sc, sr, ss, ws, st);
     return HIFIC_ERR_ARG;
