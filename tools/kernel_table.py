@@ -1,0 +1,58 @@
+"""Per-kernel table for profiles/: time from a rocprofv3 kernel trace, HBM traffic and MFMA-busy from separate --pmc
+passes of the same command.
+usage: kernel_table.py <trace.db> <fetch.db> <write.db> <mfma.db> <steps> > table.md
+
+  HBM GB/s   = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / avg duration      (KB counters; FETCH_SIZE counts 64 B per
+               128-B request of a wide stream on gfx950, MI355X_MICROARCH.md "HBM": doubled)
+  MFMA busy  = SQ_VALU_MFMA_BUSY_CYCLES / (avg duration x 2.4 GHz x 1024 SIMDs)   (the counter adds 32 cycles per
+               v_mfma_f32_32x32x16_bf16 on the issuing SIMD: 100 % = every SIMD issuing MFMAs back to back = 2.5 PF dense)
+Counter passes serialise kernels; durations come from the un-instrumented trace only.
+"""
+import sqlite3
+import sys
+
+
+def trace(db):
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    return {n: (c, s / 1e3, a / 1e3) for n, c, s, a in cur.execute(
+        f"select {name}, count(*), sum(end-start), avg(end-start) from kernels group by {name}")}
+
+
+def counters(db, names):
+    cur = sqlite3.connect(db).cursor()
+    out = {}
+    for k, c, n, v in cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                  "group by kernel_name, counter_name"):
+        if c in names:
+            out.setdefault(k, {})[c] = v
+    return out
+
+
+def main():
+    tr = trace(sys.argv[1])
+    f = counters(sys.argv[2], ("FETCH_SIZE",))
+    w = counters(sys.argv[3], ("WRITE_SIZE",))
+    m = counters(sys.argv[4], ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"))
+    steps = float(sys.argv[5])
+    total = sum(v[1] for v in tr.values())
+    print("| kernel | launches/step | avg us | ms/step | % of step | HBM MB/launch (2xFETCH+WRITE) | HBM GB/s | MFMA busy % |")
+    print("|---|---|---|---|---|---|---|---|")
+    for n, (c, tot_us, avg_us) in sorted(tr.items(), key=lambda kv: -kv[1][1]):
+        if tot_us / total < 0.002:
+            continue
+        fs, wsz = f.get(n, {}).get("FETCH_SIZE"), w.get(n, {}).get("WRITE_SIZE")
+        mb = (2 * fs + wsz) * 1024 / 1e6 if fs is not None and wsz is not None else None
+        gbps = mb * 1e6 / (avg_us * 1e-6) / 1e9 if mb is not None and avg_us > 0 else None
+        busy = m.get(n, {}).get("SQ_VALU_MFMA_BUSY_CYCLES")
+        pct = 100.0 * busy / (avg_us * 1e-6 * 2.4e9 * 1024) if busy is not None and avg_us > 0 else None
+        short = n if len(n) < 84 else n[:81] + "..."
+        print(f"| `{short}` | {c / steps:.1f} | {avg_us:.1f} | {tot_us / steps / 1e3:.3f} | {100 * tot_us / total:.1f} | "
+              f"{'-' if mb is None else f'{mb:.1f}'} | {'-' if gbps is None else f'{gbps:.0f}'} | "
+              f"{'-' if pct is None else f'{pct:.1f}'} |")
+    print(f"\nkernel time per step: {total / steps / 1e3:.3f} ms over {steps:.0f} steps")
+
+
+if __name__ == "__main__":
+    main()
