@@ -43,6 +43,7 @@ struct GcParams {
     int csplit, msplit;
     short vcol_s[16];
     int epi_wide;        // wide-store epilogue through LDS (gc_epilogue_wide): legality checked by the plan
+    int wstage;          // wide-load staging (stage_W): bf16 NCHW input, IW % 8 == 0, 16-byte aligned (set by the plan)
     int rfx;             // gather-form reflect data gradient (gconv_sp9_kernel RFX): `in` is the extended gradient
     // reflect-padded data gradient: `out` is the f32 padded plane buffer (only its rim is written); pixels inside
     // [fold_pt, fold_pt+fold_h) x [fold_pl, fold_pl+fold_w) go straight to out2 = dx[N,K,fold_h,fold_w]
@@ -65,6 +66,7 @@ struct WgParams {
     int TH, TW, NI, tiles_y, tiles_x, tiles_n, ntiles, tiles_per_split, nsplit;
     int ntaps, ngroups;
     int dbg;
+    int wstage_a, wstage_b;   // wide-load staging (stage_W) of the a / b operand: legality checked by the plan
     // small-channel (im2col) mode: virtual columns j = tap*4 + c; see wgrad_im2col_kernel
     int im2col, creal, ntaps_real, tsign, swap_out, a_bmode, a_y0, a_x0, a_h, a_w, b_y0, b_x0;
     GcPhase grp[GC_MAXPH];

@@ -143,6 +143,114 @@ __device__ __forceinline__ void stage_T(unsigned char* lds, const void* src, int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Wide-load transposing stage (bf16 source, 64-channel chunk, W % 8 == 0, 16-byte aligned tensor): same LDS image
+// as stage_T, but every global load is 16 bytes = 8 consecutive pixels of ONE channel (an aligned group of the source
+// row), so a 645-pixel x 64-channel stride-2 halo patch is 21 loads per thread instead of 161 two-byte loads and all
+// of a chunk's data is in flight in 2-3 batches (stage_T: one memory round trip per 64 patch pixels = 11 serialised
+// round trips per chunk, which is what the strided / transposed layers spent their time on).
+//   * a wave item = (patch row, pair of aligned 8-pixel groups); lane = (channel pair cp = lane & 31, group lane >> 5):
+//     two loads per lane (channels c0+2cp, c0+2cp+1), eight v_perm to interleave them, eight ds_write_b32 to rows
+//     px .. px+7, dword column cp: 32 consecutive dwords per half wave and the two halves 8 rows = 288 dwords apart
+//     -> all 64 banks, conflict-free.
+//   * group elements outside the patch columns, and whole items past the end, are redirected to a dump row (qdump).
+//   * zero padding: out-of-image rows / groups store zeros.  Reflect padding: rows are mirrored; the <= pad columns per
+//     side that lie outside the image (only on border tiles) are filled by a second, two-byte pass.
+// ---------------------------------------------------------------------------------------------------
+#ifndef GC_WSTAGE_WB
+#define GC_WSTAGE_WB 6
+#endif
+#ifndef GC_WSTAGE_WB_WG
+#define GC_WSTAGE_WB_WG 3
+#endif
+// NCP = channel pairs per chunk (32: 64-channel chunks; 16: 32-channel chunks, four groups per wave item, whose ds_writes
+// are 2-way bank conflicted at the 80-byte pitch).
+template <int PITCH, int WB, int NCP = 32>
+__device__ __forceinline__ void stage_W(unsigned char* lds, const bf16_t* __restrict__ src, int N, int C, int H, int W,
+                                        int bmode, int n0, int NI, int y0, int x0, int PH, int PW, int PWs, int c0,
+                                        int tid, int qdump) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int GPI = 64 / NCP;                              // groups per wave item
+    const int lane = tid & 63, wv = tid >> 6;
+    const int cp = lane % NCP, gg = lane / NCP;
+    const int g_lo = x0 >> 3;                                  // floor(x0 / 8), x0 may be negative
+    const int NG = ((x0 + PW - 1) >> 3) - g_lo + 1;            // aligned groups that intersect [x0, x0 + PW)
+    const int NG2 = (NG + GPI - 1) / GPI;
+    const int NR = NI * PH;
+    const int nitems = NR * NG2;
+    const unsigned plane = (unsigned)(H * W);
+    const int ca = c0 + 2 * cp;
+    const bool oka = ca < C, okb = ca + 1 < C;
+    const unsigned offa = (oka ? (unsigned)ca : 0u) * plane, offb = (okb ? (unsigned)(ca + 1) : 0u) * plane;
+    const unsigned cmask = (oka ? 0xffffu : 0u) | (okb ? 0xffff0000u : 0u);
+    const float inv_ng2 = 1.0f / (float)NG2, inv_ph = 1.0f / (float)PH;
+    const bool refl = bmode == PAD_REFLECT;
+    for (int it0 = wv; it0 < nitems; it0 += 4 * WB) {
+        u32x4_t va[WB], vb[WB];
+        int qrow[WB], px0[WB];
+        unsigned vm[WB];
+#pragma unroll
+        for (int b = 0; b < WB; ++b) {
+            const int it = it0 + 4 * b;
+            const int row = (int)(((float)it + 0.5f) * inv_ng2);
+            const int g = (it - row * NG2) * GPI + gg;
+            const int img = (int)(((float)row + 0.5f) * inv_ph);
+            const int py = row - img * PH;
+            int iy = y0 + py;
+            if (refl) iy = reflect_idx(iy, H);
+            const int n = n0 + img;
+            const int gx = (g_lo + g) * 8;
+            const bool in_patch = it < nitems && g < NG;
+            const bool col_in = gx >= 0 && gx + 8 <= W;
+            const bool ok = in_patch && n < N && (unsigned)iy < (unsigned)H && col_in;
+            const unsigned off = ok ? ((unsigned)n * (unsigned)C * plane + (unsigned)iy * (unsigned)W + (unsigned)gx) : 0u;
+            va[b] = *(const u32x4_t*)(src + off + offa);
+            vb[b] = *(const u32x4_t*)(src + off + offb);
+            // reflect mode leaves the out-of-image columns of valid images to the rim pass
+            const bool wr = in_patch && !(refl && !col_in && n < N);
+            qrow[b] = wr ? row * PWs : -0x40000000;
+            px0[b] = gx - x0;
+            vm[b] = ok ? cmask : 0u;
+        }
+#pragma unroll
+        for (int b = 0; b < WB; ++b) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned a_dw = va[b][e >> 1], b_dw = vb[b][e >> 1];
+                const unsigned v = __builtin_amdgcn_perm(b_dw, a_dw, (e & 1) ? 0x07060302u : 0x05040100u) & vm[b];
+                const int px = px0[b] + e;
+                const int q = ((unsigned)px < (unsigned)PW && qrow[b] >= 0) ? qrow[b] + px : qdump;
+                *(unsigned*)(lds + (size_t)q * PITCH + cp * 4) = v;
+            }
+        }
+    }
+    if (refl) {
+        const int nl = x0 < 0 ? (-x0 < PW ? -x0 : PW) : 0;
+        const int ovr = x0 + PW - W;
+        const int nr = ovr > 0 ? (ovr < PW ? ovr : PW) : 0;
+        const int nrim = nl + nr;
+        if (nrim > 0) {
+            const unsigned short* sp = (const unsigned short*)src;
+            const int cpr = tid % NCP, car = c0 + 2 * cpr;                 // this pass: thread = (channel pair, rim item)
+            const bool okar = car < C, okbr = car + 1 < C;
+            const unsigned offa_r = (okar ? (unsigned)car : 0u) * plane, offb_r = (okbr ? (unsigned)(car + 1) : 0u) * plane;
+            const unsigned cmask_r = (okar ? 0xffffu : 0u) | (okbr ? 0xffff0000u : 0u);
+            for (int rr = tid / NCP; rr < NR * nrim; rr += 256 / NCP) {
+                const int row = rr / nrim, rc = rr - row * nrim;
+                const int img = row / PH, py = row - img * PH;
+                const int px = rc < nl ? rc : PW - nr + (rc - nl);
+                const int iy = reflect_idx(y0 + py, H), ix = reflect_idx(x0 + px, W);
+                const int n = n0 + img;
+                const bool ok = n < N;
+                const unsigned off = ok ? ((unsigned)n * (unsigned)C * plane + (unsigned)iy * (unsigned)W + (unsigned)ix) : 0u;
+                const unsigned lo = sp[off + offa_r], hi = sp[off + offb_r];
+                const unsigned v = (lo | (hi << 16)) & (ok ? cmask_r : 0u);
+                *(unsigned*)(lds + (size_t)(row * PWs + px) * PITCH + cpr * 4) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Epilogue shared by the forward-type kernels: bias + residual + activation, NCHW store (32 consecutive pixels per
 // store instruction).  Everything that needs a LOAD is issued unconditionally up front: a load inside a (even
 // wave-uniform) branch makes hipcc wait `vmcnt(0)` right behind it, and the per-element `if (p.bias) v += p.bias[m]`
@@ -313,9 +421,15 @@ __device__ __forceinline__ void gc_epilogue_wide(const GcParams& p, const GcPhas
 // convs, 3-channel outputs) run 2-4 MFMAs per wave per tap: with one tap per step the kernel is bound by the barrier and
 // the weight-tile latency of 49-121 steps (measured 610 us for the 60->3 7x7 layer whose MFMA time is ~80 us).  TPS
 // weight tiles are fetched, stored and consumed per step instead.
-template <typename T, int BC, int WGM, int WGN, int WM, int WN, int QB, int TPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB > 1 ? 1 : 2, QB > 1 ? 1 : 8)))
+// QBW = patch pixels per lane per staging batch (stage_T QB); -1 = the wide-load staging variant (stage_W).  A separate
+// instantiation on purpose: with both loaders behind a runtime flag the 64-row kernel went from 3 to 2 waves per SIMD
+// (189 VGPRs) and every stride-1 layer on it lost 15-35 %.
+template <typename T, int BC, int WGM, int WGN, int WM, int WN, int QBW, int TPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QBW > 1 ? 1 : 2, QBW > 1 ? 1 : 8)))
 void gconv_kernel(const GcParams p) {
+    constexpr bool WIDE = QBW < 0;
+    constexpr int QB = QBW < 0 ? 1 : QBW;
+    static_assert(!WIDE || (std::is_same<T, bf16_t>::value && BC >= 32), "wide staging: bf16, 32/64-channel chunks");
     using Cfg = GcCfg<T>;
     constexpr int KS = Cfg::KS;
     constexpr int ROWB = BC * (int)sizeof(T);          // bytes of one LDS row (BC channels)
@@ -483,6 +597,10 @@ void gconv_kernel(const GcParams p) {
     do {                                                                                    \
         if (g == 0 && !((p.dbg & 1) && chunk > 0) && !(p.dbg & 64)) {                       \
             __syncthreads();                                                                \
+            if constexpr (WIDE)                                                             \
+                stage_W<PITCH, GC_WSTAGE_WB, BC / 2>(patch, (const bf16_t*)p.in, p.N, p.C, p.IH, p.IW, p.bmode, n0, p.NI, \
+                                                     iy0, ix0, PH, PW, PWs, chunk * BC, tid, p.NI * npps); \
+            else                                                                            \
             stage_T<T, DWR, PITCH, QB>(patch, p.in, p.in_f32, p.N, p.C, p.IH, p.IW, p.bmode, \
                                        n0, p.NI, iy0, ix0, PWs, PH, PW, chunk * BC, tid, 256);  \
         }                                                                                   \
@@ -1120,9 +1238,13 @@ template <typename T> struct WgCfg;
 template <> struct WgCfg<bf16_t> { static constexpr int DWR = 32, PITCH = 144, KS = 16; };
 template <> struct WgCfg<float>  { static constexpr int DWR = 64, PITCH = 260, KS = 2; };
 
-template <typename T, int QB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB > 1 ? 1 : 2, QB > 1 ? 1 : 8)))
+// QBW as in gconv_kernel: -1 = wide-load staging variant (operands with wstage_a / wstage_b set use stage_W)
+template <typename T, int QBW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QBW > 1 ? 1 : 2, QBW > 1 ? 1 : 8)))
 void wgrad_kernel(const WgParams p) {
+    constexpr bool WIDE = QBW < 0;
+    constexpr int QB = QBW < 0 ? 1 : QBW;
+    static_assert(!WIDE || std::is_same<T, bf16_t>::value, "wide staging: bf16");
     using Cfg = WgCfg<T>;
     constexpr int PITCH = Cfg::PITCH, KS = Cfg::KS, DWR = Cfg::DWR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1176,12 +1298,26 @@ void wgrad_kernel(const WgParams p) {
         const int tn = tile / (p.tiles_x * p.tiles_y);
         const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
         __syncthreads();
-        if (!(p.dbg & 1))
-        stage_T<T, DWR, PITCH, QB>(at, p.a, p.a_f32, p.N, p.M, p.AH, p.AW, PAD_ZERO,
-                                   n0, p.NI, u0, v0, 0, p.TH, p.TW, m0, tid, 256);
-        if (!(p.dbg & 2))
-        stage_T<T, DWR, PITCH, QB>(patch, p.b, p.b_f32, p.N, p.C, p.BH, p.BW, p.bmode,
-                                   n0, p.NI, u0 * p.ist + gp.dy_min, v0 * p.ist + gp.dx_min, 0, PH, PW, c0, tid, 256);
+        bool wide_a = false, wide_b = false;
+        if constexpr (WIDE) { wide_a = p.wstage_a != 0; wide_b = p.wstage_b != 0; }
+        if (!(p.dbg & 1)) {
+            if (wide_a) {
+                if constexpr (WIDE)
+                    stage_W<PITCH, GC_WSTAGE_WB_WG>(at, (const bf16_t*)p.a, p.N, p.M, p.AH, p.AW, PAD_ZERO, n0, p.NI, u0, v0,
+                                                 p.TH, p.TW, p.TW, m0, tid, GC_NPIX + npatch);
+            } else
+            stage_T<T, DWR, PITCH, QB>(at, p.a, p.a_f32, p.N, p.M, p.AH, p.AW, PAD_ZERO,
+                                       n0, p.NI, u0, v0, 0, p.TH, p.TW, m0, tid, 256);
+        }
+        if (!(p.dbg & 2)) {
+            if (wide_b) {
+                if constexpr (WIDE)
+                    stage_W<PITCH, GC_WSTAGE_WB_WG>(patch, (const bf16_t*)p.b, p.N, p.C, p.BH, p.BW, p.bmode, n0, p.NI,
+                                                 u0 * p.ist + gp.dy_min, v0 * p.ist + gp.dx_min, PH, PW, PW, c0, tid, npatch);
+            } else
+            stage_T<T, DWR, PITCH, QB>(patch, p.b, p.b_f32, p.N, p.C, p.BH, p.BW, p.bmode,
+                                       n0, p.NI, u0 * p.ist + gp.dy_min, v0 * p.ist + gp.dx_min, 0, PH, PW, c0, tid, 256);
+        }
         __syncthreads();
         for (int ks = 0; ks < ((p.dbg & 4) ? 0 : npix / KS); ++ks) {
             if constexpr (std::is_same<T, float>::value) {
@@ -1956,7 +2092,7 @@ static void finish_phase(GcPhase& ph, const GcParams& p) {
 
 template <typename T, int BC>
 static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
-                           long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+                           long long sr, long long ss, WsAlloc& ws, hipStream_t st, int tile_budget = kLdsBudget) {
     using Cfg = GcCfg<T>;
     constexpr int PITCH = BC * (int)sizeof(T) + Cfg::PAD;
     // Phase-merged software-pipelined kernel (gconv_sp9_kernel PHS) for the kernel-3 stride-2 transposed structure:
@@ -2034,9 +2170,31 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             for (int i = 0; i < p.nphase; ++i) { if (p.ph[i].PH > span_y) span_y = p.ph[i].PH; if (p.ph[i].PW > span_x) span_x = p.ph[i].PW; }
         }
     }
-    if (!phs && choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, kLdsBudget, p.TH, p.TW, p.NI, maxtaps)) {
+    if (!phs && choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, tile_budget, p.TH, p.TW, p.NI, maxtaps)) {
         const long long g = (long long)cdiv(OHt, p.TH) * cdiv(OWt, p.TW) * cdiv(p.N, p.NI) * (p.Kpad / bm) * p.nphase;
         tiled = g >= env_int("HIFIC_GC_BIGTILE_MIN_GRID", 256);
+    }
+    // Layers whose 64-channel halo patch only fits as a whole-LDS tile (stride-2 convs: four input pixels per output
+    // pixel) run ONE workgroup per CU, and its weight-load / staging / MFMA / bias / store-drain latencies are all
+    // exposed back to back (60->120 stride 2 @256x256: staging 40 + epilogue 42 + MFMA 33 + weights 19 + launch 43 us
+    // of 183).  32-channel chunks halve the patch and the weight ring, so two workgroups co-reside and overlap.
+    if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
+        // ... when the launch has at least two workgroups per CU to co-reside (a 256-workgroup launch only gets the
+        // doubled step count: 960<-480 @16x16 138 -> 191 us)
+        const long long g64 = (long long)cdiv(OHt, p.TH) * cdiv(OWt, p.TW) * cdiv(p.N, p.NI) * (p.Kpad / bm) * p.nphase;
+        if (tiled && !phs && g64 >= 512 && env_int("HIFIC_BC32", 1)) {
+            size_t need = 0;
+            for (int i = 0; i < p.nphase; ++i) {
+                const size_t b = (size_t)wbytes + (size_t)p.NI * ((p.TH - 1) * p.ist + p.ph[i].PH) * ((p.TW - 1) * p.ist + p.ph[i].PW) * PITCH;
+                if (b > need) need = b;
+            }
+            if (need > (size_t)80 * 1024) {
+                const GcParams saved = p;
+                const int rc32 = launch_gconv_tb<bf16_t, 32>(p, w, w_scale, sm, sc, sr, ss, ws, st, 72 * 1024);
+                if (rc32 != HIFIC_ERR_UNSUPPORTED) return rc32;
+                p = saved;                                 // no 72 KB tile at 32 channels either: whole-LDS tile it is
+            }
+        }
     }
     if (!tiled && !choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, 72 * 1024, p.TH, p.TW, p.NI, maxtaps))
         return HIFIC_ERR_UNSUPPORTED;
@@ -2076,6 +2234,19 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         if (nt > max_tiles) max_tiles = nt;
         size_t b = (size_t)wbytes + (size_t)p.NI * ph.PH * ph.PWs * PITCH;
         if (b > lds) lds = b;
+    }
+    // wide-load staging (stage_W): bf16 NCHW source whose rows are 16-byte aligned; + one dump row of LDS
+    p.wstage = 0;
+    if constexpr (std::is_same<T, bf16_t>::value && BC >= 32) {
+        // measured: pays on the stride-2 layers (halo patch = 4 input pixels per output pixel, 11 -> 2-3 round trips:
+        // 60->120 @256x256 222 -> 180 us); stride-1 patches are 2-3 round trips either way and the 36-pixel rows of the
+        // 60->3 virtual-row layer waste half of every aligned group (191 -> 221 us)
+        const int wst = env_int("HIFIC_WSTAGE", 1);
+        if (!p.in_f32 && p.IW % 8 == 0 && p.IW >= env_int("HIFIC_WSTAGE_MINW", 32) && ((size_t)p.in & 15) == 0 &&
+            lds + PITCH <= (size_t)kLdsBudget && tps == 1 && (wst == 2 || (wst == 1 && p.ist >= 2))) {
+            p.wstage = 1;
+            lds += PITCH;
+        }
     }
     if (lds > (size_t)kLdsBudget) return HIFIC_ERR_UNSUPPORTED;
     // wide-store epilogue (gc_epilogue_wide): one phase, output stride 1, bf16 output written straight to `out`, pieces of
@@ -2199,6 +2370,9 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     do {                                                                                                 \
         void (*kfn)(const GcParams) = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 1>;                       \
         if constexpr (kBigStage) { if (bigstage) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 12, 1>; }   \
+        if constexpr (std::is_same<T, bf16_t>::value && BC >= 32) {                                      \
+            if (p.wstage) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, -1, 1>;                            \
+        }                                                                                                \
         if constexpr (std::is_same<T, bf16_t>::value) {                                                  \
             constexpr int nwp_ = (WGM * WM * 32 * (BC * (int)sizeof(T) / 16) + 255) / 256;               \
             if constexpr (nwp_ * 4 <= 8) { if (tps == 4) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 4>; } \
@@ -2663,6 +2837,17 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
         size_t b = (size_t)fixed + (size_t)p.NI * gp.PH * gp.PW * Cfg::PITCH;
         if (b > lds) lds = b;
     }
+    // wide-load staging (stage_W) per operand: bf16 rows that are 16-byte aligned; + one shared dump row of LDS
+    p.wstage_a = p.wstage_b = 0;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        const int wst = env_int("HIFIC_WSTAGE", 1);
+        if ((wst == 2 || (wst == 1 && p.ist >= 2)) && lds + Cfg::PITCH <= (size_t)kLdsBudget) {
+            // stride-2 layers only, and not the narrowest planes (512<-256 @16x16: 191 -> 204 us)
+            p.wstage_a = !p.a_f32 && p.AW % 8 == 0 && p.AW >= env_int("HIFIC_WSTAGE_MINW", 32) && p.TW % 8 == 0 && ((size_t)p.a & 15) == 0;
+            p.wstage_b = !p.b_f32 && p.BW % 8 == 0 && p.BW >= 2 * env_int("HIFIC_WSTAGE_MINW", 32) && ((size_t)p.b & 15) == 0;
+            if (p.wstage_a || p.wstage_b) lds += Cfg::PITCH;
+        }
+    }
     if (lds > (size_t)kLdsBudget) return HIFIC_ERR_UNSUPPORTED;
     p.tiles_y = cdiv(p.AH, p.TH); p.tiles_x = cdiv(p.AW, p.TW); p.tiles_n = cdiv(p.N, p.NI);
     p.ntiles = p.tiles_n * p.tiles_y * p.tiles_x;
@@ -2712,7 +2897,10 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
     }
     if (!pipe) {
         void (*kfn)(const WgParams) = wgrad_kernel<T, 1>;
-        if constexpr (std::is_same<T, bf16_t>::value) { if (bigstage) kfn = wgrad_kernel<T, 12>; }
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            if (bigstage) kfn = wgrad_kernel<T, 12>;
+            else if (p.wstage_a || p.wstage_b) kfn = wgrad_kernel<T, -1>;
+        }
         if (lds > 48 * 1024)
             hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);

@@ -35,5 +35,11 @@ if which in ("fwd", "all"):
     run("fwd", lambda: lib.call("hific_conv2d_fwd", x.data_ptr(), w.data_ptr(), None, b.data_ptr(), None, y.data_ptr(), *geom, 0, 1, 0, ws.data_ptr(), ws.numel(), None, 0, 0, lib.stream()))
 if which in ("bwd", "all"):
     run("bwd_data", lambda: lib.call("hific_conv2d_bwd_data", gy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), *geom, 1, 0, ws.data_ptr(), ws.numel(), None, 0, 0, lib.stream()))
+if which == "convt":
+    # nn.ConvTranspose2d k3 s2 p1 op1 (generator up-sampling): x [N,C,H,H] -> y [N,K,2H,2H]
+    wt = (torch.randn(C, K, 3, 3, device=dev) * 0.01)
+    yt = torch.empty(N, K, 2 * H, 2 * H, device=dev, dtype=torch.bfloat16)
+    run("convt_fwd", lambda: lib.call("hific_conv_transpose2d_fwd", x.data_ptr(), wt.data_ptr(), b.data_ptr(), yt.data_ptr(),
+                                      N, C, H, H, K, 3, 3, 2, 1, 1, 0, 1, 0, ws.data_ptr(), ws.numel(), None, 0, 0, lib.stream()))
 if which in ("wgrad", "all"):
     run("bwd_weight", lambda: lib.call("hific_conv2d_bwd_weight", x.data_ptr(), gy.data_ptr(), dw.data_ptr(), *geom, 0, 1, 0, ws.data_ptr(), ws.numel(), lib.stream()))
