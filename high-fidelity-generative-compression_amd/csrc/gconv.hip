@@ -1397,8 +1397,23 @@ void wgrad_kernel(const WgParams p) {
 //   * both LDS images are double-buffered; the next tile's data is prefetched into registers while the current
 //     tile's 72 MFMAs per wave run (patch in two halves to keep the prefetch at 24+16 VGPRs); one barrier per tile
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
-    constexpr int PITCH = 144, NDW = 8, QI = 3, HALF = 4;
+// TS = 2: 8 waves; waves 4-7 mirror waves 0-3 on the same (m, c) tile and the same staged operands but own taps 5..8
+// (waves 0-3: taps 0..4).  80 instead of 144 accumulator registers per wave, so two waves fit per SIMD and hide each
+// other's LDS / barrier latency; no exchange at the end (different taps are different outputs); the staging work of a
+// tile is spread over 512 threads (half the prefetch registers per thread).  Needs a 9-tap group.
+// SH3 (3x3 window, taps ordered (dy, dx) with dx ascending): the B fragment of tap (dy, dx+1) is the fragment of tap
+// (dy, dx) shifted by one pixel along the reduction index, so the three fragments of a kernel row are built from 10
+// consecutive patch pixels (3 transpose reads + 4 v_alignbit) instead of 3 x 2 transpose reads: 9 instead of 18 LDS
+// reads per 9 MFMAs (the kernel is LDS-read bound: 10 KB of fragment reads per wave per 16-deep slice).  With TS = 2
+// the waves split by kernel row (rows 0-1 | row 2) instead of 5 | 4 taps.
+template <int TS, bool SH3>
+__global__ __launch_bounds__(256 * TS) __attribute__((amdgpu_waves_per_eu(TS == 2 ? 2 : 1, TS == 2 ? 2 : 8)))
+void wgrad_pipe_kernel(const WgParams p) {
+    constexpr int PITCH = 144, NDW = 8 / TS, QI = 3, HALF = NDW / 2;
+    constexpr int NTH = 256 * TS;                                  // threads
+    constexpr int NAP = 4 / TS;                                    // 16-byte A pieces per thread per tile
+    constexpr int NACC = TS == 2 ? (SH3 ? 6 : 5) : GC_TG;          // accumulator sets per wave
+    constexpr int TSPLIT = SH3 ? 6 : 5;                            // first tap of the second wave set
     constexpr int APITCH = GC_NPIX * 2 + 16;                       // 272 B per m row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -1406,7 +1421,8 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wset = wave >> 2;                                    // tap set of this wave (TS == 2)
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int pwv = tid >> 6;
 
@@ -1417,7 +1433,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
     const int split = blockIdx.z;
     const int PH = gp.PH, PW = gp.PW, npp = PH * PW;
     const int npatch = p.NI * npp;
-    const size_t patch_bytes = ((size_t)(npatch + 1) * PITCH + 15) & ~(size_t)15;   // + dump row for lanes past the patch
+    const size_t patch_bytes = ((size_t)(npatch + 3) * PITCH + 15) & ~(size_t)15;   // + dump row for lanes past the patch, + 2 rows read (unused) by SH3
     constexpr int ABYTES = 64 * APITCH;
 
     int* qtab = (int*)smem;                                         // [128]
@@ -1441,12 +1457,12 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
 #pragma unroll
     for (int t = 0; t < GC_TG; ++t) toffb[t] = toffs[t] * PITCH;
     // A pieces of this thread: piece = tid + 256*i -> (row m, 8-pixel segment); tile-independent part of the address
-    int a_img[4], a_ty[4], a_tx[4], a_row[4], a_seg[4];
-    unsigned a_rel[4];
+    int a_img[NAP], a_ty[NAP], a_tx[NAP], a_row[NAP], a_seg[NAP];
+    unsigned a_rel[NAP];
     const unsigned aplane = (unsigned)(p.AH * p.AW);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = tid + 256 * i;
+    for (int i = 0; i < NAP; ++i) {
+        const int piece = tid + NTH * i;
         a_row[i] = piece >> 4; a_seg[i] = piece & 15;
         const int r0 = a_seg[i] * 8;
         a_img[i] = r0 / thw;
@@ -1459,9 +1475,9 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
     const unsigned bplane = (unsigned)(p.BH * p.BW);
     const bool cfull = c0 + 64 <= p.C;
 
-    f32x16_t acc[GC_TG];
+    f32x16_t acc[NACC];
 #pragma unroll
-    for (int t = 0; t < GC_TG; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -1469,7 +1485,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
     int tile_hi = tile_lo + p.tiles_per_split;
     if (tile_hi > p.ntiles) tile_hi = p.ntiles;
 
-    u32x4_t areg[4]; unsigned aokm = 0;
+    u32x4_t areg[NAP]; unsigned aokm = 0;
     unsigned short plo[QI][NDW], phi[QI][NDW];                      // raw 16-bit loads, untouched until the store
     unsigned qoff[QI]; unsigned qokm = 0;
 
@@ -1481,7 +1497,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
 #define WG_LOAD_A(n0_, u0_, v0_)                                                                            \
     do {                                                                                                    \
         const unsigned tbase = (unsigned)(n0_ * p.M) * aplane + (unsigned)(u0_ * p.AW + v0_);               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        _Pragma("unroll") for (int i = 0; i < NAP; ++i) {                                                   \
             const bool ok_ = (n0_ + a_img[i] < p.N) && (u0_ + a_ty[i] < p.AH) && (v0_ + a_tx[i] < p.AW) &&   \
                      (m0 + a_row[i] < p.M) && (a_img[i] < p.NI);                                            \
             aokm = (aokm & ~(1u << i)) | ((ok_ ? 1u : 0u) << i);                                            \
@@ -1490,7 +1506,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
     } while (0)
 #define WG_STORE_A(buf_)                                                                                    \
     do {                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        _Pragma("unroll") for (int i = 0; i < NAP; ++i) {                                                   \
             u32x4_t v = areg[i];                                                                            \
             if (!((aokm >> i) & 1u)) { v.x = 0; v.y = 0; v.z = 0; v.w = 0; }                                            \
             *(u32x4_t*)((buf_) + a_row[i] * APITCH + a_seg[i] * 16) = v;                                    \
@@ -1514,7 +1530,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
         _Pragma("unroll") for (int j = 0; j < QI; ++j) {                                                    \
             _Pragma("unroll") for (int ii = 0; ii < HALF; ++ii) {                                           \
                 const int i = (h) * HALF + ii;                                                              \
-                const int c = c0 + 2 * (pwv + 4 * i);                                                       \
+                const int c = c0 + 2 * (pwv + 4 * TS * i);                                                       \
                 const unsigned off = qoff[j] + (unsigned)c * bplane;                                        \
                 const bool k0 = cfull || c < p.C, k1 = cfull || c + 1 < p.C;                                \
                 plo[j][i] = sp[k0 ? off : 0u];                                                              \
@@ -1529,14 +1545,14 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
             unsigned char* row = (buf_) + (size_t)(q < npatch ? q : npatch) * PITCH + pwv * 4;              \
             _Pragma("unroll") for (int ii = 0; ii < HALF; ++ii) {                                           \
                 const int i = (h) * HALF + ii;                                                              \
-                const int c = c0 + 2 * (pwv + 4 * i);                                                       \
+                const int c = c0 + 2 * (pwv + 4 * TS * i);                                                       \
                 const unsigned l = (((qokm >> j) & 1u) && (cfull || c < p.C)) ? (unsigned)plo[j][i] : 0u;   \
                 const unsigned hh = (((qokm >> j) & 1u) && (cfull || c + 1 < p.C)) ? (unsigned)phi[j][i] : 0u; \
-                *(unsigned*)(row + i * 16) = l | (hh << 16);                                                \
+                *(unsigned*)(row + i * 16 * TS) = l | (hh << 16);                                                \
             }                                                                                               \
         }                                                                                                   \
     } while (0)
-#define WG_COMPUTE(ab_, pb_, ks_lo, ks_hi)                                                                  \
+#define WG_COMPUTE(ab_, pb_, ks_lo, ks_hi, T0, NT)                                                                  \
     do {                                                                                                    \
         const int g = lane >> 4, i16 = lane & 15;                                                           \
         const int colb = ((g & 1) * 16 + (i16 & 3) * 4) * 2;                                                \
@@ -1549,14 +1565,46 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
             const unsigned char* b1row = (pb_) + (size_t)qtab[rb + 4] * PITCH + wn * 64 + colb;             \
             /* all GC_TG taps unconditionally (taps beyond ntaps alias tap 0, their accumulators are dropped): */ \
             /* straight-line code lets the compiler issue the 18 LDS reads ahead of the 9 independent MFMAs */   \
-            short4_t b0[GC_TG], b1[GC_TG];                                                                  \
-            _Pragma("unroll") for (int t = 0; t < GC_TG; ++t) {                                             \
-                b0[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b0row + toffb[t]));                \
-                b1[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b1row + toffb[t]));                \
+            short4_t b0[NT], b1[NT];                                                                        \
+            _Pragma("unroll") for (int t = 0; t < (NT); ++t) {                                              \
+                b0[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b0row + toffb[(T0) + t]));         \
+                b1[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(b1row + toffb[(T0) + t]));         \
             }                                                                                               \
-            _Pragma("unroll") for (int t = 0; t < GC_TG; ++t) {                                             \
+            _Pragma("unroll") for (int t = 0; t < (NT); ++t) {                                              \
                 short8_t bv = {b0[t][0], b0[t][1], b0[t][2], b0[t][3], b1[t][0], b1[t][1], b1[t][2], b1[t][3]}; \
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, bv), acc[t], 0, 0, 0); \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+
+    // SH3 form: kernel rows [D0, D0+ND) of the 3x3 window; accumulator of tap (d, j) = acc[(d - D0) * 3 + j]
+#define WG_COMPUTE_SH3(ab_, pb_, ks_lo, ks_hi, D0, ND)                                                      \
+    do {                                                                                                    \
+        const int g = lane >> 4, i16 = lane & 15;                                                           \
+        const int colb = ((g & 1) * 16 + (i16 & 3) * 4) * 2;                                                \
+        typedef __attribute__((address_space(3))) short4_t* lds_s4;                                         \
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));                                   \
+        typedef unsigned int u32x4b_t __attribute__((ext_vector_type(4)));                                  \
+        _Pragma("unroll") for (int ks = (ks_lo); ks < (ks_hi); ++ks) {                                       \
+            const bf16x8_t a = *(const bf16x8_t*)((ab_) + (wm * 32 + l31) * APITCH + (ks * 16 + lhi * 8) * 2); \
+            const int rb = ks * 16 + (g >> 1) * 8 + (i16 >> 2);                                             \
+            const unsigned char* brow = (pb_) + (size_t)qtab[rb] * PITCH + wn * 64 + colb;                  \
+            u32x2_t P[ND][3];                                                                               \
+            _Pragma("unroll") for (int d = 0; d < (ND); ++d) {                                              \
+                const unsigned char* r0 = brow + toffb[((D0) + d) * 3];                                     \
+                P[d][0] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(r0)));             \
+                P[d][1] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(r0 + 4 * PITCH))); \
+                P[d][2] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(r0 + 8 * PITCH))); \
+            }                                                                                               \
+            _Pragma("unroll") for (int d = 0; d < (ND); ++d) {                                              \
+                const unsigned R0 = P[d][0].x, R1 = P[d][0].y, R2 = P[d][1].x, R3 = P[d][1].y, R4 = P[d][2].x; \
+                const u32x4b_t f0 = {R0, R1, R2, R3};                                                       \
+                const u32x4b_t f1 = {__builtin_amdgcn_alignbit(R1, R0, 16), __builtin_amdgcn_alignbit(R2, R1, 16), \
+                                     __builtin_amdgcn_alignbit(R3, R2, 16), __builtin_amdgcn_alignbit(R4, R3, 16)}; \
+                const u32x4b_t f2 = {R1, R2, R3, R4};                                                       \
+                acc[d * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, f0), acc[d * 3 + 0], 0, 0, 0); \
+                acc[d * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, f1), acc[d * 3 + 1], 0, 0, 0); \
+                acc[d * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, f2), acc[d * 3 + 2], 0, 0, 0); \
             }                                                                                               \
         }                                                                                                   \
     } while (0)
@@ -1598,9 +1646,22 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
                 WG_DECODE_P(n0, u0, v0);
                 WG_LOAD_P(0); WG_LOAD_P(1);
             }
-            WG_COMPUTE(ab, pb, 0, GC_NPIX / 16);
+            if constexpr (SH3) {
+                if constexpr (TS == 2) {
+                    if (wset == 0) WG_COMPUTE_SH3(ab, pb, 0, GC_NPIX / 16, 0, 2);
+                    else WG_COMPUTE_SH3(ab, pb, 0, GC_NPIX / 16, 2, 1);
+                } else {
+                    WG_COMPUTE_SH3(ab, pb, 0, GC_NPIX / 16, 0, 3);
+                }
+            } else if constexpr (TS == 2) {
+                if (wset == 0) WG_COMPUTE(ab, pb, 0, GC_NPIX / 16, 0, 5);
+                else WG_COMPUTE(ab, pb, 0, GC_NPIX / 16, 5, 4);
+            } else {
+                WG_COMPUTE(ab, pb, 0, GC_NPIX / 16, 0, GC_TG);
+            }
         }
     }
+#undef WG_COMPUTE_SH3
 #undef WG_COMPUTE
 #undef WG_STORE_P
 #undef WG_LOAD_P
@@ -1614,22 +1675,24 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
     // gradient), so the tile is transposed through LDS and each m row leaves as one contiguous run of 64c x 9 taps.
     if (p.direct && p.ngroups == 1 && p.sc == gp.ntaps && p.ss == 1 && gp.ntaps == GC_TG) {
         constexpr int RP = 32 * GC_TG + 1;                      // floats per staged row (odd: conflict-free)
-        float* stg = (float*)smem + (size_t)wave * 16 * RP;     // per-wave region: 16 rows
+        float* stg = (float*)smem + (size_t)(wave & 3) * 16 * RP;   // region of the (wm, wn) quadrant: 16 rows
+        const int tbase = (TS == 2 && wset == 1) ? TSPLIT : 0;  // first tap of this wave's accumulators
         __syncthreads();                                        // all waves done with the operand buffers
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int t = 0; t < GC_TG; ++t)
+            for (int t = 0; t < NACC; ++t)
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) {
                     const int r = h * 8 + rr;
                     const int rowl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi;      // 0..15 within the half
-                    stg[rowl * RP + l31 * GC_TG + t] = acc[t][r];
+                    if (tbase + t < GC_TG) stg[rowl * RP + l31 * GC_TG + tbase + t] = acc[t][r];
                 }
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes landed (wave-private region)
-            for (int rowl = 0; rowl < 16; ++rowl) {
+            if constexpr (TS == 2) __syncthreads();   // the quadrant's two waves filled disjoint taps of the region
+            else __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes landed (wave-private region)
+            for (int rowl = (TS == 2 ? wset * 8 : 0); rowl < (TS == 2 ? wset * 8 + 8 : 16); ++rowl) {
                 const int m = m0 + wm * 32 + h * 16 + rowl;
-                if (m >= p.M) break;
+                if (m >= p.M) break;                                   // (no barrier inside this loop)
                 float* drow = p.dw + (long long)m * p.sm + (long long)(c0 + wn * 32) * p.sc;
                 int nvalid = (p.C - (c0 + wn * 32)) * GC_TG; if (nvalid > 32 * GC_TG) nvalid = 32 * GC_TG;
                 for (int j = lane; j < nvalid; j += 64) {
@@ -1637,12 +1700,15 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
                     if (p.accumulate) drow[j] += v; else drow[j] = v;
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if constexpr (TS == 2) __syncthreads();
+            else __builtin_amdgcn_s_waitcnt(0xc07f);
         }
         return;
     }
+    const int tb2 = (TS == 2 && wset == 1) ? TSPLIT : 0;
 #pragma unroll
-    for (int t = 0; t < GC_TG; ++t) {
+    for (int ta = 0; ta < NACC; ++ta) {
+        const int t = tb2 + ta;
         if (t < gp.ntaps) {
             const int tg = gp.tap0 + t;
             const long long toff_w = p.direct ? (long long)p.tap_r[tg] * p.sr + (long long)p.tap_s[tg] * p.ss : 0;
@@ -1653,10 +1719,10 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgParams p) {
                 if (p.direct) {
                     if (m < p.M && c < p.C) {
                         float* d = p.dw + m * p.sm + c * p.sc + toff_w;
-                        if (p.accumulate) *d += acc[t][r]; else *d = acc[t][r];
+                        if (p.accumulate) *d += acc[ta][r]; else *d = acc[ta][r];
                     }
                 } else {
-                    p.ws[(((size_t)split * p.Mpad + m) * p.ntaps + tg) * p.Cpad + c] = acc[t][r];
+                    p.ws[(((size_t)split * p.Mpad + m) * p.ntaps + tg) * p.Cpad + c] = acc[ta][r];
                 }
             }
         }
@@ -2877,7 +2943,7 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
             int np_ = p.NI * p.grp[gi].PH * p.grp[gi].PW;
             if (np_ > npatch_max) npatch_max = np_;
         }
-        const size_t lds_pipe = 512 + 2 * (size_t)64 * (GC_NPIX * 2 + 16) + 2 * (((size_t)(npatch_max + 1) * 144 + 15) & ~(size_t)15);
+        const size_t lds_pipe = 512 + 2 * (size_t)64 * (GC_NPIX * 2 + 16) + 2 * (((size_t)(npatch_max + 3) * 144 + 15) & ~(size_t)15);
         pipe = !p.a_f32 && !p.b_f32 && p.NI * p.TH * p.TW == GC_NPIX && p.TW % 8 == 0 && p.AW % 8 == 0 &&
                npatch_max <= 192 && lds_pipe <= (size_t)kLdsBudget && !env_int("HIFIC_NO_WGPIPE", 0);
     }
@@ -2889,10 +2955,23 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
             int np_ = p.NI * p.grp[gi].PH * p.grp[gi].PW;
             if (np_ > npatch_max) npatch_max = np_;
         }
-        const size_t lds_pipe = 512 + 2 * (size_t)64 * (GC_NPIX * 2 + 16) + 2 * (((size_t)(npatch_max + 1) * 144 + 15) & ~(size_t)15);
+        const size_t lds_pipe = 512 + 2 * (size_t)64 * (GC_NPIX * 2 + 16) + 2 * (((size_t)(npatch_max + 3) * 144 + 15) & ~(size_t)15);
         if (pipe) {
-            hipFuncSetAttribute((const void*)wgrad_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
-            hipLaunchKernelGGL(wgrad_pipe_kernel, grid, dim3(256), lds_pipe, st, p);
+            // tap-split 8-wave variant for a full 9-tap group (all 3x3 layers)
+            const bool ts2 = p.ngroups == 1 && p.ntaps == GC_TG && env_int("HIFIC_WGPIPE_TS", 2) == 2;
+            // shifted-fragment form: 3x3 window in (dy, dx) order with dx ascending by one patch pixel
+            bool sh3 = p.ngroups == 1 && p.ntaps == 9 && p.ist == 1 && env_int("HIFIC_WGPIPE_SH3", 1);
+            for (int d = 0; d < 3 && sh3; ++d)
+                for (int j = 0; j < 3; ++j)
+                    sh3 = sh3 && p.tap_dy[3 * d + j] == p.tap_dy[3 * d] && p.tap_dx[3 * d + j] == p.tap_dx[3 * d] + j;
+#define WGP_LAUNCH(TS_, SH_)                                                                                       \
+    do {                                                                                                           \
+        hipFuncSetAttribute((const void*)wgrad_pipe_kernel<TS_, SH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe); \
+        hipLaunchKernelGGL((wgrad_pipe_kernel<TS_, SH_>), grid, dim3(256 * TS_), lds_pipe, st, p);                 \
+    } while (0)
+            if (ts2) { if (sh3) WGP_LAUNCH(2, true); else WGP_LAUNCH(2, false); }
+            else { if (sh3) WGP_LAUNCH(1, true); else WGP_LAUNCH(1, false); }
+#undef WGP_LAUNCH
         }
     }
     if (!pipe) {
