@@ -16,7 +16,7 @@ The same JSON line also carries (N = 1 only, measured in the same process right 
   * `compression`: configs[1], the no-GAN model's training step (16 images per step)
   * `fwd_ms_per_image`: EVALUATION-mode forward (model.py:357-366: reconstruction + q_bpp, no losses), no-grad
   * `roofline`: the dominant GEMM kernel FUNCTION of the headline step, timed live with HIP event pairs on the
-    launch stream (in-library profiler), algorithmic FLOPs on the op's real output domain, against the dense bf16
+    launch stream (in-library profiler; single-stream execution for these steps, see profile_kernels), algorithmic FLOPs on the op's real output domain, against the dense bf16
     MFMA peak; `traffic` = HBM bytes per launch of that kernel from two rocprofv3 --pmc passes (FETCH_SIZE,
     WRITE_SIZE) of a short child run of this script, or null
   * `cpu_baseline`: the oracle (CPU restatement of the reference) on the host cores, bounded sample of the same
@@ -137,11 +137,19 @@ def timed(step, steps, warmup, fence):
 
 def profile_kernels(step, nsteps):
     """HIP-event pairs around every GEMM-class launch of `nsteps` further steps -> per kernel function totals."""
-    from hific_amd import lib
+    from hific_amd import lib, ops
     MAXK = 32
+    # Kernel durations are taken with everything on ONE stream: in the timed headline the weight gradients run on a side
+    # stream (ops._SideLaunch) concurrently with the data-gradient chain, which would charge each kernel for the time it
+    # shares the chip with another one.  (Same setting in the rocprofv3 passes under profiles/: HIFIC_SIDE_WGRAD=0.)
+    side_was = ops._SIDE_ON
+    ops.set_side_stream(False)
     lib.call("hific_prof_begin")
-    for _ in range(nsteps):
-        step()
+    try:
+        for _ in range(nsteps):
+            step()
+    finally:
+        ops.set_side_stream(side_was)
     ms = (ctypes.c_double * MAXK)(); fl = (ctypes.c_double * MAXK)(); cnt = (ctypes.c_int * MAXK)()
     names = ctypes.create_string_buffer(MAXK * 64)
     nk = lib.raw("hific_prof_end")(MAXK, ms, fl, cnt, names)

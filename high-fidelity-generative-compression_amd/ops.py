@@ -7,6 +7,7 @@ Conventions
   * nothing here computes with torch ops: torch allocates outputs and records the graph
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -180,6 +181,67 @@ def _written(*slots):
             sl.written()
 
 
+# ------------------------------------------------------------------------------------------------------
+# Weight / bias gradients on a side stream.  A layer's weight gradient depends only on (x, dy) and nothing on the rest of
+# the backward pass depends on it, so it is launched on a second HIP stream and runs concurrently with the data-gradient
+# chain: the tail of one kernel's grid (e.g. 746 workgroups on 512 slots) is filled by the other's workgroups.  Only for
+# parameters that live in a ParamArena (the kernel writes the arena's gradient slot; nothing is handed back to autograd,
+# which would read it on the main stream).  Joined (main waits for side) by an autograd-engine callback at the end of
+# every backward pass and by `join_side_stream()` (the DDP reducer calls it before a bucket's all-reduce).
+_SIDE_ON = os.environ.get("HIFIC_SIDE_WGRAD", "1") not in ("0", "")
+_side_streams = {}
+_side_state = {"pending": False, "cb": False}
+
+
+def set_side_stream(on):
+    global _SIDE_ON
+    _SIDE_ON = bool(on)
+
+
+def join_side_stream():
+    """Make the current stream wait for every weight-gradient kernel launched on the side stream so far."""
+    if _side_state["pending"]:
+        for dev_index, side in _side_streams.items():
+            torch.cuda.current_stream(dev_index).wait_stream(side)
+        _side_state["pending"] = False
+
+
+def _join_callback():
+    _side_state["cb"] = False
+    join_side_stream()
+
+
+class _SideLaunch:
+    """`with _SideLaunch(ev, x, dy):` - launches inside run on the side stream after event `ev` of the main stream."""
+
+    def __init__(self, ev, *tensors):
+        dev = tensors[0].device
+        side = _side_streams.get(dev.index)
+        if side is None:
+            side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+        side.wait_event(ev)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)           # the caching allocator must not recycle them under the side kernel
+        self._ctx = torch.cuda.stream(side)
+
+    def __enter__(self):
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        _side_state["pending"] = True
+        if not _side_state["cb"]:
+            _side_state["cb"] = True
+            torch.autograd.Variable._execution_engine.queue_callback(_join_callback)
+        return False
+
+
+def _use_side(*slots):
+    return _SIDE_ON and all(sl is not None for sl in slots)
+
+
 def _act_code(act):
     return {None: lib.ACT_NONE, "none": lib.ACT_NONE, "relu": lib.ACT_RELU, "leaky_relu": lib.ACT_LEAKY}[act]
 
@@ -231,21 +293,33 @@ class Conv2dFn(Function):
             dy = dz
         dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
         dx = dw = db = None
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
+        ev = torch.cuda.current_stream(x.device).record_event() if side else None       # dy is ready here
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
             wc = _wcache(weight, 1, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, w_scale)
             call("hific_conv2d_bwd_data", ptr(dy), ptr(weight), ptr(w_scale), ptr(dx), N, C, H, W, K, R, S, stride,
                  pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, *wc, stream())
-        if ctx.needs_input_grad[1]:
-            dwt, acc, dw = _grad_target(ctx.w_slot, weight)
-            flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
-            call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dwt), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
-                 pad_mode, acc, cd, flags, wsp, wsb, stream())
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbt, acc, db = _grad_target(ctx.b_slot, weight.new_empty(K))
-            call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
-                 wsp, wsb, stream())
+
+        def param_grads():
+            nonlocal dw, db
+            wsp_, wsb_ = _ws(x)                      # the workspace of the stream these launches go to
+            if want_w:
+                dwt, acc, dw = _grad_target(ctx.w_slot, weight)
+                flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
+                call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dwt), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                     pad_mode, acc, cd, flags, wsp_, wsb_, stream())
+            if want_b:
+                dbt, acc, db = _grad_target(ctx.b_slot, weight.new_empty(K))
+                call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
+                     wsp_, wsb_, stream())
+        if side:
+            with _SideLaunch(ev, x, dy):
+                param_grads()
+        else:
+            param_grads()
         _written(ctx.w_slot if ctx.needs_input_grad[1] else None,
                  ctx.b_slot if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
         return dx, dw, db, None, None, None, None
@@ -301,21 +375,33 @@ class ConvTranspose2dFn(Function):
             dy = dz
         dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
         dx = dw = db = None
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
+        ev = torch.cuda.current_stream(x.device).record_event() if side else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
             wc = _wcache(weight, 1, (N, Ci, H, W, Co, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
             call("hific_conv_transpose2d_bwd_data", ptr(dy), ptr(weight), ptr(dx), N, Ci, H, W, Co, R, S, stride, pad,
                  outpad, cd, flags, wsp, wsb, *wc, stream())
-        if ctx.needs_input_grad[1]:
-            dwt, acc, dw = _grad_target(ctx.w_slot, weight)
-            flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
-            call("hific_conv_transpose2d_bwd_weight", ptr(x), ptr(dy), ptr(dwt), N, Ci, H, W, Co, R, S, stride, pad,
-                 outpad, acc, cd, flags, wsp, wsb, stream())
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbt, acc, db = _grad_target(ctx.b_slot, weight.new_empty(Co))
-            call("hific_channel_sum", ptr(dy), ptr(dbt), N, Co, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
-                 wsp, wsb, stream())
+
+        def param_grads():
+            nonlocal dw, db
+            wsp_, wsb_ = _ws(x)
+            if want_w:
+                dwt, acc, dw = _grad_target(ctx.w_slot, weight)
+                flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
+                call("hific_conv_transpose2d_bwd_weight", ptr(x), ptr(dy), ptr(dwt), N, Ci, H, W, Co, R, S, stride, pad,
+                     outpad, acc, cd, flags, wsp_, wsb_, stream())
+            if want_b:
+                dbt, acc, db = _grad_target(ctx.b_slot, weight.new_empty(Co))
+                call("hific_channel_sum", ptr(dy), ptr(dbt), N, Co, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
+                     wsp_, wsb_, stream())
+        if side:
+            with _SideLaunch(ev, x, dy):
+                param_grads()
+        else:
+            param_grads()
         _written(ctx.w_slot if ctx.needs_input_grad[1] else None,
                  ctx.b_slot if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
         return dx, dw, db, None, None, None

@@ -71,6 +71,9 @@ class BucketedGradReducer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self.launched[b] = True
+        # weight gradients may still be running on ops' side stream: the collective is ordered after the CURRENT stream
+        from . import ops
+        ops.join_side_stream()
         self.works.append(dist.all_reduce(self.arena.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
                                           async_op=True))
 

@@ -1,12 +1,15 @@
 # Round-2 measurement run (GPU box): all GPU tests, the bench line (live traffic + CPU baseline), 1-rank RCCL run,
 # rocprofv3 kernel traces of both training configs, and the per-kernel HBM / MFMA-busy table (separate --pmc passes).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_final; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${OUTTAG:-r02_final}; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; cut -c1-400 $O/bench.json
 HIFIC_FORCE_DIST=1 timeout 200 python bench.py --steps 3 --warmup 2 --no-extras > $O/rccl_1rank.log 2>&1; tail -1 $O/rccl_1rank.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
 STEPS=7
+# per-kernel durations / counters with everything on one stream (the headline overlaps the weight gradients on a side
+# stream; co-scheduled kernels would be charged for each other's time): same setting as bench.py's roofline leg
+export HIFIC_SIDE_WGRAD=0
 timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/ksg -o ks -- python $R/bench.py --steps 5 --warmup 2 --no-extras > /tmp/ksg.log 2>&1
 timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/ksc -o ks -- python $R/bench.py --config compression --steps 5 --warmup 2 --no-extras > /tmp/ksc.log 2>&1
 dbg=$(find /tmp/ksg -name "*.db" | head -1); dbc=$(find /tmp/ksc -name "*.db" | head -1)
