@@ -88,3 +88,19 @@ def test_full_size_training_step_properties(hific, dev):
     assert cos > 0.98, cos
     # Adam moved every parameter that has a gradient by at most lr
     assert float((p16 - p16b).abs().max()) == 0.0
+
+
+def test_side_stream_weight_gradients_equal_single_stream(hific, dev):
+    """ops._SideLaunch: weight / bias gradients of arena parameters run on a second stream.  Same kernels, same
+    summation orders: the step must be bit-identical to single-stream execution, and the gradients must be complete
+    when backward() returns (they are read right after it, on the main stream, without a device synchronisation)."""
+    from hific_amd import ops
+    was = ops._SIDE_ON
+    try:
+        ops.set_side_stream(False)
+        l0, g0, h0, p0 = _one_step(hific, dev, torch.bfloat16, 3)
+        ops.set_side_stream(True)
+        l1, g1, h1, p1 = _one_step(hific, dev, torch.bfloat16, 3)
+    finally:
+        ops.set_side_stream(was)
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(h0, h1) and torch.equal(p0, p1)
