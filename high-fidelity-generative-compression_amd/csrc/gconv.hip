@@ -2212,13 +2212,27 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     for (int i = 0; i < p.nphase; ++i) if (p.ph[i].ntaps > maxtaps) maxtaps = p.ph[i].ntaps;
     // taps per barrier step (gconv_kernel TPS): 7 for >= 49 taps, 4 for >= 16, when the per-thread weight prefetch stays
     // within 8 x 16 bytes per register set (few-row / few-channel tiles: exactly the layers that are barrier-bound)
+    // Launches that cannot even give every CU one workgroup (the hyperprior's 4x4 .. 16x16 planes: 30-160 workgroups of
+    // 45-125 serial steps) are bound by the latency of ONE 8 KB weight tile per step (1 us per step, 240 GB/s chip-wide):
+    // several tiles in flight per step from 4 taps up, and no co-residency constraint on the ring size.
+    long long est_grid = 0;
+    for (int i = 0; i < p.nphase; ++i)
+        est_grid += cdivl((long long)p.N * p.ph[i].OHt * p.ph[i].OWt, GC_NPIX) * cdiv(p.K, 64);
+    const bool small_grid = est_grid < 256 && !env_int("HIFIC_NO_TPS_SMALL", 0);
+    // ... and with >= 25 taps, 32-row tiles: twice the workgroups, and a 4 KB weight tile per tap lets 7 taps share a step
+    if (small_grid && maxtaps >= 25 && bm == 64 && !phs && std::is_same<T, bf16_t>::value && BC == 64 &&
+        !env_int("HIFIC_NO_TPS", 0) && !env_int("HIFIC_BM", 0)) {
+        bm = 32; p.Kpad = cdiv(p.K, bm) * bm;
+    }
     auto pick_tps = [&](int bm_) -> int {
         if (!std::is_same<T, bf16_t>::value || env_int("HIFIC_NO_TPS", 0)) return 1;
         const int nwp = cdiv(bm_ * (BC * (int)sizeof(T) / 16), 256);
-        const int cand = maxtaps >= 49 ? 7 : (maxtaps >= 16 ? 4 : 1);
+        int cand = maxtaps >= 49 ? 7 : (maxtaps >= 16 ? 4 : ((small_grid && maxtaps >= 4) ? 4 : 1));
+        if (small_grid && maxtaps >= 25 && nwp * 7 <= 8) cand = 7;
         // ... and the weight ring must leave room for two co-resident workgroups (7 taps x 4.6 KB x 2 next to a 55 KB patch
         // put the 60->3 layer at one workgroup per CU: 640 -> 790 us)
-        return (cand > 1 && nwp * cand <= 8 && 2 * cand * bm_ * PITCH <= 44 * 1024) ? cand : 1;
+        const int ring_cap = small_grid ? 96 * 1024 : 44 * 1024;
+        return (cand > 1 && nwp * cand <= 8 && 2 * cand * bm_ * PITCH <= ring_cap) ? cand : 1;
     };
     int tps = pick_tps(bm);
     int wbytes = 512 + 2 * tps * bm * PITCH;

@@ -836,24 +836,36 @@ class SNConv2dFn(Function):
         dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
         inv_sigma = sig[1:]
         dx = dw = db = None
+        want_w, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
+        ev = torch.cuda.current_stream(x.device).record_event() if side else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
             call("hific_conv2d_bwd_data", ptr(dy), ptr(weight_orig), ptr(inv_sigma), ptr(dx), N, C, H, W, K, R, S,
                  stride, pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, None, 0, 0, stream())
-        if ctx.needs_input_grad[1]:
-            dws = torch.empty_like(weight_orig)       # gradient w.r.t. the normalised weight
-            flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
-            call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dws), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
-                 pad_mode, 0, cd, flags, wsp, wsb, stream())
-            dwt, acc, dw = _grad_target(ctx.w_slot, weight_orig)
-            M = weight_orig.numel() // K
-            call("hific_spectral_norm_bwd", ptr(dws), ptr(weight_orig), ptr(u), ptr(v), ptr(sig), ptr(dwt), K, M, acc,
-                 wsp, wsb, stream())
-        if ctx.needs_input_grad[2]:
-            dbt, acc, db = _grad_target(ctx.b_slot, weight_orig.new_empty(K))
-            call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
-                 wsp, wsb, stream())
+
+        def param_grads():
+            nonlocal dw, db
+            wsp_, wsb_ = _ws(x)
+            if want_w:
+                dws = torch.empty_like(weight_orig)       # gradient w.r.t. the normalised weight (stream-local scratch)
+                flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
+                call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dws), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                     pad_mode, 0, cd, flags, wsp_, wsb_, stream())
+                dwt, acc, dw = _grad_target(ctx.w_slot, weight_orig)
+                M = weight_orig.numel() // K
+                call("hific_spectral_norm_bwd", ptr(dws), ptr(weight_orig), ptr(u), ptr(v), ptr(sig), ptr(dwt), K, M,
+                     acc, wsp_, wsb_, stream())
+            if want_b:
+                dbt, acc, db = _grad_target(ctx.b_slot, weight_orig.new_empty(K))
+                call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
+                     wsp_, wsb_, stream())
+        if side:
+            with _SideLaunch(ev, x, dy, u, v, sig):
+                param_grads()
+        else:
+            param_grads()
         _written(ctx.w_slot if ctx.needs_input_grad[1] else None, ctx.b_slot if ctx.needs_input_grad[2] else None)
         return dx, dw, db, None, None, None, None, None, None
 
