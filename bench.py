@@ -141,15 +141,18 @@ def profile_kernels(step, nsteps):
     MAXK = 32
     # Kernel durations are taken with everything on ONE stream: in the timed headline the weight gradients run on a side
     # stream (ops._SideLaunch) concurrently with the data-gradient chain, which would charge each kernel for the time it
-    # shares the chip with another one.  (Same setting in the rocprofv3 passes under profiles/: HIFIC_SIDE_WGRAD=0.)
-    side_was = ops._SIDE_ON
+    # shares the chip with another one; likewise the loss branch / Discriminator branch streams of model.py.  (Same setting in
+    # the rocprofv3 passes under profiles/: HIFIC_SIDE_WGRAD=0 HIFIC_BRANCH_STREAMS=0.)
+    side_was, branch_was = ops._SIDE_ON, ops.branch_streams_on()
     ops.set_side_stream(False)
+    ops.set_branch_streams(False)
     lib.call("hific_prof_begin")
     try:
         for _ in range(nsteps):
             step()
     finally:
         ops.set_side_stream(side_was)
+        ops.set_branch_streams(branch_was)
     ms = (ctypes.c_double * MAXK)(); fl = (ctypes.c_double * MAXK)(); cnt = (ctypes.c_int * MAXK)()
     names = ctypes.create_string_buffer(MAXK * 64)
     nk = lib.raw("hific_prof_end")(MAXK, ms, fl, cnt, names)

@@ -157,10 +157,27 @@ class Model(nn.Module):
             # the reconstruction feeds the compression losses and D: explicit fan-out
             rec_a, rec_b = ops.fork(intermediates.reconstruction)
             inter_c, inter_d = intermediates._replace(reconstruction=rec_a), intermediates._replace(reconstruction=rec_b)
-        loss = self.compression_loss(inter_c, hyperinfo)
-        if self.use_discriminator:
+        if self.use_discriminator and ops.branch_streams_on() and x.is_cuda:
+            # The distortion / LPIPS / rate branch and the Discriminator branch only meet again in the sum below: the
+            # first runs on a second stream, concurrently with D.  autograd replays every op's backward on the stream
+            # its forward ran on (and synchronises producers with consumers), so the two backward chains overlap too.
+            main = torch.cuda.current_stream(x.device)
+            s2 = ops.branch_stream(x.device)
+            s2.wait_stream(main)
+            for t in (inter_c.input_image, inter_c.reconstruction, inter_c.n_bpp, inter_c.q_bpp) + tuple(hyperinfo):
+                if torch.is_tensor(t):
+                    t.record_stream(s2)
+            with torch.cuda.stream(s2):
+                loss = self.compression_loss(inter_c, hyperinfo)
             out['disc'], G_loss = self.GAN_loss(inter_d, train_generator)
+            main.wait_stream(s2)
+            loss.record_stream(main)
             loss = loss + self.args.beta * G_loss
+        else:
+            loss = self.compression_loss(inter_c, hyperinfo)
+            if self.use_discriminator:
+                out['disc'], G_loss = self.GAN_loss(inter_d, train_generator)
+                loss = loss + self.args.beta * G_loss
         out['compression'] = loss
         self._log(weighted_compression_loss=loss)
         return (out, intermediates) if return_intermediates is True else out

@@ -238,6 +238,28 @@ class _SideLaunch:
         return False
 
 
+# A second "branch" stream for independent sub-graphs of the forward pass (model.py: loss branch vs Discriminator branch)
+_BRANCH_ON = os.environ.get("HIFIC_BRANCH_STREAMS", "1") not in ("0", "")
+_branch_streams = {}
+
+
+def branch_streams_on():
+    return _BRANCH_ON
+
+
+def set_branch_streams(on):
+    global _BRANCH_ON
+    _BRANCH_ON = bool(on)
+
+
+def branch_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _branch_streams.get(idx)
+    if st is None:
+        st = _branch_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _use_side(*slots):
     return _SIDE_ON and all(sl is not None for sl in slots)
 

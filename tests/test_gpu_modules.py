@@ -277,3 +277,40 @@ def test_instance_norm_variant_trains(hific, dev, dt):
     h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"), sd["conv_block_out.1.weight"], sd["conv_block_out.1.bias"])
     assert _relerr(y.detach().float().cpu(), h) < (1e-3 if dt == torch.float32 else 6e-2)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+
+
+@pytest.mark.gpu
+def test_branch_streams_equal_single_stream(hific, dev, sd):
+    """model.py runs the distortion / LPIPS / rate branch on a second stream next to the Discriminator branch (and, with
+    arenas, weight gradients on a third): every loss and every parameter gradient of a G-turn must be bit-identical to
+    single-stream execution."""
+    import hific_amd
+    from hific_amd import ops, optim
+    from hific_amd.default_config import make_args, hific_args, ModelTypes
+    hific.set_compute_dtype(torch.bfloat16)
+
+    def run(streams_on):
+        ops.set_branch_streams(streams_on); ops.set_side_stream(streams_on)
+        torch.manual_seed(0)
+        model = hific_amd.Model(make_args(hific_args, n_residual_blocks=N_RES), model_type=ModelTypes.COMPRESSION_GAN,
+                                allow_random_lpips_backbone=True)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dev).train()
+        amort = optim.FusedAdam([p for m in model.amortization_models for p in m.parameters()], lr=1e-4)
+        disc = optim.FusedAdam(list(model.Discriminator.parameters()), lr=1e-4)
+        x = O.make_image(3, 4, 128, 128).to(dev)
+        torch.manual_seed(1)
+        losses = model(x, train_generator=True, writeout=False)
+        losses["compression"].backward()
+        out = (float(losses["compression"]), float(losses["disc"]), amort.arena.flat_grad.clone(), disc.arena.flat_grad.clone())
+        torch.cuda.synchronize()
+        return out
+
+    was = (ops.branch_streams_on(), ops._SIDE_ON)
+    try:
+        a = run(False)
+        b = run(True)
+    finally:
+        ops.set_branch_streams(was[0]); ops.set_side_stream(was[1])
+    assert a[0] == b[0] and a[1] == b[1]
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 STEPS=7
 # per-kernel durations / counters with everything on one stream (the headline overlaps the weight gradients on a side
 # stream; co-scheduled kernels would be charged for each other's time): same setting as bench.py's roofline leg
-export HIFIC_SIDE_WGRAD=0
+export HIFIC_SIDE_WGRAD=0 HIFIC_BRANCH_STREAMS=0
 timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/ksg -o ks -- python $R/bench.py --steps 5 --warmup 2 --no-extras > /tmp/ksg.log 2>&1
 timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/ksc -o ks -- python $R/bench.py --config compression --steps 5 --warmup 2 --no-extras > /tmp/ksc.log 2>&1
 dbg=$(find /tmp/ksg -name "*.db" | head -1); dbc=$(find /tmp/ksc -name "*.db" | head -1)
