@@ -174,7 +174,13 @@ class Hyperprior(CodingModel):
                                             vectorize=self.vectorize_encoding, block_decode=self.block_encode,
                                             scale_lower_bound=self.scale_lower_bound)
 
-    def forward(self, latents, spatial_shape, **kwargs):
+    def forward(self, latents, spatial_shape, defer_rate_join=False, **kwargs):
+        """`src/hyperprior.py:277-330`.  The critical path to the Generator is analysis -> quantise -> synthesis_mu ->
+        straight-through quantisation; the rate side (both hyperlatent likelihoods, synthesis_std, both latent likelihoods,
+        the four entropies) only feeds the loss, so with branch streams on it runs on ops.branch_stream() concurrently
+        with whatever the caller launches next (and its backward concurrently with the Generator's).  The caller's stream
+        waits for it before this returns unless `defer_rate_join=True` (then the caller must order its first use of the
+        *_bpp fields after ops.branch_stream(), as model.py does)."""
         if latents.dtype != torch.float32:
             latents = ops.cast_grad(latents, torch.float32)
         lat_a, lat_b = ops.fork(latents)
@@ -183,51 +189,61 @@ class Hyperprior(CodingModel):
 
         hyperlatents = self.analysis_net(lat_a)
         hyp_n, hyp_q = ops.fork(hyperlatents)
-
-        # differential entropy, hyperlatents
         noisy_hyperlatents = self._quantize(hyp_n, mode='noise')
         nh_lik, nh_dec = ops.fork(noisy_hyperlatents)
-        noisy_hyperlatent_likelihood = self.hyperlatent_likelihood(nh_lik)
-        _, noisy_hyperlatent_bpp = self._estimate_entropy(noisy_hyperlatent_likelihood, spatial_shape)
-
-        # discrete entropy, hyperlatents
         quantized_hyperlatents = self._quantize(hyp_q, mode='quantize')
         qh_lik, qh_dec = ops.fork(quantized_hyperlatents)
-        quantized_hyperlatent_likelihood = self.hyperlatent_likelihood(qh_lik)
-        _, quantized_hyperlatent_bpp = self._estimate_entropy(quantized_hyperlatent_likelihood, spatial_shape)
 
         hyperlatents_decoded = nh_dec if self.training is True else qh_dec
         hd_mu, hd_std = ops.fork(hyperlatents_decoded)
 
         latent_means = self.synthesis_mu(hd_mu)
-        latent_scales = self.synthesis_std(hd_std)
         if getattr(self, 'keep_debug', False):          # parity tests: symbols = round(decoded - means)
             self.debug_latent_means = latent_means.detach().float().clone()
-        latent_scales = lower_bound_toward(latent_scales, self.scale_lower_bound)
-
         mu_a, mu_b = ops.fork(latent_means)
         mu_c, mu_d = ops.fork(mu_b)
         mu_e, mu_f = ops.fork(mu_d)
-        sc_a, sc_b = ops.fork(latent_scales)
+        mu_g, mu_h = ops.fork(mu_f)
 
-        # differential entropy, latents (the reference adds noise to the latents irrespective of `means`)
-        noisy_latents = self._quantize(lat_c, mode='noise', means=mu_a)
-        noisy_latent_likelihood = self.latent_likelihood(noisy_latents, mean=mu_c, scale=sc_a)
-        _, noisy_latent_bpp = self._estimate_entropy(noisy_latent_likelihood, spatial_shape)
+        latents_decoded = self.quantize_latents_st(lat_f, mu_g)          # end of the critical path
 
-        # discrete entropy, latents
-        quantized_latents = self._quantize(lat_e, mode='quantize', means=mu_e)
-        quantized_latent_likelihood = self.latent_likelihood(quantized_latents, mean=mu_f, scale=sc_b)
-        _, quantized_latent_bpp = self._estimate_entropy(quantized_latent_likelihood, spatial_shape)
+        def rate_side():
+            # differential / discrete entropy, hyperlatents
+            noisy_hyperlatent_likelihood = self.hyperlatent_likelihood(nh_lik)
+            _, noisy_hyperlatent_bpp = self._estimate_entropy(noisy_hyperlatent_likelihood, spatial_shape)
+            quantized_hyperlatent_likelihood = self.hyperlatent_likelihood(qh_lik)
+            _, quantized_hyperlatent_bpp = self._estimate_entropy(quantized_hyperlatent_likelihood, spatial_shape)
 
-        latents_decoded = self.quantize_latents_st(lat_f, mu_a)
+            latent_scales = self.synthesis_std(hd_std)
+            latent_scales = lower_bound_toward(latent_scales, self.scale_lower_bound)
+            sc_a, sc_b = ops.fork(latent_scales)
 
-        return HyperInfo(
-            decoded=latents_decoded,
-            latent_nbpp=noisy_latent_bpp,
-            hyperlatent_nbpp=noisy_hyperlatent_bpp,
-            total_nbpp=noisy_latent_bpp + noisy_hyperlatent_bpp,
-            latent_qbpp=quantized_latent_bpp,
-            hyperlatent_qbpp=quantized_hyperlatent_bpp,
-            total_qbpp=quantized_latent_bpp + quantized_hyperlatent_bpp,
-        )
+            # differential entropy, latents (the reference adds noise to the latents irrespective of `means`)
+            noisy_latents = self._quantize(lat_c, mode='noise', means=mu_a)
+            noisy_latent_likelihood = self.latent_likelihood(noisy_latents, mean=mu_c, scale=sc_a)
+            _, noisy_latent_bpp = self._estimate_entropy(noisy_latent_likelihood, spatial_shape)
+
+            # discrete entropy, latents
+            quantized_latents = self._quantize(lat_e, mode='quantize', means=mu_e)
+            quantized_latent_likelihood = self.latent_likelihood(quantized_latents, mean=mu_h, scale=sc_b)
+            _, quantized_latent_bpp = self._estimate_entropy(quantized_latent_likelihood, spatial_shape)
+            return (noisy_latent_bpp, noisy_hyperlatent_bpp, noisy_latent_bpp + noisy_hyperlatent_bpp,
+                    quantized_latent_bpp, quantized_hyperlatent_bpp, quantized_latent_bpp + quantized_hyperlatent_bpp)
+
+        if ops.branch_streams_on() and latents.is_cuda:
+            main = torch.cuda.current_stream(latents.device)
+            s2 = ops.branch_stream(latents.device)
+            s2.wait_stream(main)
+            for t in (nh_lik, qh_lik, hd_std, lat_c, lat_e, mu_a, mu_c, mu_e, mu_h):
+                t.record_stream(s2)
+            with torch.cuda.stream(s2):
+                bpps = rate_side()
+            for t in bpps:
+                t.record_stream(main)
+            if not defer_rate_join:
+                main.wait_stream(s2)
+        else:
+            bpps = rate_side()
+
+        return HyperInfo(decoded=latents_decoded, latent_nbpp=bpps[0], hyperlatent_nbpp=bpps[1], total_nbpp=bpps[2],
+                         latent_qbpp=bpps[3], hyperlatent_qbpp=bpps[4], total_qbpp=bpps[5])

@@ -90,7 +90,8 @@ class Model(nn.Module):
 
     def compression_forward(self, x):
         y = self.Encoder(x)
-        hyperinfo = self.Hyperprior(y, spatial_shape=x.size()[2:])
+        # the rate side of the hyperprior runs on the branch stream; its join is deferred to the first use of the rates
+        hyperinfo = self.Hyperprior(y, spatial_shape=x.size()[2:], defer_rate_join=True)
         lat_gen, lat_disc = ops.fork(hyperinfo.decoded)
         reconstruction = self._out_activation(self.Generator(lat_gen))
         return Intermediates(x, reconstruction, lat_disc, hyperinfo.total_nbpp, hyperinfo.total_qbpp), hyperinfo
@@ -148,6 +149,10 @@ class Model(nn.Module):
         if train_generator is True:
             self.step_counter += 1            # a 'step' is one cycle of G-D training (model.py:351-353)
         intermediates, hyperinfo = self.compression_forward(x)
+        branch = ops.branch_streams_on() and x.is_cuda
+        if branch and not (self.use_discriminator and self.model_mode != ModelModes.EVALUATION):
+            # rates were produced on the branch stream (Hyperprior.forward, deferred join); below they are used on this one
+            torch.cuda.current_stream(x.device).wait_stream(ops.branch_stream(x.device))
         if self.model_mode == ModelModes.EVALUATION:
             # model.py:357-366: no losses, the clamped reconstruction and the quantised rate
             return torch.clamp(intermediates.reconstruction.float(), min=0., max=1.), intermediates.q_bpp

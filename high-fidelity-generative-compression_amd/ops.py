@@ -203,6 +203,10 @@ def join_side_stream():
     if _side_state["pending"]:
         for dev_index, side in _side_streams.items():
             torch.cuda.current_stream(dev_index).wait_stream(side)
+        # kernels of ops whose forward ran on the branch stream write parameter gradients (arena slots) from that stream in
+        # backward; autograd's own end-of-backward synchronisation only covers gradients it accumulates itself
+        for dev_index, br in _branch_streams.items():
+            torch.cuda.current_stream(dev_index).wait_stream(br)
         _side_state["pending"] = False
 
 
@@ -556,6 +560,9 @@ class AddNoiseFn(Function):
     @staticmethod
     def forward(ctx, x, noise):
         require_gpu(x, noise)
+        # the caller's noise may have been allocated on another stream than the one this runs on (branch streams) and is
+        # usually dropped right after this call: keep the allocator from recycling it under the kernel
+        noise.record_stream(torch.cuda.current_stream(noise.device))
         return _add(x, noise)
 
     @staticmethod
