@@ -200,7 +200,7 @@ def set_side_stream(on):
 
 def join_side_stream():
     """Make the current stream wait for every weight-gradient kernel launched on the side stream so far."""
-    if _side_state["pending"]:
+    if _side_state["pending"] or _branch_streams:
         for dev_index, side in _side_streams.items():
             torch.cuda.current_stream(dev_index).wait_stream(side)
         # kernels of ops whose forward ran on the branch stream write parameter gradients (arena slots) from that stream in
