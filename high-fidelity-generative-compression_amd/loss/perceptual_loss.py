@@ -30,12 +30,12 @@ ALEX_CFG = [(3, 64, 11, 4, 2, True), (64, 192, 5, 1, 2, True), (192, 384, 3, 1, 
 ALEX_FEATURE_IDX = [0, 3, 6, 8, 10]
 
 
-def _conv_fwd(x, w, b, stride, pad, cd):
+def _conv_fwd(x, w, b, stride, pad, cd, out=None):
     N, C, H, W = x.shape
     K, _, R, S = w.shape
     OH = (H + 2 * pad - R) // stride + 1
     OW = (W + 2 * pad - S) // stride + 1
-    y = torch.empty((N, K, OH, OW), dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty((N, K, OH, OW), dtype=x.dtype, device=x.device)
     ws = lib.workspace(x.device)
     geom = (N, C, H, W, K, R, S, stride, pad, pad, pad, pad, lib.PAD_ZERO)
     wc = ops._wcache(w, 0, geom, cd, 0)                      # frozen backbone: packed once
@@ -55,17 +55,44 @@ def _conv_bwd_data(dy, w, xshape, stride, pad, cd):
     return dx
 
 
-def _maxpool(x):
+def _maxpool(x, out=None):
     N, C, H, W = x.shape
     OH, OW = (H - 3) // 2 + 1, (W - 3) // 2 + 1
-    y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device)
     call("hific_maxpool3s2_fwd", ptr(x), ptr(y), N * C, H, W, lib.dtype_code(x), stream())
     return y
 
 
+def _alex_half(h, wb, cd, feats, lo, B):
+    """AlexNet.features on the B images `h`; the feature map of layer li goes to rows [lo, lo+B) of the 2B-image buffer
+    feats[li] (allocated here on first use).  Every output pixel is computed by the same instruction sequence whatever
+    the batch size, so filling the two halves separately gives the bits of one 2B pass."""
+    for li, (ci, co, k, s, p, pool) in enumerate(ALEX_CFG):
+        N, C, H, W = h.shape
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        if feats[li] is None:
+            feats[li] = torch.empty((2 * B, co, OH, OW), dtype=h.dtype, device=h.device)
+        f = feats[li][lo:lo + B]
+        _conv_fwd(h, wb[2 * li], wb[2 * li + 1], s, p, cd, out=f)
+        h = _maxpool(f) if (pool and li < len(ALEX_CFG) - 1) else f
+
+
+class TargetFeatures:
+    """Target-image half of the LPIPS feature maps, computed ahead of the loss (PerceptualLoss.prefetch_target): it
+    depends on the input image only, so it can run on a second stream while the Encoder / Generator produce the other
+    image."""
+
+    def __init__(self, key, feats, event):
+        self.key, self.feats, self.event = key, feats, event
+
+
+def _target_key(target, normalize, cd):
+    return (target.data_ptr(), target._version, tuple(target.shape), target.dtype, int(normalize), cd)
+
+
 class LpipsFn(Function):
     @staticmethod
-    def forward(ctx, pred, target, normalize, lins, *wb):
+    def forward(ctx, pred, target, normalize, lins, pre, *wb):
         lib.require_gpu(pred, target, *lins, *wb)
         cdt = ops.get_compute_dtype()
         cd = lib.HIFIC_F32 if cdt == torch.float32 else lib.HIFIC_BF16
@@ -74,21 +101,25 @@ class LpipsFn(Function):
         # in0 = target, in1 = pred (perceptual_loss.py:40: self.model.forward(target, pred))
         call("hific_lpips_prep", ptr(target), 1 if target.dtype == torch.float32 else 0, ptr(pred),
              1 if pred.dtype == torch.float32 else 0, ptr(x), B, H * W, int(normalize), cd, stream())
-        feats, pools = [], []
         val = torch.empty(B, dtype=torch.float32, device=pred.device)
         ws = lib.workspace(pred.device)
-        h = x
+        if pre is not None and pre.key == _target_key(target, normalize, cd):
+            cur = torch.cuda.current_stream(pred.device)
+            cur.wait_event(pre.event)
+            feats = pre.feats
+            for f in feats:
+                f.record_stream(cur)
+            _alex_half(x[B:], wb, cd, feats, B, B)               # generated-image half only
+        else:
+            feats = [None] * len(ALEX_CFG)
+            h = x
+            for li, (ci, co, k, s, p, pool) in enumerate(ALEX_CFG):
+                feats[li] = _conv_fwd(h, wb[2 * li], wb[2 * li + 1], s, p, cd)
+                h = _maxpool(feats[li]) if (pool and li < len(ALEX_CFG) - 1) else feats[li]
         for li, (ci, co, k, s, p, pool) in enumerate(ALEX_CFG):
-            f = _conv_fwd(h, wb[2 * li], wb[2 * li + 1], s, p, cd)
-            feats.append(f)
+            f = feats[li]
             call("hific_lpips_tap_fwd", ptr(f), ptr(lins[li]), ptr(val), B, co, f.shape[2] * f.shape[3],
                  0 if li == 0 else 1, cd, ws.data_ptr(), ws.numel(), stream())
-            if pool and li < len(ALEX_CFG) - 1:
-                h = _maxpool(f)
-                pools.append(h)
-            else:
-                h = f
-                pools.append(None)
         ctx.normalize, ctx.cd, ctx.B, ctx.in_shape, ctx.pred_dtype = int(normalize), cd, B, (B, 3, H, W), pred.dtype
         ctx.lins = lins
         ctx.save_for_backward(x, *feats, *wb)
@@ -136,7 +167,7 @@ class LpipsFn(Function):
         dpred = torch.empty(ctx.in_shape, dtype=ctx.pred_dtype, device=g.device)
         call("hific_lpips_prep_bwd", ptr(grad), ptr(dpred), B, ctx.in_shape[2] * ctx.in_shape[3],
              ctx.normalize, cd, 1 if ctx.pred_dtype == torch.float32 else 0, stream())
-        return (dpred, None, None, None) + (None,) * len(wb)
+        return (dpred, None, None, None, None) + (None,) * len(wb)
 
 
 class PerceptualLoss(nn.Module):
@@ -218,4 +249,25 @@ class PerceptualLoss(nn.Module):
         wb = []
         for idx in ALEX_FEATURE_IDX:
             wb += [self._t[f"features.{idx}.weight"], self._t[f"features.{idx}.bias"]]
-        return LpipsFn.apply(pred.contiguous(), target.contiguous(), normalize, lins, *wb)
+        pre = self.__dict__.pop("_prefetched", None)
+        return LpipsFn.apply(pred.contiguous(), target.contiguous(), normalize, lins, pre, *wb)
+
+    def prefetch_target(self, target, normalize=False):
+        """Computes the target-image half of the feature maps now, on the current stream, for the next forward() with this
+        very `target` (same tensor, unmodified).  A forward() with another target ignores it."""
+        cdt = ops.get_compute_dtype()
+        cd = lib.HIFIC_F32 if cdt == torch.float32 else lib.HIFIC_BF16
+        target = target.contiguous()
+        lib.require_gpu(target)
+        wb = []
+        for idx in ALEX_FEATURE_IDX:
+            wb += [self._t[f"features.{idx}.weight"], self._t[f"features.{idx}.bias"]]
+        B, _, H, W = target.shape
+        with torch.no_grad():
+            xt = torch.empty((2 * B, 3, H, W), dtype=cdt, device=target.device)
+            tf = 1 if target.dtype == torch.float32 else 0
+            call("hific_lpips_prep", ptr(target), tf, ptr(target), tf, ptr(xt), B, H * W, int(normalize), cd, stream())
+            feats = [None] * len(ALEX_CFG)
+            _alex_half(xt[:B], wb, cd, feats, 0, B)
+        ev = torch.cuda.current_stream(target.device).record_event()
+        self.__dict__["_prefetched"] = TargetFeatures(_target_key(target, normalize, cd), feats, ev)

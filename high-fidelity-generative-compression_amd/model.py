@@ -148,8 +148,17 @@ class Model(nn.Module):
         self.writeout = writeout
         if train_generator is True:
             self.step_counter += 1            # a 'step' is one cycle of G-D training (model.py:351-353)
-        intermediates, hyperinfo = self.compression_forward(x)
         branch = ops.branch_streams_on() and x.is_cuda
+        if branch and self.model_mode != ModelModes.EVALUATION:
+            # the LPIPS features of the input image depend on nothing the networks compute: start them on the branch
+            # stream now, next to the Encoder (perceptual_loss_wrapper below picks them up)
+            main = torch.cuda.current_stream(x.device)
+            s2 = ops.branch_stream(x.device)
+            s2.wait_stream(main)
+            x.record_stream(s2)
+            with torch.cuda.stream(s2):
+                self.perceptual_loss.prefetch_target(x, normalize=True)
+        intermediates, hyperinfo = self.compression_forward(x)
         if branch and not (self.use_discriminator and self.model_mode != ModelModes.EVALUATION):
             # rates were produced on the branch stream (Hyperprior.forward, deferred join); below they are used on this one
             torch.cuda.current_stream(x.device).wait_stream(ops.branch_stream(x.device))

@@ -143,6 +143,38 @@ def test_lpips_forward_backward(hific, dev, dt, tol):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_lpips_target_prefetch_is_bit_identical(hific, dev, dt):
+    """PerceptualLoss.prefetch_target computes the target half of the feature maps ahead of time (model.py starts it on
+    a second stream): value and gradient must equal the single 2B-batch pass bit for bit; a forward with another target
+    must ignore the stale prefetch."""
+    from hific_amd.loss.perceptual_loss import PerceptualLoss
+    hific.set_compute_dtype(dt)
+    B, H = 4, 96
+    pl = PerceptualLoss(allow_random_backbone=True).to(dev)
+    target = O.make_image(3, B, H, H).to(dev)
+    other = O.make_image(4, B, H, H).to(dev)
+    pred = (target + 0.1 * _rnd((B, 3, H, H), 5).to(dev)).clamp(0, 1).to(dt)
+
+    def run(prefetch, tgt):
+        pd = pred.clone().requires_grad_(True)
+        if prefetch is not None:
+            s2 = torch.cuda.Stream(device=dev)
+            s2.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s2):
+                pl.prefetch_target(prefetch, normalize=True)
+        v = pl(pd, tgt, normalize=True)
+        v.mean().backward()
+        torch.cuda.synchronize()
+        return v.detach().clone(), pd.grad.clone()
+
+    v0, g0 = run(None, target)
+    v1, g1 = run(target, target)
+    v2, g2 = run(other, target)              # stale prefetch (different tensor): ignored
+    assert torch.equal(v0, v1) and torch.equal(g0, g1)
+    assert torch.equal(v0, v2) and torch.equal(g0, g2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_maxpool_fwd_bwd(hific, dev, dt):
     from hific_amd import lib
     x = F.relu(_rnd((2, 5, 15, 31), 1))
