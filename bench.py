@@ -131,8 +131,13 @@ def timed(step, steps, warmup, fence):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    t_enq = time.perf_counter() - t0            # host finished enqueueing (diagnostic: host-bound if ~ the total)
     fence()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if os.environ.get("HIFIC_BENCH_DIAG"):
+        print(f"[bench diag] {steps} steps: host enqueue {t_enq * 1e3 / steps:.2f} ms/step, total {dt * 1e3 / steps:.2f} ms/step",
+              file=sys.stderr)
+    return dt
 
 
 def profile_kernels(step, nsteps):

@@ -242,7 +242,15 @@ def join_side_stream():
         # kernels of ops whose forward ran on the branch stream write parameter gradients (arena slots) from that stream in
         # backward; autograd's own end-of-backward synchronisation only covers gradients it accumulates itself
         for dev_index, br in _branch_streams.items():
-            torch.cuda.current_stream(dev_index).wait_stream(br)
+            cur = torch.cuda.current_stream(dev_index)
+            if cur.cuda_stream != br.cuda_stream:
+                cur.wait_stream(br)
+            else:
+                # called from a backward node that itself runs on the branch stream (a DDP bucket sealed there): the
+                # collective launched next is ordered after THIS stream, so it must also see the caller's main stream
+                home = _home_streams.get(dev_index)
+                if home is not None:
+                    cur.wait_stream(home)
         _side_state["pending"] = False
 
 
@@ -292,11 +300,19 @@ def set_branch_streams(on):
     _BRANCH_ON = bool(on)
 
 
+_home_streams = {}
+
+
 def branch_stream(device):
+    """The branch stream of `device`; the stream that is current when it is requested is remembered as the model's main
+    stream (callers ask for it right before forking work off their current stream)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _branch_streams.get(idx)
     if st is None:
         st = _branch_streams[idx] = torch.cuda.Stream(device=device)
+    cur = torch.cuda.current_stream(idx)
+    if cur.cuda_stream != st.cuda_stream:
+        _home_streams[idx] = cur
     return st
 
 
