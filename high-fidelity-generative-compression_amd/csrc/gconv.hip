@@ -2227,8 +2227,8 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     auto pick_tps = [&](int bm_) -> int {
         if (!std::is_same<T, bf16_t>::value || env_int("HIFIC_NO_TPS", 0)) return 1;
         const int nwp = cdiv(bm_ * (BC * (int)sizeof(T) / 16), 256);
-        int cand = maxtaps >= 49 ? 7 : (maxtaps >= 16 ? 4 : ((small_grid && maxtaps >= 4) ? 4 : 1));
-        if (small_grid && maxtaps >= 25 && nwp * 7 <= 8) cand = 7;
+        // (7 taps per step on the 32-row 5x5 layers measured 190 vs 80 us with 4: not taken)
+        const int cand = maxtaps >= 49 ? 7 : (maxtaps >= 16 ? 4 : ((small_grid && maxtaps >= 4) ? 4 : 1));
         // ... and the weight ring must leave room for two co-resident workgroups (7 taps x 4.6 KB x 2 next to a 55 KB patch
         // put the 60->3 layer at one workgroup per CU: 640 -> 790 us)
         const int ring_cap = small_grid ? 96 * 1024 : 44 * 1024;
