@@ -90,6 +90,7 @@ class Model(nn.Module):
 
     def compression_forward(self, x):
         y = self.Encoder(x)
+        ops.wait_late_params()     # FusedAdam(overlap_from=...): everything after the Encoder was updated on the optimizer stream
         # the rate side of the hyperprior runs on the branch stream; its join is deferred to the first use of the rates
         hyperinfo = self.Hyperprior(y, spatial_shape=x.size()[2:], defer_rate_join=True)
         lat_gen, lat_disc = ops.fork(hyperinfo.decoded)
@@ -203,6 +204,7 @@ class Model(nn.Module):
         assert self.model_mode == ModelModes.EVALUATION and (self.training is False), \
             f'Set model mode to {ModelModes.EVALUATION} for compression.'
         spatial_shape = tuple(x.size()[2:])
+        ops.wait_late_params()
         with torch.no_grad():
             x = utils.pad_factor(x, x.size()[2:], 2 ** self.Encoder.n_downsampling_layers)
             y = self.Encoder(x.contiguous())
@@ -226,6 +228,7 @@ class Model(nn.Module):
         assert self.model_mode == ModelModes.EVALUATION and (self.training is False), \
             f'Set model mode to {ModelModes.EVALUATION} for decompression.'
         device = next(self.Generator.parameters()).device
+        ops.wait_late_params()
         with torch.no_grad():
             latents_decoded = self.Hyperprior.decompress_forward(compression_output, device=device)
             reconstruction = self._out_activation(self.Generator(latents_decoded.contiguous()))

@@ -132,9 +132,15 @@ class WeightPackCache:
             return
         dev = stale[0][1].buf.device
         cur = torch.cuda.current_stream(dev)
+        late = {k for k, e in stale if _is_late(e.weight())}
         for dt in (HIFIC_BF16, HIFIC_F32):
-            for kinds in ((0,), (1,)) if _PACK_STREAM_ON else ((0, 1),):
-                group = [(k, e) for k, e in stale if e.dtype == dt and e.kind in kinds]
+            # (late?, kinds): weights whose optimizer update is still running on the optimizer stream are packed there,
+            # right behind it - forward packs first, they are needed first
+            plans = [(False, (0,)), (False, (1,))] if _PACK_STREAM_ON else [(False, (0, 1))]
+            if late:
+                plans += [(True, (0,)), (True, (1,))]
+            for is_late, kinds in plans:
+                group = [(k, e) for k, e in stale if e.dtype == dt and e.kind in kinds and ((k in late) == is_late)]
                 if not group:
                     continue
                 sig = tuple(k for k, _ in group)
@@ -150,7 +156,10 @@ class WeightPackCache:
                     self.prepared[sig] = prep
                 jobs_dev, prefix_dev, tot, lds_b = prep
                 st = cur
-                if _PACK_STREAM_ON and kinds == (1,):
+                if is_late:
+                    st = opt_stream(dev)             # FIFO behind the optimizer tail that writes these weights
+                    jobs_dev.record_stream(st); prefix_dev.record_stream(st)
+                elif _PACK_STREAM_ON and kinds == (1,):
                     st = _pack_stream(dev)
                     st.wait_stream(cur)              # the weights were written (optimizer) on / before the current stream
                     jobs_dev.record_stream(st); prefix_dev.record_stream(st)
@@ -159,6 +168,52 @@ class WeightPackCache:
                 for _, e in group:
                     e.token = self._token(e.weight())
                     e.event, e.pack_sid, e.waited = ev, st.cuda_stream, set()
+
+
+# ---- optimizer tail on its own stream -----------------------------------------------------------------------------------
+# FusedAdam(overlap_from=k) updates the first k parameters (the Encoder: what the next forward pass needs first) on the
+# current stream and the rest - plus their weight re-packs, see refresh_stale - on this stream, so the next step's Encoder
+# forward overlaps with ~70 % of the (HBM-bound) optimizer + pack work.  The model orders itself after the tail with
+# wait_late_params() before it touches those parameters (hific_amd.Model: right after the Encoder).
+# Measured (round 2, batch 16 x 256^2): 26.0 -> 26.4 ms per GAN cycle, 16.8 -> 17.3 ms per compression step - the HBM-bound
+# optimizer / pack kernels slow the Encoder convolutions they run next to by more than they hide.  Opt-in.
+_OPT_STREAM_ON = os.environ.get("HIFIC_OPT_STREAM", "0") not in ("0", "")
+_opt_streams = {}
+_late_arenas = []
+
+
+def opt_stream_on():
+    return _OPT_STREAM_ON
+
+
+def opt_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _opt_streams.get(idx)
+    if st is None:
+        st = _opt_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
+def register_late(arena):
+    if arena not in _late_arenas:
+        _late_arenas.append(arena)
+
+
+def wait_late_params():
+    """Orders the current stream after every pending optimizer tail (no-op when there is none)."""
+    while _late_arenas:
+        a = _late_arenas.pop()
+        if a.late_event is not None:
+            torch.cuda.current_stream(a.flat.device).wait_event(a.late_event)
+            a.late_event = None
+
+
+def _is_late(weight):
+    sl = getattr(weight, "_hific_slot", None)
+    if sl is None:
+        return False
+    a = sl.arena
+    return getattr(a, "late_event", None) is not None and a.offsets[sl.index] >= a.late_start
 
 
 # measured (round 2): the HBM-bound re-pack on its own stream slows the forward pass it overlaps with more than it saves

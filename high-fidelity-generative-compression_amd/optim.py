@@ -54,6 +54,7 @@ class ParamArena:
         self.slots = []
         self.on_write = None
         self.epoch = 0          # bumped by every optimizer step over this arena (ops.WeightPackCache tokens)
+        self.late_start, self.late_event = 0, None      # element offset / completion event of a pending optimizer tail
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(params, offs)):
                 n = p.numel()
@@ -130,25 +131,49 @@ class ParamArena:
 class FusedAdam:
     """torch.optim.Adam semantics (amsgrad=False, weight_decay=0) over one ParamArena."""
 
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, device=None):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, device=None, overlap_from=None):
         self.arena = params if isinstance(params, ParamArena) else ParamArena(list(params), device)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.exp_avg = torch.zeros_like(self.arena.flat)
         self.exp_avg_sq = torch.zeros_like(self.arena.flat)
         self.step_count = 0
         self.grad_scale = 1.0
+        # number of leading parameters updated on the current stream; the rest go to ops.opt_stream() (None: all here).
+        # The caller must then use ops.wait_late_params() / synchronize() before touching the tail: hific_amd.Model does
+        self.overlap_from = overlap_from
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False,
                                   params=self.arena.params)]
 
     def step(self):
-        self.arena.rebind()
-        self.arena.zero_unwritten()
+        a = self.arena
+        a.rebind()
+        a.zero_unwritten()
         self.step_count += 1
         g = self.param_groups[0]
-        ops.adam_step(self.arena.flat, self.arena.flat_grad, self.exp_avg, self.exp_avg_sq,
-                      g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count, self.grad_scale)
-        self.arena.epoch += 1
+        hyper = (g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count, self.grad_scale)
+        off = 0
+        if self.overlap_from and ops.opt_stream_on() and a.flat.is_cuda and 0 < self.overlap_from < len(a.params):
+            off = a.offsets[self.overlap_from]
+        if off:
+            # head (what the next forward needs first) here, tail on the optimizer stream: see ops.opt_stream
+            ops.wait_late_params()                     # a previous tail nobody waited for
+            ops.adam_step(a.flat[:off], a.flat_grad[:off], self.exp_avg[:off], self.exp_avg_sq[:off], *hyper)
+            cur = torch.cuda.current_stream(a.flat.device)
+            st = ops.opt_stream(a.flat.device)
+            st.wait_stream(cur)                        # gradients (and the all-reduce) are complete on this stream
+            with torch.cuda.stream(st):
+                ops.adam_step(a.flat[off:], a.flat_grad[off:], self.exp_avg[off:], self.exp_avg_sq[off:], *hyper)
+            a.late_start, a.late_event = off, st.record_event()
+            ops.register_late(a)
+        else:
+            ops.adam_step(a.flat, a.flat_grad, self.exp_avg, self.exp_avg_sq, *hyper)
+        a.epoch += 1
         ops.note_weights_changed()
+
+    def synchronize(self):
+        """Orders the current stream after a pending optimizer tail (overlap_from): call before reading the parameters
+        from code that does not go through hific_amd.Model (checkpointing, evaluation with another module, ...)."""
+        ops.wait_late_params()
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
@@ -156,6 +181,7 @@ class FusedAdam:
     # ---- checkpointing in torch.optim.Adam's own format (the reference saves `*_optimizer_state_dict`, -------------
     # ---- utils.py:131-137, and restores them in load_model, utils.py:191-197) ---------------------------------------
     def state_dict(self):
+        ops.wait_late_params()
         state = {}
         if self.step_count > 0:
             for i, p in enumerate(self.arena.params):

@@ -50,6 +50,49 @@ def test_conv_adjoint_identities_full_size(hific, dev, name, dt, tol):
     assert float((y3.float() - 0.5 * y.detach().float()).abs().max()) <= tol * float(y.detach().float().abs().max()) + 1e-6
 
 
+def _two_steps_overlap(hific, dev, overlap):
+    """Two training steps (the second one uses weights and packs produced by the first optimizer step)."""
+    import hific_amd
+    from hific_amd import optim
+    from hific_amd.default_config import make_args, mse_lpips_args, ModelTypes
+    hific.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(5)
+    model = hific_amd.Model(make_args(mse_lpips_args, batch_size=8), model_type=ModelTypes.COMPRESSION,
+                            allow_random_lpips_backbone=True, device_rate_select=True).to(dev).train()
+    amort_params = [p for m in model.amortization_models for p in m.parameters()]
+    n_enc = len(list(model.Encoder.parameters()))
+    amort = optim.FusedAdam(amort_params, lr=1e-3, overlap_from=n_enc if overlap else None)
+    hyper = optim.FusedAdam(list(model.Hyperprior.hyperlatent_likelihood.parameters()), lr=1e-3)
+    g = torch.Generator(device=dev).manual_seed(6)
+    out = []
+    for it in range(2):
+        x = torch.rand((8, 3, 256, 256), generator=g, device=dev)
+        torch.manual_seed(7 + it)
+        losses = model(x, train_generator=True, writeout=False)
+        losses["compression"].backward()
+        out.append(float(losses["compression"]))
+        amort.step(); hyper.step(); amort.zero_grad(); hyper.zero_grad()
+    amort.synchronize()
+    torch.cuda.synchronize()
+    return out, amort.arena.flat.clone()
+
+
+def test_optimizer_tail_on_its_own_stream_is_bit_identical(hific, dev):
+    """FusedAdam(overlap_from=#Encoder parameters): Generator / hyper-net parameters and their re-packs are updated on the
+    optimizer stream under the next Encoder forward (model.py waits before it touches them).  Losses of both steps and
+    the final parameters must equal the single-stream run bit for bit."""
+    from hific_amd import ops
+    was = ops._OPT_STREAM_ON
+    ops._OPT_STREAM_ON = True               # opt-in feature (HIFIC_OPT_STREAM=1)
+    try:
+        l0, p0 = _two_steps_overlap(hific, dev, False)
+        l1, p1 = _two_steps_overlap(hific, dev, True)
+    finally:
+        ops._OPT_STREAM_ON = was
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1)
+
+
 def _one_step(hific, dev, dt, seed):
     import hific_amd
     from hific_amd import optim
