@@ -2933,7 +2933,25 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
     p.ntiles = p.tiles_n * p.tiles_y * p.tiles_x;
     const int base_blocks = (p.Mpad / 64) * (p.Cpad / 64) * p.ngroups;
     // enough (m,c,tap-group) tiles to fill the chip: no pixel split, epilogue writes the final layout directly
-    int nsplit = base_blocks >= env_int("HIFIC_WG_NOSPLIT", 160) ? 1 : cdiv(768, base_blocks);
+    int nsplit = 1;
+    if (base_blocks < env_int("HIFIC_WG_NOSPLIT", 160)) {
+        const int target = env_int("HIFIC_WG_TARGET", 0);
+        if (target > 0) {
+            nsplit = cdiv(target, base_blocks);
+        } else {
+            // Two workgroups co-reside per CU (512 slots): a launch of 746 workgroups runs as two rounds, the second one
+            // half empty (60<-120 stride 2: 227 us at 746 workgroups, 187 us at exactly 512).  Pick the split that
+            // minimises rounds x tiles per workgroup; every split also costs one partial tile of HBM traffic.
+            double best = 1e30;
+            const int nmax = p.ntiles < 4096 / base_blocks ? p.ntiles : 4096 / base_blocks;
+            for (int n = 1; n <= nmax; ++n) {
+                const int rounds = cdiv(base_blocks * n, 512);
+                const int tps_ = cdiv(p.ntiles, n);
+                const double cost = (double)rounds * tps_ + 0.02 * n;
+                if (cost < best - 1e-9) { best = cost; nsplit = n; }
+            }
+        }
+    }
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     if (nsplit < 1) nsplit = 1;
     p.tiles_per_split = cdiv(p.ntiles, nsplit);
