@@ -126,6 +126,42 @@ __global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, const T* __restri
     }
 }
 
+// 2x2 stride-2 max pooling (torchvision VGG16.features: nn.MaxPool2d(2, 2); LPIPS net='vgg') and its adjoint in gather
+// form: windows do not overlap, an input pixel receives its window's gradient iff it is the window's first maximum in
+// row-major order (torch semantics); rows / columns past 2*OH / 2*OW belong to no window.
+template <typename T>
+__global__ void maxpool2s2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long planes, int H, int W,
+                                      int OH, int OW) {
+    const long long total = planes * OH * OW;
+    EW_LOOP(i, total) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const long long pc = i / ((long long)OW * OH);
+        const T* xp = x + pc * H * W + (size_t)(oy * 2) * W + ox * 2;
+        const float a = DT<T>::ld(xp), b = DT<T>::ld(xp + 1), c = DT<T>::ld(xp + W), d = DT<T>::ld(xp + W + 1);
+        DT<T>::st(y + i, fmaxf(fmaxf(a, b), fmaxf(c, d)));
+    }
+}
+template <typename T>
+__global__ void maxpool2s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                      long long planes, int H, int W, int OH, int OW) {
+    const long long total = planes * H * W;
+    EW_LOOP(i, total) {
+        const int ix = (int)(i % W), iy = (int)((i / W) % H);
+        const long long pc = i / ((long long)W * H);
+        const int oy = iy >> 1, ox = ix >> 1;
+        float g = 0.f;
+        if (oy < OH && ox < OW) {
+            const T* xp = x + pc * H * W + (size_t)(oy * 2) * W + ox * 2;
+            const float v[4] = {DT<T>::ld(xp), DT<T>::ld(xp + 1), DT<T>::ld(xp + W), DT<T>::ld(xp + W + 1)};
+            int am = 0; float m = v[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; am = k; }
+            if (am == (iy & 1) * 2 + (ix & 1)) g = DT<T>::ld(dy + pc * OH * OW + (size_t)oy * OW + ox);
+        }
+        DT<T>::st(dx + i, g);
+    }
+}
+
 // ---- squared-error sum: part[b] = sum (s*a - s*b)^2 ; final = sum(part) -----------------------------
 template <typename TA>
 __global__ __launch_bounds__(256) void sqdiff_partial_kernel(const TA* __restrict__ a, const float* __restrict__ b,
@@ -407,6 +443,25 @@ int hific_maxpool3s2_fwd(const void* x, void* y, long long planes, int H, int W,
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(maxpool3s2_fwd_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)x, (float*)y, planes, H, W, OH, OW),
         hipLaunchKernelGGL(maxpool3s2_fwd_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, planes, H, W, OH, OW));
+    return hific_launch_status();
+}
+int hific_maxpool2s2_fwd(const void* x, void* y, long long planes, int H, int W, int dtype, hipStream_t st) {
+    if (H < 2 || W < 2 || planes < 0) return HIFIC_ERR_ARG;
+    const int OH = H / 2, OW = W / 2;
+    const long long total = planes * OH * OW;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(maxpool2s2_fwd_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)x, (float*)y, planes, H, W, OH, OW),
+        hipLaunchKernelGGL(maxpool2s2_fwd_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, planes, H, W, OH, OW));
+    return hific_launch_status();
+}
+int hific_maxpool2s2_bwd(const void* x, const void* dy, void* dx, long long planes, int H, int W, int dtype,
+                         hipStream_t st) {
+    if (H < 2 || W < 2 || planes < 0) return HIFIC_ERR_ARG;
+    const int OH = H / 2, OW = W / 2;
+    const long long total = planes * H * W;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(maxpool2s2_bwd_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, planes, H, W, OH, OW),
+        hipLaunchKernelGGL(maxpool2s2_bwd_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, planes, H, W, OH, OW));
     return hific_launch_status();
 }
 int hific_maxpool3s2_bwd(const void* x, const void* dy, void* dx, long long planes, int H, int W, int dtype,

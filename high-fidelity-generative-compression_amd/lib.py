@@ -39,6 +39,8 @@ SIGNATURES = {
     "hific_cast": (I, [P, I, P, I, L, P]),
     "hific_axpby_f32": (I, [P, P, P, F, F, L, P]),
     "hific_channel_sum": (I, [P, P, I, I, I, I, I, P, Z, P]),
+    "hific_maxpool2s2_fwd": (I, [P, P, L, I, I, I, P]),
+    "hific_maxpool2s2_bwd": (I, [P, P, P, L, I, I, I, P]),
     "hific_maxpool3s2_fwd": (I, [P, P, L, I, I, I, P]),
     "hific_maxpool3s2_bwd": (I, [P, P, P, L, I, I, I, P]),
     "hific_mse_fwd": (I, [P, P, P, L, F, I, P, Z, P]),

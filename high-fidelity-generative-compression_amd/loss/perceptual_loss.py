@@ -1,6 +1,6 @@
 """Drop-in for the reference's LPIPS perceptual loss as HiFIC uses it
 (src/loss/perceptual_similarity/perceptual_loss.py:13-46 -> dist_model.py:105-113 -> networks_basic.py:61-88,
-model='net-lin', net='alex', version 0.1, spatial=False).
+model='net-lin', net='alex' - or net='vgg', the reference's other documented backbone - version 0.1, spatial=False).
 
 PerceptualLoss.forward(pred, target, normalize) -> (N,1,1,1), differentiable w.r.t. `pred` only (the backbone is
 frozen and the target image carries no gradient on the HiFIC path, src/model.py:196-199).  The whole
@@ -24,10 +24,20 @@ from ..lib import call, ptr, stream
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-# (C_in, C_out, kernel, stride, pad, maxpool-after-relu) of torchvision AlexNet.features up to relu5
-ALEX_CFG = [(3, 64, 11, 4, 2, True), (64, 192, 5, 1, 2, True), (192, 384, 3, 1, 1, False),
-            (384, 256, 3, 1, 1, False), (256, 256, 3, 1, 1, False)]
-ALEX_FEATURE_IDX = [0, 3, 6, 8, 10]
+# Backbones (pretrained_networks.py:59-94 alexnet, :96-134 vgg16): per conv layer
+#   (C_in, C_out, kernel, stride, pad, max-pool after the ReLU ('3s2' | '2s2' | None), tapped by LPIPS?, index in
+#    torchvision's `features` Sequential)
+NETS = {
+    "alex": [(3, 64, 11, 4, 2, "3s2", True, 0), (64, 192, 5, 1, 2, "3s2", True, 3), (192, 384, 3, 1, 1, None, True, 6),
+             (384, 256, 3, 1, 1, None, True, 8), (256, 256, 3, 1, 1, None, True, 10)],
+    "vgg": [(3, 64, 3, 1, 1, None, False, 0), (64, 64, 3, 1, 1, "2s2", True, 2),
+            (64, 128, 3, 1, 1, None, False, 5), (128, 128, 3, 1, 1, "2s2", True, 7),
+            (128, 256, 3, 1, 1, None, False, 10), (256, 256, 3, 1, 1, None, False, 12), (256, 256, 3, 1, 1, "2s2", True, 14),
+            (256, 512, 3, 1, 1, None, False, 17), (512, 512, 3, 1, 1, None, False, 19), (512, 512, 3, 1, 1, "2s2", True, 21),
+            (512, 512, 3, 1, 1, None, False, 24), (512, 512, 3, 1, 1, None, False, 26), (512, 512, 3, 1, 1, None, True, 28)],
+}
+ALEX_CFG = [c[:5] + (c[5] is not None,) for c in NETS["alex"]]          # legacy names (tests, tools)
+ALEX_FEATURE_IDX = [c[7] for c in NETS["alex"]]
 
 
 def _conv_fwd(x, w, b, stride, pad, cd, out=None):
@@ -63,18 +73,31 @@ def _maxpool(x, out=None):
     return y
 
 
-def _alex_half(h, wb, cd, feats, lo, B):
-    """AlexNet.features on the B images `h`; the feature map of layer li goes to rows [lo, lo+B) of the 2B-image buffer
-    feats[li] (allocated here on first use).  Every output pixel is computed by the same instruction sequence whatever
-    the batch size, so filling the two halves separately gives the bits of one 2B pass."""
-    for li, (ci, co, k, s, p, pool) in enumerate(ALEX_CFG):
+def _pool(f, kind):
+    if kind == "3s2":
+        return _maxpool(f)
+    N, C, H, W = f.shape
+    y = torch.empty((N, C, H // 2, W // 2), dtype=f.dtype, device=f.device)
+    call("hific_maxpool2s2_fwd", ptr(f), ptr(y), N * C, H, W, lib.dtype_code(f), stream())
+    return y
+
+
+def _pooled_hw(kind, H, W):
+    return ((H - 3) // 2 + 1, (W - 3) // 2 + 1) if kind == "3s2" else (H // 2, W // 2)
+
+
+def _net_half(h, wb, cd, feats, lo, B, cfg):
+    """Backbone features on the B images `h`; the feature map of conv layer li goes to rows [lo, lo+B) of the 2B-image
+    buffer feats[li] (allocated here on first use).  Every output pixel is computed by the same instruction sequence
+    whatever the batch size, so filling the two halves separately gives the bits of one 2B pass."""
+    for li, (ci, co, k, s, p, pool, tap, idx) in enumerate(cfg):
         N, C, H, W = h.shape
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         if feats[li] is None:
             feats[li] = torch.empty((2 * B, co, OH, OW), dtype=h.dtype, device=h.device)
         f = feats[li][lo:lo + B]
         _conv_fwd(h, wb[2 * li], wb[2 * li + 1], s, p, cd, out=f)
-        h = _maxpool(f) if (pool and li < len(ALEX_CFG) - 1) else f
+        h = _pool(f, pool) if (pool and li < len(cfg) - 1) else f
 
 
 class TargetFeatures:
@@ -86,14 +109,15 @@ class TargetFeatures:
         self.key, self.feats, self.event = key, feats, event
 
 
-def _target_key(target, normalize, cd):
-    return (target.data_ptr(), target._version, tuple(target.shape), target.dtype, int(normalize), cd)
+def _target_key(target, normalize, cd, net="alex"):
+    return (target.data_ptr(), target._version, tuple(target.shape), target.dtype, int(normalize), cd, net)
 
 
 class LpipsFn(Function):
     @staticmethod
-    def forward(ctx, pred, target, normalize, lins, pre, *wb):
+    def forward(ctx, pred, target, normalize, lins, pre, net, *wb):
         lib.require_gpu(pred, target, *lins, *wb)
+        cfg = NETS[net]
         cdt = ops.get_compute_dtype()
         cd = lib.HIFIC_F32 if cdt == torch.float32 else lib.HIFIC_BF16
         B, _, H, W = pred.shape
@@ -103,63 +127,74 @@ class LpipsFn(Function):
              1 if pred.dtype == torch.float32 else 0, ptr(x), B, H * W, int(normalize), cd, stream())
         val = torch.empty(B, dtype=torch.float32, device=pred.device)
         ws = lib.workspace(pred.device)
-        if pre is not None and pre.key == _target_key(target, normalize, cd):
+        if pre is not None and pre.key == _target_key(target, normalize, cd, net):
             cur = torch.cuda.current_stream(pred.device)
             cur.wait_event(pre.event)
             feats = pre.feats
             for f in feats:
                 f.record_stream(cur)
-            _alex_half(x[B:], wb, cd, feats, B, B)               # generated-image half only
+            _net_half(x[B:], wb, cd, feats, B, B, cfg)           # generated-image half only
         else:
-            feats = [None] * len(ALEX_CFG)
+            feats = [None] * len(cfg)
             h = x
-            for li, (ci, co, k, s, p, pool) in enumerate(ALEX_CFG):
+            for li, (ci, co, k, s, p, pool, tap, idx) in enumerate(cfg):
                 feats[li] = _conv_fwd(h, wb[2 * li], wb[2 * li + 1], s, p, cd)
-                h = _maxpool(feats[li]) if (pool and li < len(ALEX_CFG) - 1) else feats[li]
-        for li, (ci, co, k, s, p, pool) in enumerate(ALEX_CFG):
+                h = _pool(feats[li], pool) if (pool and li < len(cfg) - 1) else feats[li]
+        ti = 0
+        for li, (ci, co, k, s, p, pool, tap, idx) in enumerate(cfg):
+            if not tap:
+                continue
             f = feats[li]
-            call("hific_lpips_tap_fwd", ptr(f), ptr(lins[li]), ptr(val), B, co, f.shape[2] * f.shape[3],
-                 0 if li == 0 else 1, cd, ws.data_ptr(), ws.numel(), stream())
+            call("hific_lpips_tap_fwd", ptr(f), ptr(lins[ti]), ptr(val), B, co, f.shape[2] * f.shape[3],
+                 0 if ti == 0 else 1, cd, ws.data_ptr(), ws.numel(), stream())
+            ti += 1
         ctx.normalize, ctx.cd, ctx.B, ctx.in_shape, ctx.pred_dtype = int(normalize), cd, B, (B, 3, H, W), pred.dtype
-        ctx.lins = lins
+        ctx.lins, ctx.net = lins, net
         ctx.save_for_backward(x, *feats, *wb)
         return val.view(B, 1, 1, 1)
 
     @staticmethod
     def backward(ctx, g):
+        cfg = NETS[ctx.net]
+        nl = len(cfg)
         saved = ctx.saved_tensors
-        x, feats, wb = saved[0], saved[1:6], saved[6:]
+        x, feats, wb = saved[0], saved[1:1 + nl], saved[1 + nl:]
         B, cd = ctx.B, ctx.cd
         gval = g.contiguous().view(B).float()
         grad = None                        # gradient w.r.t. feats[li][B:] (post-ReLU, gen half)
-        for li in reversed(range(5)):
-            ci, co, k, s, p, pool = ALEX_CFG[li]
+        ti = sum(1 for c in cfg if c[6]) - 1
+        for li in reversed(range(nl)):
+            ci, co, k, s, p, pool, tap, idx = cfg[li]
             f = feats[li]
             fgen = f[B:]
-            if grad is None:
-                grad = torch.empty_like(fgen)
-                acc = 0
-            else:
-                acc = 1
-            call("hific_lpips_tap_bwd", ptr(f), ptr(ctx.lins[li]), ptr(gval), ptr(grad), B, co,
-                 f.shape[2] * f.shape[3], acc, cd, stream())
+            if tap:
+                if grad is None:
+                    grad = torch.empty_like(fgen)
+                    acc = 0
+                else:
+                    acc = 1
+                call("hific_lpips_tap_bwd", ptr(f), ptr(ctx.lins[ti]), ptr(gval), ptr(grad), B, co,
+                     f.shape[2] * f.shape[3], acc, cd, stream())
+                ti -= 1
             dz = torch.empty_like(grad)
             call("hific_act_bwd", ptr(grad), ptr(fgen), ptr(dz), grad.numel(), 0.0, lib.dtype_code(grad), stream())
-            # input of conv li: pooled feats[li-1] (li in {1,2}), feats[li-1] (li in {3,4}), or the prepped image
+            # input of conv li: the pooled or plain feature map of layer li-1, or the prepped image
+            prev_pool = cfg[li - 1][5] if li > 0 else None
             if li == 0:
                 in_shape = (B,) + tuple(x.shape[1:])
             else:
                 prev = feats[li - 1]
-                if ALEX_CFG[li - 1][5]:
-                    in_shape = (B, prev.shape[1], (prev.shape[2] - 3) // 2 + 1, (prev.shape[3] - 3) // 2 + 1)
+                if prev_pool:
+                    in_shape = (B, prev.shape[1]) + _pooled_hw(prev_pool, prev.shape[2], prev.shape[3])
                 else:
                     in_shape = (B,) + tuple(prev.shape[1:])
             din = _conv_bwd_data(dz, wb[2 * li], in_shape, s, p, cd)
-            if li > 0 and ALEX_CFG[li - 1][5]:
+            if prev_pool:
                 prev_gen = feats[li - 1][B:]
                 dprev = torch.empty_like(prev_gen)
-                call("hific_maxpool3s2_bwd", ptr(prev_gen), ptr(din), ptr(dprev), B * prev_gen.shape[1],
-                     prev_gen.shape[2], prev_gen.shape[3], lib.dtype_code(prev_gen), stream())
+                call("hific_maxpool3s2_bwd" if prev_pool == "3s2" else "hific_maxpool2s2_bwd", ptr(prev_gen), ptr(din),
+                     ptr(dprev), B * prev_gen.shape[1], prev_gen.shape[2], prev_gen.shape[3], lib.dtype_code(prev_gen),
+                     stream())
                 grad = dprev
             else:
                 grad = din
@@ -167,7 +202,7 @@ class LpipsFn(Function):
         dpred = torch.empty(ctx.in_shape, dtype=ctx.pred_dtype, device=g.device)
         call("hific_lpips_prep_bwd", ptr(grad), ptr(dpred), B, ctx.in_shape[2] * ctx.in_shape[3],
              ctx.normalize, cd, 1 if ctx.pred_dtype == torch.float32 else 0, stream())
-        return (dpred, None, None, None, None) + (None,) * len(wb)
+        return (dpred, None, None, None, None, None) + (None,) * len(wb)
 
 
 class PerceptualLoss(nn.Module):
@@ -177,27 +212,31 @@ class PerceptualLoss(nn.Module):
     def __init__(self, model='net-lin', net='alex', colorspace='rgb', spatial=False, use_gpu=True, gpu_ids=[0],
                  version='0.1', backbone_seed=1234, backbone_state_dict=None, backbone_path=None,
                  allow_random_backbone=False):
-        """Backbone weights, in order of precedence: `backbone_state_dict` (torchvision alexnet keys), `backbone_path`
-        / $HIFIC_LPIPS_ALEX_WEIGHTS (a torch.save'd state_dict: torchvision's alexnet-owt-*.pth works as is).  With
-        neither, the backbone is a *seeded random* AlexNet - fine for benchmarks and parity tests
+        """net: 'alex' (what HiFIC uses, src/model.py:101) or 'vgg' (VGG16, networks_basic.py:36-38, taps relu1_2 ..
+        relu5_3).  Backbone weights, in order of precedence: `backbone_state_dict` (torchvision keys `features.N.*`),
+        `backbone_path` / $HIFIC_LPIPS_ALEX_WEIGHTS resp. $HIFIC_LPIPS_VGG_WEIGHTS (a torch.save'd state_dict:
+        torchvision's alexnet-owt-*.pth / vgg16-*.pth work as they are).  With
+        neither, the backbone is a *seeded random* network - fine for benchmarks and parity tests
         (`allow_random_backbone=True` says so explicitly), wrong for real training: a loud warning is issued."""
         super().__init__()
-        if model != 'net-lin' or net != 'alex' or colorspace != 'rgb' or spatial or version != '0.1':
-            raise NotImplementedError("hific_amd PerceptualLoss implements the configuration HiFIC uses: "
-                                      "model='net-lin', net='alex', colorspace='rgb', spatial=False, version='0.1'")
+        if model != 'net-lin' or net not in NETS or colorspace != 'rgb' or spatial or version != '0.1':
+            raise NotImplementedError("hific_amd PerceptualLoss implements model='net-lin', net='alex' (HiFIC's choice) or "
+                                      "'vgg', colorspace='rgb', spatial=False, version='0.1'")
+        self.net = net
+        cfg = NETS[net]
         self.use_gpu, self.gpu_ids, self.spatial = use_gpu, gpu_ids, spatial
         # backbone tensors in torchvision's `features.N.{weight,bias}` naming; frozen (requires_grad=False)
         gen = torch.Generator().manual_seed(backbone_seed)
         t = {}
-        for idx, (ci, co, k, s, p, _) in zip(ALEX_FEATURE_IDX, ALEX_CFG):
+        for (ci, co, k, s, p, _, _, idx) in cfg:
             bound = 1.0 / np.sqrt(ci * k * k)
             t[f"features.{idx}.weight"] = (torch.rand((co, ci, k, k), generator=gen) * 2 - 1) * bound
             t[f"features.{idx}.bias"] = (torch.rand((co,), generator=gen) * 2 - 1) * bound
-        lin = np.load(os.path.join(_HERE, "weights", "lpips_alex_lin_v0.1.npz"))
+        lin = np.load(os.path.join(_HERE, "weights", f"lpips_{net}_lin_v0.1.npz"))
         for i in range(5):
             t[f"lin{i}"] = torch.from_numpy(lin[f"lin{i}"].copy())
         object.__setattr__(self, "_t", t)          # plain dict: invisible to state_dict()/parameters()
-        backbone_path = backbone_path or os.environ.get("HIFIC_LPIPS_ALEX_WEIGHTS")
+        backbone_path = backbone_path or os.environ.get(f"HIFIC_LPIPS_{net.upper()}_WEIGHTS")
         self.backbone_source = "seeded-random"
         if backbone_state_dict is None and backbone_path:
             backbone_state_dict = torch.load(backbone_path, map_location="cpu")
@@ -209,10 +248,10 @@ class PerceptualLoss(nn.Module):
         elif not allow_random_backbone:
             import logging
             import warnings
-            msg = ("hific_amd PerceptualLoss: NO pretrained AlexNet weights given - the LPIPS backbone is a seeded "
-                   "RANDOM network (the reference downloads torchvision's ImageNet AlexNet, pretrained_networks.py:59). "
+            msg = (f"hific_amd PerceptualLoss: NO pretrained {net} weights given - the LPIPS backbone is a seeded "
+                   "RANDOM network (the reference downloads torchvision's ImageNet weights, pretrained_networks.py:59,99). "
                    "Training against it optimises a meaningless perceptual term. Pass backbone_path= / "
-                   "backbone_state_dict=, set $HIFIC_LPIPS_ALEX_WEIGHTS, or call load_backbone_state_dict(); "
+                   "backbone_state_dict=, set $HIFIC_LPIPS_ALEX_WEIGHTS / $HIFIC_LPIPS_VGG_WEIGHTS, or call load_backbone_state_dict(); "
                    "allow_random_backbone=True silences this for benchmarks and tests.")
             warnings.warn(msg, RuntimeWarning, stacklevel=2)
             logging.getLogger("hific_amd").warning(msg)
@@ -233,10 +272,10 @@ class PerceptualLoss(nn.Module):
         return super().__getattr__(name)
 
     def load_backbone_state_dict(self, sd):
-        """Accepts torchvision alexnet keys (`features.N.weight`) or bare `N.weight`."""
+        """Accepts torchvision keys (`features.N.weight`) or bare `N.weight`."""
         self.backbone_source = "state_dict"
         with torch.no_grad():
-            for idx in ALEX_FEATURE_IDX:
+            for idx in [c[7] for c in NETS[self.net]]:
                 for nm in ("weight", "bias"):
                     key = f"features.{idx}.{nm}" if f"features.{idx}.{nm}" in sd else f"{idx}.{nm}"
                     dst = self._t[f"features.{idx}.{nm}"]
@@ -247,10 +286,10 @@ class PerceptualLoss(nn.Module):
             raise NotImplementedError("gradient w.r.t. the LPIPS target image is not implemented (not on the HiFIC path)")
         lins = tuple(self._t[f"lin{i}"] for i in range(5))
         wb = []
-        for idx in ALEX_FEATURE_IDX:
+        for idx in [c[7] for c in NETS[self.net]]:
             wb += [self._t[f"features.{idx}.weight"], self._t[f"features.{idx}.bias"]]
         pre = self.__dict__.pop("_prefetched", None)
-        return LpipsFn.apply(pred.contiguous(), target.contiguous(), normalize, lins, pre, *wb)
+        return LpipsFn.apply(pred.contiguous(), target.contiguous(), normalize, lins, pre, self.net, *wb)
 
     def prefetch_target(self, target, normalize=False):
         """Computes the target-image half of the feature maps now, on the current stream, for the next forward() with this
@@ -260,14 +299,15 @@ class PerceptualLoss(nn.Module):
         target = target.contiguous()
         lib.require_gpu(target)
         wb = []
-        for idx in ALEX_FEATURE_IDX:
+        cfg = NETS[self.net]
+        for idx in [c[7] for c in cfg]:
             wb += [self._t[f"features.{idx}.weight"], self._t[f"features.{idx}.bias"]]
         B, _, H, W = target.shape
         with torch.no_grad():
             xt = torch.empty((2 * B, 3, H, W), dtype=cdt, device=target.device)
             tf = 1 if target.dtype == torch.float32 else 0
             call("hific_lpips_prep", ptr(target), tf, ptr(target), tf, ptr(xt), B, H * W, int(normalize), cd, stream())
-            feats = [None] * len(ALEX_CFG)
-            _alex_half(xt[:B], wb, cd, feats, 0, B)
+            feats = [None] * len(cfg)
+            _net_half(xt[:B], wb, cd, feats, 0, B, cfg)
         ev = torch.cuda.current_stream(target.device).record_event()
-        self.__dict__["_prefetched"] = TargetFeatures(_target_key(target, normalize, cd), feats, ev)
+        self.__dict__["_prefetched"] = TargetFeatures(_target_key(target, normalize, cd, self.net), feats, ev)

@@ -29,9 +29,10 @@ Disc_out = namedtuple("disc_out", ["D_real", "D_gen", "D_real_logits", "D_gen_lo
 class Model(nn.Module):
     def __init__(self, args, logger=None, storage_train=None, storage_test=None, model_mode=ModelModes.TRAINING,
                  model_type=ModelTypes.COMPRESSION, device_rate_select=False, lpips_backbone=None,
-                 allow_random_lpips_backbone=False, build_tables=True):
+                 allow_random_lpips_backbone=False, build_tables=True, lpips_net=None):
         """`lpips_backbone`: path or state_dict of torchvision's pretrained AlexNet (also `args.lpips_backbone`,
-        $HIFIC_LPIPS_ALEX_WEIGHTS); without it PerceptualLoss warns loudly (see loss/perceptual_loss.py)."""
+        $HIFIC_LPIPS_ALEX_WEIGHTS); without it PerceptualLoss warns loudly (see loss/perceptual_loss.py).
+        `lpips_net`: 'alex' (the reference's hard-wired choice, src/model.py:101; default) or 'vgg' (also `args.lpips_net`)."""
         super().__init__()
         self.args, self.logger = args, logger
         self.model_mode, self.model_type = model_mode, model_type
@@ -66,7 +67,8 @@ class Model(nn.Module):
         # LPIPS tensors are unregistered (not in the state_dict, like the reference's DistModel) but follow .to()
         bb = lpips_backbone if lpips_backbone is not None else getattr(args, 'lpips_backbone', None)
         self.perceptual_loss = ps.PerceptualLoss(
-            model='net-lin', net='alex', use_gpu=False, allow_random_backbone=allow_random_lpips_backbone,
+            model='net-lin', net=lpips_net or getattr(args, 'lpips_net', None) or 'alex', use_gpu=False,
+            allow_random_backbone=allow_random_lpips_backbone,
             backbone_path=bb if isinstance(bb, str) else None,
             backbone_state_dict=bb if isinstance(bb, dict) else None)
 

@@ -95,6 +95,11 @@ int hific_axpby_f32(const float* a, const float* b, float* o, float alpha, float
 int hific_channel_sum(const void* x, float* out, int N, int C, int HW, int accumulate, int dtype, void* ws,
                       size_t ws_bytes, hipStream_t stream);
 /* nn.MaxPool2d(3, 2) of torchvision AlexNet (pretrained_networks.py:59) */
+/* nn.MaxPool2d(2, 2) of torchvision VGG16.features (LPIPS net='vgg', pretrained_networks.py:96-134): y [planes, H/2, W/2];
+ * backward routes each window's gradient to its first maximum (torch semantics). */
+int hific_maxpool2s2_fwd(const void* x, void* y, long long planes, int H, int W, int dtype, hipStream_t stream);
+int hific_maxpool2s2_bwd(const void* x, const void* dy, void* dx, long long planes, int H, int W, int dtype,
+                         hipStream_t stream);
 int hific_maxpool3s2_fwd(const void* x, void* y, long long planes, int H, int W, int dtype, hipStream_t stream);
 int hific_maxpool3s2_bwd(const void* x, const void* dy, void* dx, long long planes, int H, int W, int dtype,
                          hipStream_t stream);

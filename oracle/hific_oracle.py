@@ -210,15 +210,37 @@ def alexnet_taps(backbone, x):
     return taps
 
 
-def lpips_forward(backbone, lins, pred, target, normalize=True):
+# torchvision VGG16.features (pretrained_networks.py:96-134): conv index in the Sequential -> (C_in, C_out), 2x2 max pool
+# BEFORE the convs at 5, 10, 17, 24; LPIPS taps relu1_2, relu2_2, relu3_3, relu4_3, relu5_3 = the ReLUs after convs 2, 7,
+# 14, 21, 28
+VGG_CONVS = [(0, 3, 64), (2, 64, 64), (5, 64, 128), (7, 128, 128), (10, 128, 256), (12, 256, 256), (14, 256, 256),
+             (17, 256, 512), (19, 512, 512), (21, 512, 512), (24, 512, 512), (26, 512, 512), (28, 512, 512)]
+VGG_POOL_BEFORE = (5, 10, 17, 24)
+VGG_TAPS = (2, 7, 14, 21, 28)
+
+
+def vgg16_taps(backbone, x):
+    taps = []
+    h = x
+    for idx, ci, co in VGG_CONVS:
+        if idx in VGG_POOL_BEFORE:
+            h = F.max_pool2d(h, kernel_size=2, stride=2)
+        h = F.relu(F.conv2d(h, backbone[f"features.{idx}.weight"], backbone[f"features.{idx}.bias"], stride=1, padding=1))
+        if idx in VGG_TAPS:
+            taps.append(h)
+    return taps
+
+
+def lpips_forward(backbone, lins, pred, target, normalize=True, net="alex"):
     """perceptual_loss.py:26-46 + networks_basic.py:61-108: returns (N,1,1,1).  in0 = target, in1 = pred."""
     if normalize:
         target = 2 * target - 1
         pred = 2 * pred - 1
     shift = torch.tensor(LPIPS_SHIFT, dtype=pred.dtype).view(1, 3, 1, 1)
     scale = torch.tensor(LPIPS_SCALE, dtype=pred.dtype).view(1, 3, 1, 1)
-    t0 = alexnet_taps(backbone, (target - shift) / scale)
-    t1 = alexnet_taps(backbone, (pred - shift) / scale)
+    taps_fn = alexnet_taps if net == "alex" else vgg16_taps
+    t0 = taps_fn(backbone, (target - shift) / scale)
+    t1 = taps_fn(backbone, (pred - shift) / scale)
     val = 0
     for k in range(5):
         f0 = t0[k] / torch.sqrt(torch.sum(t0[k] ** 2, dim=1, keepdim=True) + 1e-10)
@@ -391,6 +413,16 @@ def make_alex_backbone(seed=1234, dtype=torch.float32):
         bound = 1.0 / math.sqrt(ci * k * k)
         sd[f"features.{idx}.weight"] = ((torch.rand((co, ci, k, k), generator=g) * 2 - 1) * bound).to(dtype)
         sd[f"features.{idx}.bias"] = ((torch.rand((co,), generator=g) * 2 - 1) * bound).to(dtype)
+    return sd
+
+
+def make_vgg_backbone(seed=4321, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for idx, ci, co in VGG_CONVS:
+        bound = math.sqrt(6.0 / (ci * 9))                 # keeps activations alive through 13 ReLU layers
+        sd[f"features.{idx}.weight"] = ((torch.rand((co, ci, 3, 3), generator=g) * 2 - 1) * bound).to(dtype)
+        sd[f"features.{idx}.bias"] = ((torch.rand((co,), generator=g) * 2 - 1) * 0.05).to(dtype)
     return sd
 
 

@@ -58,11 +58,26 @@ def _install_shims():
         def alexnet(pretrained=False, **kw):
             return _AlexNet()
 
+        class _VGG16(nn.Module):
+            def __init__(self):
+                super().__init__()
+                layers, c = [], 3
+                for v in (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"):
+                    if v == "M":
+                        layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                    else:
+                        layers += [nn.Conv2d(c, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                        c = v
+                self.features = nn.Sequential(*layers)
+
+        def vgg16(pretrained=False, **kw):
+            return _VGG16()
+
         def _unavailable(*a, **k):
-            raise RuntimeError("torchvision shim: only alexnet() is provided")
+            raise RuntimeError("torchvision shim: only alexnet() and vgg16() are provided")
 
         models.alexnet = alexnet
-        models.vgg16 = _unavailable
+        models.vgg16 = vgg16
         models.squeezenet1_1 = _unavailable
         models.resnet18 = models.resnet34 = models.resnet50 = models.resnet101 = models.resnet152 = _unavailable
         utils.save_image = _unavailable
@@ -142,9 +157,11 @@ def build_reference_model(ns, gan=False, training=True, log_dir="/tmp/hific_ref_
 
 
 def set_lpips_backbone(ref_model, backbone_sd):
-    """Load the seeded AlexNet backbone (oracle.make_alex_backbone) into the reference's LPIPS net."""
+    """Load a seeded backbone (oracle.make_alex_backbone / make_vgg_backbone) into the reference's LPIPS net;
+    `ref_model` is the reference Model or a reference PerceptualLoss."""
     import torch
-    net = ref_model.perceptual_loss.model.net   # PNetLin
+    pl = getattr(ref_model, "perceptual_loss", ref_model)
+    net = pl.model.net   # PNetLin
     feats = {}
     for sl in (net.net.slice1, net.net.slice2, net.net.slice3, net.net.slice4, net.net.slice5):
         for name, mod in sl.named_children():
@@ -156,5 +173,5 @@ def set_lpips_backbone(ref_model, backbone_sd):
 
 
 def reference_lins(ref_model):
-    net = ref_model.perceptual_loss.model.net
+    net = getattr(ref_model, "perceptual_loss", ref_model).model.net
     return [l.model[-1].weight.detach().reshape(-1).clone() for l in net.lins]

@@ -195,6 +195,56 @@ def test_maxpool_fwd_bwd(hific, dev, dt):
     assert _relerr(dx.float().cpu(), xr.grad) < (1e-6 if dt == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("hw", [(16, 32), (15, 31)], ids=["even", "odd"])
+def test_maxpool2s2_fwd_bwd(hific, dev, dt, hw):
+    """nn.MaxPool2d(2, 2) of VGG16.features: values exact, gradient to the first maximum of a window (ties included:
+    post-ReLU maps are full of equal zeros), nothing to the uncovered last row / column of odd planes."""
+    from hific_amd import lib
+    H, W = hw
+    x = F.relu(_rnd((2, 5, H, W), 1))
+    x = x.to(dt).float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    gy = _rnd(tuple(yr.shape), 2).to(dt).float()
+    yr.backward(gy)
+    xd = x.to(dev).to(dt)
+    y = torch.empty(yr.shape, dtype=dt, device=dev)
+    lib.call("hific_maxpool2s2_fwd", xd.data_ptr(), y.data_ptr(), 10, H, W, lib.dtype_code(xd), lib.stream())
+    dx = torch.empty_like(xd)
+    gyd = gy.to(dev).to(dt)
+    lib.call("hific_maxpool2s2_bwd", xd.data_ptr(), gyd.data_ptr(), dx.data_ptr(), 10, H, W, lib.dtype_code(xd),
+             lib.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y.float().cpu(), yr.detach())
+    assert torch.equal(dx.float().cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 5e-2)], ids=["f32", "bf16"])
+def test_lpips_vgg_forward_backward(hific, dev, dt, tol):
+    """PerceptualLoss(net='vgg') (networks_basic.py:36-38): value and gradient vs the oracle (which is pinned to the
+    reference's VGG variant in tests/test_oracle_vs_reference.py::test_lpips_vgg_variant)."""
+    from hific_amd.loss.perceptual_loss import PerceptualLoss
+    hific.set_compute_dtype(dt)
+    B, H = 2, 64
+    bb = O.make_vgg_backbone()
+    pl = PerceptualLoss(net='vgg', allow_random_backbone=True).to(dev)
+    pl.load_backbone_state_dict(bb)
+    lins = [getattr(pl, f"lin{i}").cpu() for i in range(5)]
+    target = O.make_image(3, B, H, H)
+    pred = (target + 0.1 * _rnd((B, 3, H, H), 5)).clamp(0, 1)
+    pr = pred.clone().requires_grad_(True)
+    vr = O.lpips_forward(bb, lins, pr, target, normalize=True, net="vgg")
+    vr.mean().backward()
+    pd = pred.to(dev).to(dt).requires_grad_(True)
+    v = pl(pd, target.to(dev), normalize=True)
+    v.mean().backward()
+    torch.cuda.synchronize()
+    assert v.shape == (B, 1, 1, 1)
+    assert _relerr(v.detach().cpu(), vr.detach()) < tol
+    assert _relerr(pd.grad.float().cpu(), pr.grad) < max(tol * 5, 1e-3)
+
+
 def test_mse_and_bce(hific, dev):
     from hific_amd import ops
     a = _rnd((2, 3, 32, 32), 1, 0, 1)
