@@ -162,6 +162,20 @@ __global__ void maxpool2s2_bwd_kernel(const T* __restrict__ x, const T* __restri
     }
 }
 
+// ---- tanh output activation and the [-1,1] -> [0,1] map of `normalize_input_image` (src/model.py:155-156, 206-209) ----
+template <typename T>
+__global__ void tanh_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {
+    EW_LOOP(i, n) DT<T>::st(y + i, tanhf(DT<T>::ld(x + i)));
+}
+template <typename T>
+__global__ void tanh_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, long long n) {
+    EW_LOOP(i, n) { const float t = DT<T>::ld(y + i); DT<T>::st(dx + i, DT<T>::ld(dy + i) * (1.f - t * t)); }
+}
+template <typename T>
+__global__ void scale_shift_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float a, float b) {
+    EW_LOOP(i, n) DT<T>::st(y + i, a * DT<T>::ld(x + i) + b);
+}
+
 // ---- squared-error sum: part[b] = sum (s*a - s*b)^2 ; final = sum(part) -----------------------------
 template <typename TA>
 __global__ __launch_bounds__(256) void sqdiff_partial_kernel(const TA* __restrict__ a, const float* __restrict__ b,
@@ -394,6 +408,25 @@ int hific_act_bwd(const void* dy, const void* y, void* dx, long long n, float sl
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(act_bwd_kernel<float>, EW_GRID(n), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n, slope),
         hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, EW_GRID(n), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n, slope));
+    return hific_launch_status();
+}
+
+int hific_tanh_fwd(const void* x, void* y, long long n, int dtype, hipStream_t st) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(tanh_fwd_kernel<float>, EW_GRID(n), dim3(256), 0, st, (const float*)x, (float*)y, n),
+        hipLaunchKernelGGL(tanh_fwd_kernel<bf16_t>, EW_GRID(n), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n));
+    return hific_launch_status();
+}
+int hific_tanh_bwd(const void* y, const void* dy, void* dx, long long n, int dtype, hipStream_t st) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(tanh_bwd_kernel<float>, EW_GRID(n), dim3(256), 0, st, (const float*)y, (const float*)dy, (float*)dx, n),
+        hipLaunchKernelGGL(tanh_bwd_kernel<bf16_t>, EW_GRID(n), dim3(256), 0, st, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, n));
+    return hific_launch_status();
+}
+int hific_scale_shift(const void* x, void* y, long long n, float a, float b, int dtype, hipStream_t st) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(scale_shift_kernel<float>, EW_GRID(n), dim3(256), 0, st, (const float*)x, (float*)y, n, a, b),
+        hipLaunchKernelGGL(scale_shift_kernel<bf16_t>, EW_GRID(n), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n, a, b));
     return hific_launch_status();
 }
 

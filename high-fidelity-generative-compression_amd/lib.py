@@ -35,6 +35,9 @@ SIGNATURES = {
     "hific_channelnorm_bwd_ws_bytes": (Z, [I, I, I]),
     "hific_channelnorm_bwd": (I, [P] * 9 + [I, I, I, I, I, I, P, Z, P]),
     "hific_act_bwd": (I, [P, P, P, L, F, I, P]),
+    "hific_tanh_fwd": (I, [P, P, L, I, P]),
+    "hific_tanh_bwd": (I, [P, P, P, L, I, P]),
+    "hific_scale_shift": (I, [P, P, L, F, F, I, P]),
     "hific_add": (I, [P, P, P, L, I, P]),
     "hific_cast": (I, [P, I, P, I, L, P]),
     "hific_axpby_f32": (I, [P, P, P, F, F, L, P]),

@@ -86,8 +86,8 @@ class Model(nn.Module):
 
     # ---- forward pieces -----------------------------------------------------------------------------------------
     def _out_activation(self, reconstruction):
-        if self.args.normalize_input_image is True:
-            raise NotImplementedError("normalize_input_image=True (tanh output) is off in the reference defaults")
+        if self.args.normalize_input_image is True:          # model.py:155-156 (off in the shipped configs)
+            return ops.tanh(reconstruction)
         return reconstruction
 
     def compression_forward(self, x):
@@ -121,7 +121,11 @@ class Model(nn.Module):
 
     def compression_loss(self, intermediates, hyperinfo):
         x_real = intermediates.input_image
-        x_gen_mse, x_gen_lpips = ops.fork(intermediates.reconstruction)
+        x_gen = intermediates.reconstruction
+        if self.args.normalize_input_image is True:          # [-1,1] -> [0,1] (model.py:206-209)
+            x_real = ops.scale_shift(x_real, 0.5, 0.5)
+            x_gen = ops.scale_shift(x_gen, 0.5, 0.5)
+        x_gen_mse, x_gen_lpips = ops.fork(x_gen)
         distortion = self.distortion_loss(x_gen_mse, x_real)
         perceptual = self.perceptual_loss_wrapper(x_gen_lpips, x_real, normalize=True)
         w_dist, w_perc = self.args.k_M * distortion, self.args.k_P * perceptual
@@ -167,7 +171,10 @@ class Model(nn.Module):
             torch.cuda.current_stream(x.device).wait_stream(ops.branch_stream(x.device))
         if self.model_mode == ModelModes.EVALUATION:
             # model.py:357-366: no losses, the clamped reconstruction and the quantised rate
-            return torch.clamp(intermediates.reconstruction.float(), min=0., max=1.), intermediates.q_bpp
+            rec = intermediates.reconstruction
+            if self.args.normalize_input_image is True:      # model.py:361-363
+                rec = ops.scale_shift(rec, 0.5, 0.5)
+            return torch.clamp(rec.float(), min=0., max=1.), intermediates.q_bpp
         out = dict()
         inter_c = inter_d = intermediates
         if self.use_discriminator:
@@ -235,4 +242,7 @@ class Model(nn.Module):
             latents_decoded = self.Hyperprior.decompress_forward(compression_output, device=device)
             reconstruction = self._out_activation(self.Generator(latents_decoded.contiguous()))
             H, W = compression_output.spatial_shape
-            return torch.clamp(reconstruction[:, :, :H, :W].float(), min=0., max=1.)
+            reconstruction = reconstruction[:, :, :H, :W]
+            if self.args.normalize_input_image is True:      # model.py:338-340
+                reconstruction = ops.scale_shift(reconstruction.contiguous(), 0.5, 0.5)
+            return torch.clamp(reconstruction.float(), min=0., max=1.)

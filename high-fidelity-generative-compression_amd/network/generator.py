@@ -1,6 +1,7 @@
 """Drop-in for the reference's src/network/generator.py (ResidualBlock, Generator): same constructors, child names
 (`conv_block_init.{0,2,3}`, `resblock_{m}.{conv1,conv2,norm1,norm2}`, `upconv_block{1-4}.{0,1}`,
 `conv_block_out.1`) and state_dict layout; forward on the gfx950 kernels."""
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -43,8 +44,6 @@ class Generator(nn.Module):
         super().__init__()
         if activation != 'relu':
             raise NotImplementedError("hific_amd Generator: only activation='relu' has a kernel")
-        if sample_noise:
-            raise NotImplementedError("sample_noise=True is off in every reference config (default_config.py:52,112)")
         kernel_dim = 3
         filters = [960, 480, 240, 120, 60]
         self.n_residual_blocks = n_residual_blocks
@@ -60,6 +59,8 @@ class Generator(nn.Module):
             HipConv2d(C, filters[0], (3, 3), stride=1, pads=(1, 1, 1, 1), pad_mode="reflect"),
             norm(filters[0]),
         )
+        if sample_noise is True:
+            filters[0] += self.noise_dim            # noise is concatenated to the head (generator.py:105-107, 149-152)
         for m in range(n_residual_blocks):
             self.add_module(f'resblock_{m}', ResidualBlock(input_dims=(batch_size, filters[0], H0, W0),
                                                            channel_norm=channel_norm, activation=activation))
@@ -74,8 +75,16 @@ class Generator(nn.Module):
             HipConv2d(filters[-1], 3, (7, 7), stride=1, pads=(3, 3, 3, 3), pad_mode="reflect"),
         )
 
+    def _draw_noise(self, shape):
+        return torch.randn(shape)
+
     def forward(self, x):
         head = self.conv_block_init(x)
+        if self.sample_noise is True:
+            # same draw as the reference: host RNG, then moved to the head's device / dtype (generator.py:149-152)
+            B, C, H, W = tuple(head.size())
+            z = self._draw_noise((B, self.noise_dim, H, W)).to(head)
+            head = torch.cat((head, z), dim=1)
         head_res, head_skip = ops.fork(head)
         x = head_res
         for m in range(self.n_residual_blocks):

@@ -605,6 +605,55 @@ def add(a, b):
     return AddFn.apply(a.contiguous(), b.contiguous())
 
 
+class TanhFn(Function):
+    """tanh on the reconstruction (`normalize_input_image`, src/model.py:155-156)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        require_gpu(x)
+        y = torch.empty_like(x)
+        call("hific_tanh_fwd", ptr(x), ptr(y), x.numel(), lib.dtype_code(x), stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        if g.dtype != y.dtype:
+            g = cast(g, y.dtype)
+        dx = torch.empty_like(y)
+        call("hific_tanh_bwd", ptr(y), ptr(g), ptr(dx), y.numel(), lib.dtype_code(y), stream())
+        return dx
+
+
+class ScaleShiftFn(Function):
+    """a * x + b (the [-1,1] -> [0,1] map of src/model.py:206-209)."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        require_gpu(x)
+        y = torch.empty_like(x)
+        call("hific_scale_shift", ptr(x), ptr(y), x.numel(), float(a), float(b), lib.dtype_code(x), stream())
+        ctx.a = float(a)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        call("hific_scale_shift", ptr(g), ptr(dx), g.numel(), ctx.a, 0.0, lib.dtype_code(g), stream())
+        return dx, None, None
+
+
+def tanh(x):
+    return TanhFn.apply(x.contiguous())
+
+
+def scale_shift(x, a, b):
+    return ScaleShiftFn.apply(x.contiguous(), a, b)
+
+
 class ForkFn(Function):
     """Explicit fan-out: returns two aliases of x; backward sums the two incoming gradients with the HIP add kernel
     (instead of leaving the accumulation to the autograd engine's ATen add)."""

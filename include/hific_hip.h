@@ -86,6 +86,11 @@ int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, con
 /* ---- elementwise / reductions (csrc/elementwise.hip) -------------------------------------------------------- */
 /* dx = y>0 ? dy : slope*dy — backward of F.relu (src/network/hyper.py:59-60,91-92) / LeakyReLU */
 int hific_act_bwd(const void* dy, const void* y, void* dx, long long n, float slope, int dtype, hipStream_t stream);
+/* `normalize_input_image` option (src/model.py:155-156 tanh on the reconstruction; :206-209, :338-340, :361-363 the
+ * [-1,1] -> [0,1] map): y = tanh(x); dx = dy (1 - y^2); y = a x + b. */
+int hific_tanh_fwd(const void* x, void* y, long long n, int dtype, hipStream_t stream);
+int hific_tanh_bwd(const void* y, const void* dy, void* dx, long long n, int dtype, hipStream_t stream);
+int hific_scale_shift(const void* x, void* y, long long n, float a, float b, int dtype, hipStream_t stream);
 /* residual adds: src/network/generator.py:44,161; also gradient fan-in sums */
 int hific_add(const void* a, const void* b, void* o, long long n, int dtype, hipStream_t stream);
 int hific_cast(const void* a, int src_dtype, void* o, int dst_dtype, long long n, hipStream_t stream);

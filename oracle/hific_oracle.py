@@ -86,12 +86,15 @@ def residual_block_forward(sd, x, prefix):
     return r + x
 
 
-def generator_forward(sd, y, n_residual_blocks=9, prefix="Generator."):
-    """src/network/generator.py:98-103,145-168."""
+def generator_forward(sd, y, n_residual_blocks=9, prefix="Generator.", noise=None):
+    """src/network/generator.py:98-103,145-168.  `noise` (B, noise_dim, H, W): the sample_noise=True variant, whose
+    draw is concatenated to the head (:149-152)."""
     p = prefix
     h = channel_norm(y, sd[p + "conv_block_init.0.gamma"], sd[p + "conv_block_init.0.beta"])
     h = F.conv2d(reflect_pad(h, 1, 1, 1, 1), sd[p + "conv_block_init.2.weight"], sd[p + "conv_block_init.2.bias"])
     head = channel_norm(h, sd[p + "conv_block_init.3.gamma"], sd[p + "conv_block_init.3.beta"])
+    if noise is not None:
+        head = torch.cat((head, noise.to(head)), dim=1)
     h = head
     for m in range(n_residual_blocks):
         h = residual_block_forward(sd, h, p + f"resblock_{m}.")
@@ -305,8 +308,12 @@ def model_forward(sd, backbone, lins, x, step_counter=1, training=True, gan=Fals
     y = encoder_forward(sd, x)
     hi = hyperprior_forward(sd, y, x.shape[2:], training, noise_hyper, noise_latent)
     x_gen = generator_forward(sd, hi.decoded, n_residual_blocks)
-    distortion = torch.mean((x_gen * 255. - x * 255.) ** 2)                       # model.py:190-194
-    perceptual = torch.mean(lpips_forward(backbone, lins, x_gen, x, normalize=True))   # model.py:196-199
+    x_l, xg_l = x, x_gen
+    if a.get("normalize_input_image", False):                                     # model.py:155-156, 206-209
+        x_gen = torch.tanh(x_gen)
+        x_l, xg_l = (x + 1.) / 2., (x_gen + 1.) / 2.
+    distortion = torch.mean((xg_l * 255. - x_l * 255.) ** 2)                      # model.py:190-194
+    perceptual = torch.mean(lpips_forward(backbone, lins, xg_l, x_l, normalize=True))   # model.py:196-199
     lam_A = get_scheduled_params(a["lambda_A"], a["lambda_schedule"], step_counter, a["ignore_schedule"])
     lam_B = get_scheduled_params(a["lambda_B"], a["lambda_schedule"], step_counter, a["ignore_schedule"])
     target = get_scheduled_params(a["target_rate"], a["target_schedule"], step_counter, a["ignore_schedule"])

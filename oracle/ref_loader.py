@@ -140,7 +140,7 @@ def load(root=None):
     return ns
 
 
-def build_reference_model(ns, gan=False, training=True, log_dir="/tmp/hific_ref_logs"):
+def build_reference_model(ns, gan=False, training=True, log_dir="/tmp/hific_ref_logs", **overrides):
     """Reference src.model.Model on CPU (TRAINING mode), with a throw-away logger."""
     import logging
     cfg = ns.default_config
@@ -148,6 +148,7 @@ def build_reference_model(ns, gan=False, training=True, log_dir="/tmp/hific_ref_
     d = {}
     for klass in reversed(base.__mro__):
         d.update({k: v for k, v in vars(klass).items() if not k.startswith("__")})
+    d.update(overrides)
     args = ns.utils.Struct(**d)
     logger = logging.getLogger("hific_ref")
     mtype = cfg.ModelTypes.COMPRESSION_GAN if gan else cfg.ModelTypes.COMPRESSION

@@ -314,3 +314,65 @@ def test_branch_streams_equal_single_stream(hific, dev, sd):
         ops.set_branch_streams(was[0]); ops.set_side_stream(was[1])
     assert a[0] == b[0] and a[1] == b[1]
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+def test_generator_sample_noise_variant(hific, dev):
+    """Generator(sample_noise=True) (generator.py:105-107, 149-152: 32 noise channels concatenated to the head, 992-channel
+    residual blocks): forward and input gradient vs the oracle with the same draw."""
+    from hific_amd.network.generator import Generator
+    hific.set_compute_dtype(torch.float32)
+    torch.manual_seed(11)
+    gen = Generator((8, 16, 16), 2, C=8, n_residual_blocks=1, sample_noise=True, noise_dim=32).to(dev)
+    assert gen.resblock_0.conv1.weight.shape[:2] == (992, 992)
+    sdg = {"Generator." + k: v.detach().cpu() for k, v in gen.state_dict().items()}
+    y = O.make_noise(21, (2, 8, 16, 16))
+    z = O.make_noise(22, (2, 32, 16, 16))
+    gen._draw_noise = lambda shape: z.clone()
+    yr = y.clone().requires_grad_(True)
+    out_or = O.generator_forward(sdg, yr, 1, noise=z)
+    out_or.square().mean().backward()
+    yd = y.to(dev).requires_grad_(True)
+    out = gen(yd)
+    out.float().square().mean().backward()
+    torch.cuda.synchronize()
+    assert out.shape == (2, 3, 256, 256)
+    assert _relerr(out.detach().float().cpu(), out_or.detach()) < 1e-3
+    assert _relerr(yd.grad.float().cpu(), yr.grad) < 1e-2
+
+
+def test_normalize_input_image_variant(hific, dev, sd):
+    """args.normalize_input_image=True (model.py:155-156, 206-209, 361-363): tanh on the reconstruction, [-1,1] -> [0,1]
+    before the losses.  Losses and a gradient vs the oracle (pinned to the reference's Model in
+    tests/test_oracle_vs_reference.py::test_normalize_input_image_variant)."""
+    import hific_amd
+    from hific_amd.default_config import make_args, mse_lpips_args, ModelTypes, ModelModes
+    hific.set_compute_dtype(torch.float32)
+    args = make_args(mse_lpips_args, n_residual_blocks=N_RES, normalize_input_image=True)
+    model = hific_amd.Model(args, model_type=ModelTypes.COMPRESSION, allow_random_lpips_backbone=True)
+    model.load_state_dict({k: v for k, v in sd.items() if not k.startswith("Discriminator.")}, strict=True)
+    bb = O.make_alex_backbone()
+    model.perceptual_loss.load_backbone_state_dict(bb)
+    model = model.to(dev).train()
+    lins = [getattr(model.perceptual_loss, f"lin{i}").cpu() for i in range(5)]
+    nh, nl = O.make_noise(6, (2, 320, 2, 2)), O.make_noise(7, (2, 220, 8, 8))
+    x = O.make_image(2, 2, 128, 128) * 2 - 1
+    noises = [nh.to(dev), nl.to(dev)]
+    model.Hyperprior._draw_noise = lambda t: noises.pop(0)
+    losses = model(x.to(dev), train_generator=True, writeout=False)
+    losses["compression"].backward()
+    torch.cuda.synchronize()
+    key = "Generator.conv_block_out.1.weight"
+    sdr = {k: (v.clone().requires_grad_(True) if k == key else v.clone()) for k, v in sd.items()}
+    out = O.model_forward(sdr, bb, lins, x, step_counter=1, training=True, gan=False, noise_hyper=nh, noise_latent=nl,
+                          args=dict(normalize_input_image=True), n_residual_blocks=N_RES)
+    out["compression"].backward()
+    a, b = float(losses["compression"]), float(out["compression"])
+    assert abs(a - b) < 1e-3 * abs(b), (a, b)
+    g = dict(model.named_parameters())[key].grad.float().cpu()
+    assert _relerr(g, sdr[key].grad) < 1e-2
+    # EVALUATION forward maps the tanh output to [0, 1]
+    del model.Hyperprior._draw_noise                 # back to the RNG draw
+    model.eval(); model.model_mode = ModelModes.EVALUATION
+    with torch.no_grad():
+        rec, _ = model(x.to(dev))
+    assert float(rec.min()) >= 0.0 and float(rec.max()) <= 1.0

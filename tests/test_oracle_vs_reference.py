@@ -88,6 +88,40 @@ def test_discriminator_and_lpips(ns):
     assert torch.allclose(v_ref, v_or, rtol=1e-5, atol=1e-7)
 
 
+def test_generator_sample_noise_variant(ns):
+    """Generator(sample_noise=True) (generator.py:105-107, 149-152): the oracle with the same draw == the reference."""
+    G = ns.generator.Generator((8, 4, 4), 2, C=8, n_residual_blocks=1, sample_noise=True, noise_dim=32)
+    y = O.make_noise(21, (2, 8, 4, 4))
+    torch.manual_seed(99)
+    out_ref = G(y)
+    torch.manual_seed(99)
+    z = torch.randn((2, 32, 4, 4))
+    sd = {"Generator." + k: v for k, v in G.state_dict().items()}
+    out_or = O.generator_forward(sd, y, 1, noise=z)
+    assert out_ref.shape == (2, 3, 64, 64)
+    assert torch.allclose(out_ref, out_or, rtol=1e-4, atol=1e-5)
+
+
+def test_normalize_input_image_variant(ns):
+    """args.normalize_input_image=True (tanh reconstruction, [-1,1] -> [0,1] before the losses; model.py:155-156,
+    206-209): oracle == reference Model."""
+    m = ref_loader.build_reference_model(ns, gan=False, normalize_input_image=True)
+    bb = O.make_alex_backbone()
+    ref_loader.set_lpips_backbone(m, bb)
+    lins = ref_loader.reference_lins(m)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = O.make_image(31, 2, 128, 128) * 2 - 1
+    torch.manual_seed(5)
+    losses = m(x, train_generator=True, writeout=False)
+    nh_shape, nl_shape = (2, 320, 2, 2), (2, 220, 8, 8)
+    torch.manual_seed(5)
+    nh = torch.nn.init.uniform_(torch.zeros(nh_shape), -0.5, 0.5)
+    nl = torch.nn.init.uniform_(torch.zeros(nl_shape), -0.5, 0.5)
+    out = O.model_forward(sd, bb, lins, x, step_counter=1, training=True, gan=False, noise_hyper=nh, noise_latent=nl,
+                          args=dict(normalize_input_image=True), n_residual_blocks=m.args.n_residual_blocks)
+    assert torch.allclose(losses["compression"], out["compression"], rtol=1e-4, atol=1e-5)
+
+
 def test_lpips_vgg_variant(ns):
     """The reference's other LPIPS backbone (networks_basic.py:36-38, pretrained_networks.py:96-134): oracle == reference
     with the same seeded VGG16 weights, and the packaged linear heads are the reference's vgg.pth."""
