@@ -684,11 +684,17 @@ __host__ __device__ constexpr int sp9_tap_in_phase(int phs, int t) {
     return phs == 1 ? (t < 1 ? t : t < 3 ? t - 1 : t < 5 ? t - 3 : t - 5)
                     : phs == 2 ? (t < 4 ? t : t < 6 ? t - 4 : t < 8 ? t - 6 : t - 8) : t;
 }
-template <int WM, int KSP, bool RFX, int PHS>
+// DS = true (16-pixel tile rows, taps ordered (dy, dx) with dx ascending by one patch pixel): the B fragment of tap
+// (dy, dx+1) for pixel n is the fragment of tap (dy, dx) for pixel n+1, i.e. the neighbouring lane's registers.  A tile
+// row is exactly one 16-lane DPP row, so taps dx = 1, 2 of a kernel row take their fragments with `row_shl:1` from the
+// previous tap's and only the last pixel of each tile row (lanes 15, 31, 47, 63: the halo column) reads LDS.  B-side LDS
+// reads per kernel row: 3 KB -> 1.1 KB per fragment slice (the kernel is LDS-read bound).
+template <int WM, int KSP, bool RFX, int PHS, bool DS = false>
 __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(PHS ? 1 : 2, PHS ? 1 : 2)))
 void gconv_sp9_kernel(const GcParams p) {
     typedef bf16_t T;
     static_assert(!(PHS && (RFX || KSP != 1)), "phase-merged mode: 4 waves, no reflect gather");
+    static_assert(!(DS && (RFX || PHS)), "shifted fragments: plain 3x3 stride-1 forward type only");
     constexpr int NPH = PHS ? 4 : 1;
     constexpr int BC = 64, KS = 16, PITCH = 144, PPR = 8, WGN = 2, WN = 2, NT = 9, QJ = 3;
     constexpr int BM = 2 * WM * 32;
@@ -818,6 +824,8 @@ void gconv_sp9_kernel(const GcParams p) {
     constexpr int PD = 2 / KSP;                                 // patch dword columns issued per step (steps 0..3)
     u32x4_t wS[3][NWP];
     unsigned short rlo[3][PD * QJ], rhi[3][PD * QJ];
+    u32x4_t bsh[WN][BC / KS / KSP];                             // DS: B fragments carried from tap to tap of a kernel row
+    const bool edge_lane = (l31 & 15) == 15;                    // last pixel of a 16-pixel tile row
 
     // prologue: patch of chunk 0 staged synchronously (by the first four waves: stage_T's thread map is 4 waves wide),
     // weight tiles 0..2 requested, tile 0 in ring slot 0
@@ -875,8 +883,20 @@ void gconv_sp9_kernel(const GcParams p) {
             bf16x8_t a[WM], b[WN];                                                                              \
             _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
                 a[mi] = *(const bf16x8_t*)(ab + mi * 32 * PITCH + kk * 32);                                     \
-            _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                                   \
-                b[ni] = *(const bf16x8_t*)(pcur + bo[ni] + kk * 32);                                            \
+            _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                                 \
+                if constexpr (DS) {                                                                             \
+                    if ((tt) % 3 == 0) {                                                                        \
+                        bsh[ni][kq] = *(const u32x4_t*)(pcur + bo[ni] + kk * 32);                               \
+                    } else {                                                                                    \
+                        u32x4_t edge_ = {0u, 0u, 0u, 0u};                                                       \
+                        if (edge_lane) edge_ = *(const u32x4_t*)(pcur + bo[ni] + kk * 32);                      \
+                        _Pragma("unroll") for (int d = 0; d < 4; ++d)                                           \
+                            bsh[ni][kq][d] = (unsigned)__builtin_amdgcn_update_dpp((int)edge_[d], (int)bsh[ni][kq][d], \
+                                                                                   0x101, 0xf, 0xf, false);     \
+                    }                                                                                           \
+                    b[ni] = __builtin_bit_cast(bf16x8_t, bsh[ni][kq]);                                          \
+                } else b[ni] = *(const bf16x8_t*)(pcur + bo[ni] + kk * 32);                                     \
+            }                                                                                                   \
             _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
                 _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                               \
                     acc[sp9_phase(PHS, tt)][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                 \
@@ -2516,9 +2536,20 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         hipFuncSetAttribute((const void*)gconv_sp9_kernel<WM_, KSP_, RFX_, PHS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp); \
         hipLaunchKernelGGL((gconv_sp9_kernel<WM_, KSP_, RFX_, PHS_>), grid, dim3(256 * KSP_), lds_sp, st, p);       \
     } while (0)
+                // shifted B fragments (DS): 16-pixel tile rows, taps (dy, dx) with dx ascending by one pixel
+                // measured (round 2): 115 -> 128 us on 960x960 @16x16x16 - the exec-masked edge reads and the DPP -> MFMA
+                // dependency cost more than the saved LDS bytes: opt-in experiment
+                bool ds = !phs && !p.rfx && p.TW == 16 && p.ph[0].ntaps == 9 && env_int("HIFIC_SP9_DS", 0);
+                for (int r = 0; r < 3 && ds; ++r)
+                    for (int c = 0; c < 3; ++c)
+                        ds = ds && p.tap_dy[3 * r + c] == p.tap_dy[3 * r] && p.tap_dx[3 * r + c] == p.tap_dx[3 * r] + c;
                 if (phs == 1) SP9_LAUNCH(1, 1, false, 1);
                 else if (phs == 2) SP9_LAUNCH(1, 1, false, 2);
                 else if (p.rfx) { if (bm == 128) SP9_LAUNCH(2, 2, true, 0); else SP9_LAUNCH(1, 1, true, 0); }
+                else if (bm == 128 && ks2 && ds) {
+                    hipFuncSetAttribute((const void*)gconv_sp9_kernel<2, 2, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
+                    hipLaunchKernelGGL((gconv_sp9_kernel<2, 2, false, 0, true>), grid, dim3(512), lds_sp, st, p);
+                }
                 else if (bm == 128) { if (ks2) SP9_LAUNCH(2, 2, false, 0); else SP9_LAUNCH(2, 1, false, 0); }
                 else { if (ks2 && env_int("HIFIC_SP9_KSPLIT64", 0)) SP9_LAUNCH(1, 2, false, 0); else SP9_LAUNCH(1, 1, false, 0); }
 #undef SP9_LAUNCH
