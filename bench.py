@@ -207,7 +207,8 @@ def measure_traffic(args, kernel_name):
         cmd = [rocprof, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                "--traffic-child", "--steps", "1", "--warmup", "1", "--batch", str(args.batch), "--size", str(args.size),
                "--config", args.config, "--dtype", args.dtype]
-        env = dict(os.environ, TMPDIR="/tmp")
+        # counters are per dispatch: single-stream execution in the child, like the timing leg (profile_kernels)
+        env = dict(os.environ, TMPDIR="/tmp", HIFIC_SIDE_WGRAD="0", HIFIC_BRANCH_STREAMS="0")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
         try:
