@@ -309,6 +309,29 @@ def join_side_stream():
         _side_state["pending"] = False
 
 
+_reduce_streams = {}
+
+
+def reduce_stream(device):
+    """Stream the DDP reducer issues its collectives from (parallel.BucketedGradReducer)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _reduce_streams.get(idx)
+    if st is None:
+        st = _reduce_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
+def producer_streams(device):
+    """Every stream gradient kernels may have been enqueued on: the current one, the model's main stream, side, branch."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    out = [torch.cuda.current_stream(idx)]
+    for table in (_home_streams, _side_streams, _branch_streams):
+        st = table.get(idx)
+        if st is not None and all(st.cuda_stream != o.cuda_stream for o in out):
+            out.append(st)
+    return out
+
+
 def _join_callback():
     _side_state["cb"] = False
     join_side_stream()
