@@ -185,3 +185,32 @@ def test_instance_norm_variant_constructs_like_the_reference(hific):
     ref = torch.relu(torch.nn.InstanceNorm2d(5, affine=True)(x))
     assert torch.allclose(m(x), ref, atol=1e-6)
     assert m(x.bfloat16()).dtype == torch.bfloat16
+
+
+def test_option_variants_keep_the_reference_layout(hific):
+    """Options that are off in the shipped configs but honoured: Generator(sample_noise=True) has the reference's
+    state_dict layout (992-channel blocks; checked against the reference class where the checkout exists), and
+    PerceptualLoss(net='vgg') carries VGG16's 13 conv layers with the reference's linear-head widths."""
+    import warnings
+    from hific_amd.network.generator import Generator
+    from hific_amd.loss.perceptual_loss import PerceptualLoss, NETS
+    gen = Generator((8, 4, 4), 2, C=8, n_residual_blocks=1, sample_noise=True, noise_dim=32)
+    sd = gen.state_dict()
+    assert tuple(sd["conv_block_init.2.weight"].shape) == (960, 8, 3, 3)
+    assert tuple(sd["resblock_0.conv1.weight"].shape) == (992, 992, 3, 3)
+    assert tuple(sd["upconv_block1.0.weight"].shape) == (992, 480, 3, 3)
+    from oracle import ref_loader
+    if ref_loader.available():
+        ns = ref_loader.load()
+        ref = ns.generator.Generator((8, 4, 4), 2, C=8, n_residual_blocks=1, sample_noise=True, noise_dim=32)
+        rsd = ref.state_dict()
+        assert list(rsd.keys()) == list(sd.keys())
+        assert all(tuple(rsd[k].shape) == tuple(sd[k].shape) for k in sd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pl = PerceptualLoss(net='vgg', use_gpu=False, allow_random_backbone=True)
+    assert pl.net == 'vgg' and len(NETS['vgg']) == 13 and sum(1 for c in NETS['vgg'] if c[6]) == 5
+    assert [tuple(pl._t[f"lin{i}"].shape) for i in range(5)] == [(64,), (128,), (256,), (512,), (512,)]
+    assert tuple(pl._t["features.28.weight"].shape) == (512, 512, 3, 3)
+    with pytest.raises(NotImplementedError):
+        PerceptualLoss(net='squeeze', use_gpu=False, allow_random_backbone=True)
