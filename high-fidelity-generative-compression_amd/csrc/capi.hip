@@ -38,7 +38,8 @@ static bool geomT_ok(const ConvTGeom& g) {
 }
 
 // y = act(conv2d(pad(x), w*w_scale) + bias [+ resid]);  x [N,C,H,W], w f32 [K,C,R,S], y [N,K,OH,OW]
-// flags: bit0 = x is f32 although dtype is bf16, bit1 = y (and resid) are f32 although dtype is bf16
+// flags: bit0 = x is f32 although dtype is bf16, bit1 = y (and resid) are f32 although dtype is bf16, bit2 = C is the
+// 3x split-bf16 reduction of a C/3-channel layer (hific_split3; only the profiler's FLOP count changes)
 int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const float* bias, const void* resid, void* y,
                      int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb, int pr,
                      int pad_mode, int act, int dtype, int flags, void* ws, size_t ws_bytes, void* wcache,
@@ -47,6 +48,7 @@ int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const 
     if (!geom_ok(g) || !x || !w || !y) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
     a.wcache = wcache; a.wcache_bytes = wcache_bytes; a.wcache_state = wcache_state;
+    g.red_split = (flags >> 2) & 1;
     return gc_conv_fwd(g, x, w, w_scale, bias, y, resid, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 
@@ -81,6 +83,7 @@ int hific_conv_transpose2d_fwd(const void* x, const float* w, const float* bias,
     if (!geomT_ok(g) || !x || !w || !y) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
     a.wcache = wcache; a.wcache_bytes = wcache_bytes; a.wcache_state = wcache_state;
+    g.red_split = (flags >> 2) & 1;
     return gc_convT_fwd(g, x, w, bias, y, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 int hific_conv_transpose2d_bwd_data(const void* dy, const float* w, void* dx, int N, int Ci, int H, int W, int Co,

@@ -455,6 +455,53 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Split-bf16 operands (exact-index mode).  A float32 value v is carried as hi = bf16(v) and
+// lo = bf16(v - hi) (v - hi is exact in f32); x*w ~= xh*wh + xl*wh + xh*wl (relative error ~2^-17 per product instead
+// of 2^-9), three bf16 MFMA products accumulated in f32.  The three terms are laid out as 3C reduction channels so the
+// ordinary bf16 contraction kernels compute the sum: activations (hi, lo, hi), weights (hi, hi, lo).
+// src f32 [outer][C][inner] -> dst [outer][3C][inner].
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_hl(float v, float& h, float& l) {
+    h = bf2f(f2bf(v));
+    l = bf2f(f2bf(v - h));
+}
+template <typename TO, int WHICH>
+__global__ void split3_kernel(const float* __restrict__ src, TO* __restrict__ dst, long long total, unsigned C,
+                              unsigned inner) {
+    const unsigned ci = C * inner;
+    EW_LOOP(i, total) {
+        const unsigned long long o = (unsigned long long)i / ci;
+        const unsigned r = (unsigned)((unsigned long long)i - o * ci);
+        float h, l;
+        split_hl(src[i], h, l);
+        TO* d = dst + o * 3ull * ci + r;
+        DT<TO>::st(d, h);
+        DT<TO>::st(d + ci, WHICH == 0 ? l : h);
+        DT<TO>::st(d + 2ull * ci, WHICH == 0 ? h : l);
+    }
+}
+// 4 consecutive elements per thread (inner % 4 == 0, 16-byte aligned): one 16-byte load, three 8-byte bf16 stores
+template <int WHICH>
+__global__ void split3_bf16x4_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long long total4, unsigned C,
+                                     unsigned inner4) {
+    const unsigned ci = C * inner4;
+    EW_LOOP(i, total4) {
+        const unsigned long long o = (unsigned long long)i / ci;
+        const unsigned r = (unsigned)((unsigned long long)i - o * ci);
+        const float4 v = src[i];
+        float h0, l0, h1, l1, h2, l2, h3, l3;
+        split_hl(v.x, h0, l0); split_hl(v.y, h1, l1); split_hl(v.z, h2, l2); split_hl(v.w, h3, l3);
+        uint2 H, L;
+        H.x = ew_pack2(h0, h1); H.y = ew_pack2(h2, h3);
+        L.x = ew_pack2(l0, l1); L.y = ew_pack2(l2, l3);
+        uint2* d = dst + o * 3ull * ci + r;
+        d[0] = H;
+        d[ci] = WHICH == 0 ? L : H;
+        d[2ull * ci] = WHICH == 0 ? H : L;
+    }
+}
+
 extern "C" {
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
@@ -513,6 +560,28 @@ int hific_cast(const void* a, int src_dtype, void* o, int dst_dtype, long long n
     else if (src_dtype == HIFIC_BF16 && dst_dtype == HIFIC_BF16)
         hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), EW_GRID(n), dim3(256), 0, st, (const bf16_t*)a, (bf16_t*)o, n);
     else return HIFIC_ERR_ARG;
+    return hific_launch_status();
+}
+
+// which 0: activation layout (hi, lo, hi); 1: weight layout (hi, hi, lo).  dst_dtype bf16 (activations) or f32 (a
+// derived weight tensor whose values are exactly bf16-representable, fed to the ordinary weight-pack path).
+int hific_split3(const float* src, void* dst, long long outer, int C, long long inner, int which, int dst_dtype,
+                 hipStream_t st) {
+    if (!src || !dst || outer <= 0 || C <= 0 || inner <= 0 || (which != 0 && which != 1)) return HIFIC_ERR_ARG;
+    if ((long long)C * inner >= (1ll << 31)) return HIFIC_ERR_UNSUPPORTED;
+    const long long total = outer * C * inner;
+    if (dst_dtype == HIFIC_BF16 && inner % 4 == 0 && (((size_t)src & 15) | ((size_t)dst & 7)) == 0) {
+        if (which == 0) hipLaunchKernelGGL(split3_bf16x4_kernel<0>, EW_GRID(total / 4), dim3(256), 0, st, (const float4*)src, (uint2*)dst, total / 4, (unsigned)C, (unsigned)(inner / 4));
+        else hipLaunchKernelGGL(split3_bf16x4_kernel<1>, EW_GRID(total / 4), dim3(256), 0, st, (const float4*)src, (uint2*)dst, total / 4, (unsigned)C, (unsigned)(inner / 4));
+        return hific_launch_status();
+    }
+    if (dst_dtype == HIFIC_BF16) {
+        if (which == 0) hipLaunchKernelGGL((split3_kernel<bf16_t, 0>), EW_GRID(total), dim3(256), 0, st, src, (bf16_t*)dst, total, (unsigned)C, (unsigned)inner);
+        else hipLaunchKernelGGL((split3_kernel<bf16_t, 1>), EW_GRID(total), dim3(256), 0, st, src, (bf16_t*)dst, total, (unsigned)C, (unsigned)inner);
+    } else if (dst_dtype == HIFIC_F32) {
+        if (which == 0) hipLaunchKernelGGL((split3_kernel<float, 0>), EW_GRID(total), dim3(256), 0, st, src, (float*)dst, total, (unsigned)C, (unsigned)inner);
+        else hipLaunchKernelGGL((split3_kernel<float, 1>), EW_GRID(total), dim3(256), 0, st, src, (float*)dst, total, (unsigned)C, (unsigned)inner);
+    } else return HIFIC_ERR_ARG;
     return hific_launch_status();
 }
 

@@ -77,12 +77,14 @@ struct WgParams {
 // geometry of a conv layer as the reference constructs it (nn.Conv2d semantics)
 struct ConvGeom {
     int N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode;
+    int red_split = 0;   // C is 3x the layer's channels (split-bf16 operands, hific_split3): count 1/3 of the FLOPs
     int OH() const { return (H + pt + pb - R) / stride + 1; }
     int OW() const { return (W + pl + pr - S) / stride + 1; }
 };
 // nn.ConvTranspose2d semantics: x[N,Ci,H,W], w[Ci,Co,R,S]
 struct ConvTGeom {
     int N, Ci, H, W, Co, R, S, stride, pad, outpad;
+    int red_split = 0;
     int OH() const { return (H - 1) * stride - 2 * pad + R + outpad; }
     int OW() const { return (W - 1) * stride - 2 * pad + S + outpad; }
 };

@@ -2782,7 +2782,7 @@ int gc_conv_fwd(const ConvGeom& g, const void* x, const float* w, const float* w
     ph.ntaps = nt; ph.tap0 = 0; ph.ooy = 0; ph.oox = 0; ph.OHt = p.OHf; ph.OWt = p.OWf;
     finish_phase(ph, p);
     const long long RS = (long long)g.R * g.S;
-    p.aflops = 2.0 * g.K * g.C * (double)RS * g.N * g.OH() * g.OW();
+    p.aflops = 2.0 * g.K * g.C * (double)RS * g.N * g.OH() * g.OW() / (g.red_split ? 3.0 : 1.0);
     return launch_gconv(p, dtype, w, w_scale, (long long)g.C * RS, RS, g.S, 1, ws, st);
 }
 
@@ -2924,7 +2924,7 @@ int gc_convT_fwd(const ConvTGeom& g, const void* x, const float* w, const float*
     }
     p.nphase = np;
     const long long RS = (long long)g.R * g.S;
-    p.aflops = 2.0 * g.Ci * g.Co * (double)RS * g.N * g.H * g.W;           // every (input pixel, tap) pair once
+    p.aflops = 2.0 * g.Ci * g.Co * (double)RS * g.N * g.H * g.W / (g.red_split ? 3.0 : 1.0);   // every (input pixel, tap) pair once
     // w[ci][co][r][s]: m = co (stride RS), reduction channel ci (stride Co*RS)
     return launch_gconv(p, dtype, w, nullptr, RS, (long long)g.Co * RS, g.S, 1, ws, st);
 }

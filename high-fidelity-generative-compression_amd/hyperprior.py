@@ -98,6 +98,9 @@ class Hyperprior(CodingModel):
         self.synthesis_mu = hyper.HyperpriorSynthesis(C=bottleneck_capacity, N=hyperlatent_filters)
         self.synthesis_std = hyper.HyperpriorSynthesis(C=bottleneck_capacity, N=hyperlatent_filters)
         self.amortization_models = [self.analysis_net, self.synthesis_mu, self.synthesis_std]
+        # y - mu is floored into the indices: both nets that produce mu run the exact-index forward (ops.set_exact_index)
+        hyper.mark_exact_index_chain(self.analysis_net)
+        hyper.mark_exact_index_chain(self.synthesis_mu)
         self.hyperlatent_likelihood = hyperprior_model.HyperpriorDensity(n_channels=hyperlatent_filters)
         if likelihood_type == 'gaussian':
             self.likelihood_logistic = 0
@@ -200,6 +203,7 @@ class Hyperprior(CodingModel):
         latent_means = self.synthesis_mu(hd_mu)
         if getattr(self, 'keep_debug', False):          # parity tests: symbols = round(decoded - means)
             self.debug_latent_means = latent_means.detach().float().clone()
+            self.debug_latents = latents.detach().float().clone()
         mu_a, mu_b = ops.fork(latent_means)
         mu_c, mu_d = ops.fork(mu_b)
         mu_e, mu_f = ops.fork(mu_d)

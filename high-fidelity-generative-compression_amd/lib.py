@@ -40,6 +40,7 @@ SIGNATURES = {
     "hific_scale_shift": (I, [P, P, L, F, F, I, P]),
     "hific_add": (I, [P, P, P, L, I, P]),
     "hific_cast": (I, [P, I, P, I, L, P]),
+    "hific_split3": (I, [P, P, L, I, L, I, I, P]),
     "hific_axpby_f32": (I, [P, P, P, F, F, L, P]),
     "hific_channel_sum": (I, [P, P, I, I, I, I, I, P, Z, P]),
     "hific_maxpool2s2_fwd": (I, [P, P, L, I, I, I, P]),

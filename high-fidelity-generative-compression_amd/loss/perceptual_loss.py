@@ -105,8 +105,10 @@ class TargetFeatures:
     depends on the input image only, so it can run on a second stream while the Encoder / Generator produce the other
     image."""
 
-    def __init__(self, key, feats, event):
-        self.key, self.feats, self.event = key, feats, event
+    def __init__(self, key, feats, event, target):
+        # `target` keeps the tensor alive, so its address cannot be recycled for another batch while this is pending, and
+        # the consumer matches by identity of the storage (data_ptr + version + shape of a live tensor)
+        self.key, self.feats, self.event, self.target = key, feats, event, target
 
 
 def _target_key(target, normalize, cd, net="alex"):
@@ -310,4 +312,8 @@ class PerceptualLoss(nn.Module):
             feats = [None] * len(cfg)
             _net_half(xt[:B], wb, cd, feats, 0, B, cfg)
         ev = torch.cuda.current_stream(target.device).record_event()
-        self.__dict__["_prefetched"] = TargetFeatures(_target_key(target, normalize, cd, self.net), feats, ev)
+        self.__dict__["_prefetched"] = TargetFeatures(_target_key(target, normalize, cd, self.net), feats, ev, target)
+
+    def drop_prefetch(self):
+        """Forget a prefetch nobody consumed (Model.forward calls this first: a forward that raised must not leave one)."""
+        self.__dict__.pop("_prefetched", None)

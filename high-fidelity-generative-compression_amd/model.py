@@ -156,7 +156,9 @@ class Model(nn.Module):
         if train_generator is True:
             self.step_counter += 1            # a 'step' is one cycle of G-D training (model.py:351-353)
         branch = ops.branch_streams_on() and x.is_cuda
-        if branch and self.model_mode != ModelModes.EVALUATION:
+        self.perceptual_loss.drop_prefetch()
+        # (with normalize_input_image the loss sees a rescaled copy of x, which a prefetch on x could never match)
+        if branch and self.model_mode != ModelModes.EVALUATION and self.args.normalize_input_image is not True:
             # the LPIPS features of the input image depend on nothing the networks compute: start them on the branch
             # stream now, next to the Encoder (perceptual_loss_wrapper below picks them up)
             main = torch.cuda.current_stream(x.device)

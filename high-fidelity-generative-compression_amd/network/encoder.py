@@ -5,7 +5,7 @@ loader; ChannelNorm + ReLU (encoder.py:58-60) is one fused kernel."""
 import torch.nn as nn
 
 from ..normalisation import channel, instance
-from .layers import HipConv2d
+from .layers import HipConv2d, mark_exact_index_chain
 
 
 class Encoder(nn.Module):
@@ -47,6 +47,8 @@ class Encoder(nn.Module):
             nn.Identity(),
             HipConv2d(filters[4], C, kernel_dim, stride=1, pads=(1, 1, 1, 1), pad_mode="reflect", out_f32=True),
         )
+        # the latents are floored into the entropy coder's indices (src/hyperprior.py:68-74): split-bf16 forward
+        mark_exact_index_chain(self)
 
     def forward(self, x):
         x = self.conv_block1(x)

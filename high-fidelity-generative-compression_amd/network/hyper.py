@@ -3,7 +3,7 @@
 around these nets is float32, so the first conv reads float32 and the last conv writes float32 in bf16 mode."""
 import torch.nn as nn
 
-from .layers import HipConv2d, HipConvTranspose2d
+from .layers import HipConv2d, HipConvTranspose2d, mark_exact_index_chain  # noqa: F401
 
 
 class HyperpriorAnalysis(nn.Module):

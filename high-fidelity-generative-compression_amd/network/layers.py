@@ -16,10 +16,12 @@ class HipConv2d(nn.Conv2d):
         self.hip_pad_mode = lib.PAD_REFLECT if pad_mode == "reflect" else lib.PAD_ZERO
         self.act = act
         self.out_f32 = out_f32
+        self.exact_index_chain = False     # set by the owner: this layer feeds the floor() of the latent indices
 
     def forward(self, x):
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], pads=self.pads,
-                          pad_mode=self.hip_pad_mode, act=self.act, out_f32=self.out_f32)
+                          pad_mode=self.hip_pad_mode, act=self.act, out_f32=self.out_f32,
+                          exact=self.exact_index_chain and ops.exact_index_on())
 
     def extra_repr(self):
         return super().extra_repr() + f", pads(t,l,b,r)={self.pads}, hip_act={self.act}"
@@ -34,7 +36,19 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
                          output_padding=output_padding)
         self.act = act
         self.out_f32 = out_f32
+        self.exact_index_chain = False
 
     def forward(self, x):
         return ops.conv_transpose2d(x, self.weight, self.bias, self.stride[0], self.padding[0],
-                                    self.output_padding[0], act=self.act, out_f32=self.out_f32)
+                                    self.output_padding[0], act=self.act, out_f32=self.out_f32,
+                                    exact=self.exact_index_chain and ops.exact_index_on())
+
+
+def mark_exact_index_chain(module, on=True):
+    """Every conv of `module` runs its forward with split-bf16 operands in bf16 mode (ops.set_exact_index): the
+    Encoder, the hyper-analysis net and the mean synthesis net - the chain behind floor(y - mu + 0.5)
+    (src/hyperprior.py:68-74,108-122)."""
+    for m in module.modules():
+        if isinstance(m, (HipConv2d, HipConvTranspose2d)):
+            m.exact_index_chain = bool(on)
+    return module

@@ -60,7 +60,8 @@ _PACK_CACHE_ON = __import__("os").environ.get("HIFIC_PACK_CACHE", "1") != "0"
 
 
 class _PackEntry:
-    __slots__ = ("weight", "buf", "job", "token", "nblocks", "lds", "dtype", "kind", "event", "pack_sid", "waited")
+    __slots__ = ("weight", "buf", "job", "token", "nblocks", "lds", "dtype", "kind", "event", "pack_sid", "waited",
+                 "last_use")
 
 
 class WeightPackCache:
@@ -68,6 +69,27 @@ class WeightPackCache:
         self.entries = {}
         self.prepared = {}          # tuple(entry keys) -> (jobs_dev, prefix_dev, total_blocks, lds, dtype)
         self.job_bytes = None
+        self.tick = 0
+        self.bytes = 0
+        # Keys carry the full geometry, so inference over many image sizes would add a packed copy of every weight per
+        # size: least-recently-used entries are dropped beyond this many bytes (one training configuration needs ~0.8 GB)
+        self.cap_bytes = int(os.environ.get("HIFIC_PACK_CACHE_MB", "6144")) << 20
+
+    def _drop(self, key):
+        e = self.entries.pop(key)
+        self.bytes -= e.buf.numel()
+        # kernels on other streams may still read the packed image: the allocator must not recycle it under them
+        for st in producer_streams(e.buf.device):
+            e.buf.record_stream(st)
+
+    def _make_room(self, device):
+        if self.bytes <= self.cap_bytes:
+            return
+        for key, _ in sorted(self.entries.items(), key=lambda kv: kv[1].last_use):
+            if self.bytes <= self.cap_bytes // 2:
+                break
+            self._drop(key)
+        self.prepared.clear()
 
     @staticmethod
     def _token(w):
@@ -76,6 +98,7 @@ class WeightPackCache:
 
     def clear(self):
         self.entries.clear(); self.prepared.clear()
+        self.bytes = 0
 
     def lookup(self, weight, kind, geom, cd, flags, transposed):
         """-> (wcache ptr, bytes, state) for the C-ABI call."""
@@ -91,7 +114,9 @@ class WeightPackCache:
             # relate to the packed image): start over for this key
             e = None
             self.prepared.clear()
+        self.tick += 1
         if e is None:
+            self._make_room(weight.device)
             e = _PackEntry()
             e.job = ctypes.create_string_buffer(self.job_bytes)
             fn = "hific_conv_transpose2d_pack_plan" if transposed else "hific_conv2d_pack_plan"
@@ -105,7 +130,9 @@ class WeightPackCache:
             e.token = None                       # never packed yet
             e.kind, e.event, e.pack_sid, e.waited = kind, None, None, set()
             self.entries[key] = e
+            self.bytes += e.buf.numel()
             self.prepared.clear()
+        e.last_use = self.tick
         if e.token != tok:
             self.refresh_stale()
         # packed on another stream (the batched re-pack runs on the stream of the first stale lookup; data-gradient packs on
@@ -122,9 +149,13 @@ class WeightPackCache:
         (dtype, direction).  Forward packs (kind 0) run on the current stream - the caller needs one of them right now;
         data-gradient packs (kind 1) are first needed in the next backward pass and run on a separate stream, off the
         critical path when HIFIC_PACK_STREAM=1 (default 0: everything on the current stream - measured faster)."""
-        dead = [k for k, e in self.entries.items() if e.weight() is None]
+        split_weights.refresh()        # derived (hi, hi, lo) weight images first: their packed images are entries here
+        # dead: the weight object is gone, or it no longer lives at the address this entry was keyed (and its pack job was
+        # pointed) at - `model.cpu().to(dev)` before ParamArena.rebind(): re-packing from the old address would read freed
+        # memory, and nothing would ever look the entry up again
+        dead = [k for k, e in self.entries.items() if e.weight() is None or e.weight().data_ptr() != k[0]]
         for k in dead:
-            del self.entries[k]
+            self._drop(k)
         if dead:
             self.prepared.clear()
         stale = [(k, e) for k, e in self.entries.items() if e.token != self._token(e.weight())]
@@ -231,6 +262,96 @@ def _pack_stream(device):
 
 
 pack_cache = WeightPackCache()
+
+
+# ------------------------------------------------------------------------------------------------------
+# Exact-index mode.  The reference floors y - mu + 0.5 into the latent indices
+# (src/hyperprior.py:68-74,108-122); with bf16 operands in the chain that produces y and mu (Encoder -> analysis ->
+# synthesis_mu) 0.3-0.4 % of the indices flip by one.  In this mode the FORWARD contractions of that chain run with
+# split-bf16 operands (hific_split3: x*w ~= xh*wh + xl*wh + xh*wl over 3C reduction channels of the ordinary bf16 MFMA
+# kernels, f32 accumulate, f32 activations in between); everything else - and the whole backward pass - stays bf16.
+# Only meaningful in bf16 compute mode (float32 mode is exact already).  HIFIC_EXACT_INDEX=0 restores the plain bf16 chain.
+_EXACT_INDEX = os.environ.get("HIFIC_EXACT_INDEX", "1") not in ("0", "")
+
+
+def set_exact_index(on):
+    global _EXACT_INDEX
+    _EXACT_INDEX = bool(on)
+
+
+def exact_index_on():
+    return _EXACT_INDEX
+
+
+class _SplitEntry:
+    __slots__ = ("weight", "w3", "token", "addr", "transposed")
+
+
+class SplitWeightCache:
+    """(hi, hi, lo) images of the weights of the exact-index chain along their reduction-channel dimension: float32 tensors
+    [K, 3C, R, S] (conv) / [3Ci, Co, R, S] (conv-transpose) whose values are exactly bf16-representable, so the ordinary
+    weight-pack path turns them into the packed bf16 operand.  Refreshed (all stale entries together, before the batched
+    re-pack looks at them) when the source weight's (version, arena epoch) token changes."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def clear(self):
+        self.entries.clear()
+
+    def get(self, weight, transposed):
+        e = self.entries.get(id(weight))
+        if e is not None and e.weight() is not weight:
+            e = None
+        if e is None:
+            e = _SplitEntry()
+            e.weight, e.transposed, e.token, e.addr, e.w3 = weakref.ref(weight), transposed, None, None, None
+            self.entries[id(weight)] = e
+        if e.token != WeightPackCache._token(weight) or e.addr != weight.data_ptr():
+            self.refresh()
+        return e.w3
+
+    def refresh(self):
+        dead = [k for k, e in self.entries.items() if e.weight() is None]
+        for k in dead:
+            del self.entries[k]
+        waited = False
+        for e in self.entries.values():
+            w = e.weight()
+            tok = WeightPackCache._token(w)
+            if e.token == tok and e.addr == w.data_ptr():
+                continue
+            if not w.is_cuda:
+                continue
+            if not waited and _is_late(w):
+                wait_late_params(); waited = True
+            shape = list(w.shape)
+            if e.transposed:
+                outer, C, inner = 1, shape[0], w.numel() // shape[0]
+                shape[0] *= 3
+            else:
+                outer, C, inner = shape[0], shape[1], shape[2] * shape[3]
+                shape[1] *= 3
+            if e.w3 is None or e.w3.device != w.device or list(e.w3.shape) != shape:
+                e.w3 = torch.empty(shape, dtype=torch.float32, device=w.device)
+            with torch.cuda.device(w.device):
+                call("hific_split3", w.data_ptr(), e.w3.data_ptr(), outer, C, inner, 1, HIFIC_F32,
+                     torch.cuda.current_stream(w.device).cuda_stream)
+            torch.autograd.graph.increment_version(e.w3)        # the pack cache keys on it
+            e.token, e.addr = tok, w.data_ptr()
+
+
+split_weights = SplitWeightCache()
+
+
+def _split3_act(x):
+    """float32 [N, C, H, W] -> bf16 [N, 3C, H, W] = (hi, lo, hi)."""
+    if x.dtype != torch.float32:
+        raise lib.HificError("exact-index convolutions take float32 activations")
+    N, C, H, W = x.shape
+    x3 = torch.empty((N, 3 * C, H, W), dtype=torch.bfloat16, device=x.device)
+    call("hific_split3", ptr(x), ptr(x3), N, C, H * W, 0, HIFIC_BF16, stream())
+    return x3
 
 
 def _wcache(weight, kind, geom, cd, flags, w_scale=None, transposed=False):
@@ -407,7 +528,7 @@ class Conv2dFn(Function):
     """y = act(conv2d(pad(x)) + b).  geom = (stride, pt, pl, pb, pr, pad_mode)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, act, out_f32, w_scale):
+    def forward(ctx, x, weight, bias, geom, act, out_f32, w_scale, exact=False):
         require_gpu(x, weight, bias)
         cd = _cd()
         stride, pt, pl, pb, pr, pad_mode = geom
@@ -416,15 +537,24 @@ class Conv2dFn(Function):
         assert Cw == C, "channel mismatch"
         OH = (H + pt + pb - R) // stride + 1
         OW = (W + pl + pr - S) // stride + 1
-        ydt = torch.float32 if (cd == HIFIC_F32 or out_f32) else torch.bfloat16
+        exact = bool(exact) and cd == HIFIC_BF16 and w_scale is None
+        ydt = torch.float32 if (cd == HIFIC_F32 or out_f32 or exact) else torch.bfloat16
         if cd == HIFIC_F32 and x.dtype != torch.float32:
             raise lib.HificError("float32 compute mode needs float32 activations")
         y = torch.empty((N, K, OH, OW), dtype=ydt, device=x.device)
-        flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | ((1 if ydt == torch.float32 else 0) << 1 if cd == HIFIC_BF16 else 0)
         wsp, wsb = _ws(x)
-        wc = _wcache(weight, 0, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, w_scale)
-        call("hific_conv2d_fwd", ptr(x), ptr(weight), ptr(w_scale), ptr(bias), None, ptr(y),
-             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
+        if exact:
+            # split-bf16 forward: 3C reduction channels of (hi, lo, hi) x (hi, hi, lo); flags bit2 = count C (not 3C) FLOPs
+            x3, w3 = _split3_act(x), split_weights.get(weight, transposed=False)
+            flags = (1 << 1) | (1 << 2)
+            wc = _wcache(w3, 0, (N, 3 * C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None)
+            call("hific_conv2d_fwd", ptr(x3), ptr(w3), None, ptr(bias), None, ptr(y),
+                 N, 3 * C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
+        else:
+            flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | ((1 if ydt == torch.float32 else 0) << 1 if cd == HIFIC_BF16 else 0)
+            wc = _wcache(weight, 0, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, w_scale)
+            call("hific_conv2d_fwd", ptr(x), ptr(weight), ptr(w_scale), ptr(bias), None, ptr(y),
+                 N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
         ctx.geom = geom
         ctx.act = act
         ctx.cd = cd
@@ -478,19 +608,24 @@ class Conv2dFn(Function):
             param_grads()
         _written(ctx.w_slot if ctx.needs_input_grad[1] else None,
                  ctx.b_slot if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride=1, pads=(0, 0, 0, 0), pad_mode=lib.PAD_ZERO, act=None, out_f32=False, w_scale=None):
+def conv2d(x, weight, bias, stride=1, pads=(0, 0, 0, 0), pad_mode=lib.PAD_ZERO, act=None, out_f32=False, w_scale=None,
+           exact=False):
+    """`exact=True` (bf16 compute mode only): split-bf16 forward on float32 activations, float32 output - the exact-index
+    chain (see set_exact_index); the backward pass is the ordinary bf16 one."""
     pt, pl, pb, pr = pads
-    return Conv2dFn.apply(x.contiguous(), weight, bias, (stride, pt, pl, pb, pr, pad_mode), act, out_f32, w_scale)
+    if exact and _compute_dtype == torch.bfloat16 and x.dtype != torch.float32:
+        x = cast_grad(x, torch.float32)
+    return Conv2dFn.apply(x.contiguous(), weight, bias, (stride, pt, pl, pb, pr, pad_mode), act, out_f32, w_scale, exact)
 
 
 class ConvTranspose2dFn(Function):
     """nn.ConvTranspose2d semantics: weight [Cin, Cout, R, S]; geom = (stride, pad, outpad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, act, out_f32):
+    def forward(ctx, x, weight, bias, geom, act, out_f32, exact=False):
         require_gpu(x, weight, bias)
         cd = _cd()
         stride, pad, outpad = geom
@@ -499,17 +634,25 @@ class ConvTranspose2dFn(Function):
         assert Ciw == Ci
         OH = (H - 1) * stride - 2 * pad + R + outpad
         OW = (W - 1) * stride - 2 * pad + S + outpad
-        ydt = torch.float32 if (cd == HIFIC_F32 or out_f32) else torch.bfloat16
+        exact = bool(exact) and cd == HIFIC_BF16
+        ydt = torch.float32 if (cd == HIFIC_F32 or out_f32 or exact) else torch.bfloat16
         if cd == HIFIC_F32 and x.dtype != torch.float32:
             raise lib.HificError("float32 compute mode needs float32 activations")
         y = torch.empty((N, Co, OH, OW), dtype=ydt, device=x.device)
-        flags = 0
-        if cd == HIFIC_BF16:
-            flags = _is_f32(x) | (_is_f32(y) << 1)
         wsp, wsb = _ws(x)
-        wc = _wcache(weight, 0, (N, Ci, H, W, Co, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
-        call("hific_conv_transpose2d_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), N, Ci, H, W, Co, R, S, stride, pad,
-             outpad, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
+        if exact:
+            x3, w3 = _split3_act(x), split_weights.get(weight, transposed=True)
+            flags = (1 << 1) | (1 << 2)
+            wc = _wcache(w3, 0, (N, 3 * Ci, H, W, Co, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
+            call("hific_conv_transpose2d_fwd", ptr(x3), ptr(w3), ptr(bias), ptr(y), N, 3 * Ci, H, W, Co, R, S, stride, pad,
+                 outpad, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
+        else:
+            flags = 0
+            if cd == HIFIC_BF16:
+                flags = _is_f32(x) | (_is_f32(y) << 1)
+            wc = _wcache(weight, 0, (N, Ci, H, W, Co, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
+            call("hific_conv_transpose2d_fwd", ptr(x), ptr(weight), ptr(bias), ptr(y), N, Ci, H, W, Co, R, S, stride, pad,
+                 outpad, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
         ctx.geom, ctx.act, ctx.cd, ctx.has_bias = geom, act, cd, bias is not None
         ctx.w_slot, ctx.b_slot = _slot(weight), _slot(bias)
         ctx.save_for_backward(x, weight, y if act not in (None, "none") else None)
@@ -560,11 +703,13 @@ class ConvTranspose2dFn(Function):
             param_grads()
         _written(ctx.w_slot if ctx.needs_input_grad[1] else None,
                  ctx.b_slot if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv_transpose2d(x, weight, bias, stride, pad, outpad, act=None, out_f32=False):
-    return ConvTranspose2dFn.apply(x.contiguous(), weight, bias, (stride, pad, outpad), act, out_f32)
+def conv_transpose2d(x, weight, bias, stride, pad, outpad, act=None, out_f32=False, exact=False):
+    if exact and _compute_dtype == torch.bfloat16 and x.dtype != torch.float32:
+        x = cast_grad(x, torch.float32)
+    return ConvTranspose2dFn.apply(x.contiguous(), weight, bias, (stride, pad, outpad), act, out_f32, exact)
 
 
 # ------------------------------------------------------------------------------------------------------

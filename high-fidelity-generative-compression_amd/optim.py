@@ -17,13 +17,14 @@ _ALIGN = 64   # elements (256 B)
 
 
 class GradSlot:
-    __slots__ = ("grad", "fresh", "arena", "index")
+    __slots__ = ("grad", "fresh", "arena", "index", "autograd")
 
     def __init__(self, grad, arena, index):
         self.grad = grad
         self.fresh = True
         self.arena = arena
         self.index = index
+        self.autograd = False     # gradient arrives through autograd's AccumulateGrad (no kernel writes this slot)
 
     def take(self):
         """Returns the accumulate flag for the next write (0 = overwrite) and marks the slot written."""
@@ -65,11 +66,29 @@ class ParamArena:
                 p._hific_slot = slot
                 p.grad = gview
                 self.slots.append(slot)
+                p.register_post_accumulate_grad_hook(self._autograd_hook(i))
+
+    def _autograd_hook(self, i):
+        """Parameters whose gradient is produced by ATen ops (the InstanceNorm fallback's affine pair, or any user module
+        mixed into a group) are accumulated IN PLACE into the slot view by autograd's AccumulateGrad, which knows nothing
+        of `fresh`: such slots are zeroed by zero_grad() (they are tiny) and marked written here, so zero_unwritten()
+        keeps them and data-parallel buckets count them."""
+        def hook(p):
+            s = self.slots[i]
+            if p.grad is not s.grad and p.grad is not None and p.grad.data_ptr() != s.grad.data_ptr():
+                s.grad.copy_(p.grad)            # autograd replaced the view (grad was None): bring it home
+                p.grad = s.grad
+            s.autograd = True
+            s.fresh = False
+            s.written()
+        return hook
 
     def zero_grad(self):
-        """Marks every slot fresh (next backward overwrites): no memset needed."""
+        """Marks every slot fresh (next backward overwrites): no memset needed, except for autograd-written slots."""
         for s in self.slots:
             s.fresh = True
+            if s.autograd:
+                s.grad.zero_()
 
     def slice_of(self, i):
         o = self.offsets[i]
@@ -181,6 +200,8 @@ class FusedAdam:
     # ---- checkpointing in torch.optim.Adam's own format (the reference saves `*_optimizer_state_dict`, -------------
     # ---- utils.py:131-137, and restores them in load_model, utils.py:191-197) ---------------------------------------
     def state_dict(self):
+        """torch.optim.Adam's layout; `step` is a float32 0-d tensor (torch >= 1.12 convention; the reference's torch 1.6
+        wrote a Python int - both load here)."""
         ops.wait_late_params()
         state = {}
         if self.step_count > 0:
@@ -204,11 +225,15 @@ class FusedAdam:
         g = self.param_groups[0]
         g["lr"], g["betas"], g["eps"] = groups[0]["lr"], tuple(groups[0]["betas"]), groups[0]["eps"]
         steps = set()
+        ops.wait_late_params()             # a pending optimizer tail still reads / writes the moment buffers
         with torch.no_grad():
             self.exp_avg.zero_(); self.exp_avg_sq.zero_()
             for k, st in sd["state"].items():
                 i = int(k)
                 o, n = self.arena.slice_of(i)
+                if st["exp_avg"].numel() != n or st["exp_avg_sq"].numel() != n:
+                    raise ValueError(f"optimizer state of parameter {i} has {st['exp_avg'].numel()} elements, the "
+                                     f"parameter {n}")
                 self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
                 steps.add(int(float(st["step"])))

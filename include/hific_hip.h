@@ -94,6 +94,13 @@ int hific_scale_shift(const void* x, void* y, long long n, float a, float b, int
 /* residual adds: src/network/generator.py:44,161; also gradient fan-in sums */
 int hific_add(const void* a, const void* b, void* o, long long n, int dtype, hipStream_t stream);
 int hific_cast(const void* a, int src_dtype, void* o, int dst_dtype, long long n, hipStream_t stream);
+/* Split-bf16 operands of the exact-index mode: the Encoder -> analysis -> synthesis_mu chain whose output is floored
+ * into the latent indices (src/hyperprior.py:68-74,108-122; src/network/encoder.py:104-111) runs its forward
+ * contractions as x*w ~= xh*wh + xl*wh + xh*wl (hi = bf16(v), lo = bf16(v - hi)), i.e. over 3C reduction channels of the
+ * ordinary bf16 kernels.  src f32 [outer][C][inner] -> dst [outer][3C][inner]; which 0 = activation layout (hi, lo, hi),
+ * 1 = weight layout (hi, hi, lo); dst_dtype HIFIC_BF16 or HIFIC_F32 (values exactly bf16-representable). */
+int hific_split3(const float* src, void* dst, long long outer, int C, long long inner, int which, int dst_dtype,
+                 hipStream_t stream);
 int hific_axpby_f32(const float* a, const float* b, float* o, float alpha, float beta, long long n,
                     hipStream_t stream);
 /* out[c] = sum_{n,hw} x[n,c,hw] (bias gradients) */

@@ -91,30 +91,55 @@ def _symbols(model, inter):
     return torch.round(inter.latents_quantized.detach().float() - mu).to(torch.int64)
 
 
+def _tie_distance(model):
+    """Distance of y - mu + 0.5 from the nearest integer, from the tensors the hyperprior kept (keep_debug)."""
+    frac = (model.Hyperprior.debug_latents - model.Hyperprior.debug_latent_means + 0.5).cpu()
+    frac = frac - torch.floor(frac)
+    return torch.minimum(frac, 1 - frac)
+
+
+def _assert_tie_only(sym, sym_ref, tie, what):
+    """The index equality of the float32 tests: equal, except at most 1e-4 of the indices, each by one step and only
+    where the reference value sits within 1e-4 of a rounding tie."""
+    flips = sym != sym_ref
+    n = int(flips.sum())
+    worst = float(tie[flips].max()) if n else 0.0
+    print(f"[{what}] index flips {n}/{sym.numel()} ({100.0 * n / sym.numel():.4f} %), max tie distance {worst:.2e}")
+    assert n <= max(2, 1e-4 * sym.numel()), n
+    assert worst < 1e-4, worst
+    assert int(((sym - sym_ref).abs() > 1).sum()) == 0
+    return n
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_reference_golden_replay_bf16(hific, dev, case):
-    """The fast mode on the reference's own vectors: same quantities, bf16 bounds; index flips vs the f32 mode."""
+    """The benchmarked mode (bf16 MFMA + exact-index chain) on the reference's own vectors: the
+    quantised latents obey the SAME assertions as the float32 replay (patch within 1e-3, sum within one symbol, indices
+    equal to the float32 device run except at rounding ties); losses / rates / reconstruction statistics carry the
+    rounding of the bf16 Generator and loss networks (bounds = 3x what was measured)."""
+    from hific_amd import ops
+    assert ops.exact_index_on()
     g, m32, _, i32, _ = _run_case(hific, dev, case, torch.float32)
     sym32 = _symbols(m32, i32).cpu()
+    tie = _tie_distance(m32)
     g, model, losses, inter, grads = _run_case(hific, dev, case, torch.bfloat16)
     sym16 = _symbols(model, inter).cpu()
-    flips = int((sym16 != sym32).sum())
-    big = int(((sym16 - sym32).abs() > 1).sum())
+    _assert_tie_only(sym16, sym32, tie, f"bf16 exact-index vs f32 device, {case}")
+    dec = inter.latents_quantized.detach().float().cpu()
+    assert float((dec[:, :4, :3, :3] - g["latents_patch"]).abs().max()) < 1e-3
+    assert abs(float(dec.sum()) - g["latents_sum"]) < 2.5 + 1e-3 * abs(g["latents_sum"])   # <= two tie flips
     rec = inter.reconstruction.detach().float().cpu()
     worst_g = max([_rel(grads[k], n) for k, n in g.get("grad_norms", {}).items()] or [0.0])
-    print(f"\n[bf16 vs reference] {case}: loss rel {_rel(float(losses['compression']), g['compression']):.2e}, "
+    print(f"[bf16 vs reference] {case}: loss rel {_rel(float(losses['compression']), g['compression']):.2e}, "
           f"n_bpp rel {_rel(float(inter.n_bpp), g['n_bpp']):.2e}, q_bpp rel {_rel(float(inter.q_bpp), g['q_bpp']):.2e}, "
           f"recon patch abs {float((rec[:, :, :6, :6] - g['recon_patch']).abs().max()):.2e}, "
-          f"worst grad-norm rel {worst_g:.2e}, index flips {flips}/{sym32.numel()} "
-          f"({100.0 * flips / sym32.numel():.2f} %), off by more than one: {big}")
-    # measured (round 2): loss 5e-4, bpp 1e-3, 0.34-0.44 % of the indices flip by one step; a flipped index moves the
-    # decoded latent by 1.0, so pointwise reconstruction / Discriminator-gradient errors are dominated by the flips
-    # (patch 0.2 abs, D-turn gradient norms 0.13): those are reported, the aggregate quantities are bounded
-    assert _rel(float(losses["compression"]), g["compression"]) < 1e-2
-    assert _rel(float(inter.n_bpp), g["n_bpp"]) < 1e-2 and _rel(float(inter.q_bpp), g["q_bpp"]) < 1e-2
-    assert abs(float(rec.mean()) - g["recon_mean"]) < 2e-2 * g["recon_std"] and _rel(float(rec.std()), g["recon_std"]) < 2e-2
+          f"recon mean abs {abs(float(rec.mean()) - g['recon_mean']):.2e} std rel {_rel(float(rec.std()), g['recon_std']):.2e}, "
+          f"worst grad-norm rel {worst_g:.2e}")
+    # rates depend only on the exact chain + float32 entropy kernels (+ the bf16 synthesis_std net on the latent rate)
+    assert _rel(float(inter.n_bpp), g["n_bpp"]) < 3e-3 and _rel(float(inter.q_bpp), g["q_bpp"]) < 3e-3
+    assert _rel(float(losses["compression"]), g["compression"]) < 5e-3
+    assert abs(float(rec.mean()) - g["recon_mean"]) < 1e-2 * g["recon_std"] and _rel(float(rec.std()), g["recon_std"]) < 1e-2
     assert worst_g < (0.25 if not g["train_generator"] else 8e-2)
-    assert flips <= 0.02 * sym32.numel() and big == 0
     if g["gan"]:
         assert _rel(float(losses["disc"]), g["disc"]) < 3e-2
 
@@ -175,27 +200,55 @@ def test_fullsize_f32_matches_oracle(hific, dev, fullsize_oracle):
     assert _relerr(inter.reconstruction.detach().float().cpu(), rec_ref) < 1e-3
 
 
-def test_fullsize_bf16_reported_against_oracle(hific, dev, fullsize_oracle):
-    """The benchmarked mode (bf16 MFMA, f32 accumulate) at the benchmarked shape: error and index flip rate vs the
-    oracle.  bf16 activations move the latents by ~1e-2 relative, so indices near a rounding tie flip: the rate is
-    reported and bounded; no index may move by more than one step."""
+def test_fullsize_bf16_exact_index_against_oracle(hific, dev, fullsize_oracle):
+    """The benchmarked mode (bf16 MFMA, f32 accumulate, exact-index chain) at the benchmarked shape: the 901 120 quantised
+    indices obey the float32 test's tie-aware equality against the ORACLE; rates within 1e-3; given equal indices the
+    reconstruction differs from the oracle Generator's only by the bf16 rounding of the Generator's activations."""
+    from hific_amd import ops
+    assert ops.exact_index_on()
     fo = fullsize_oracle
     out = fo["out"]
     hi = out["hyperinfo"]
     model, losses, inter = _run_fullsize(hific, dev, fo, torch.bfloat16)
     sym_o = O.quantized_indices(out["y"], hi.latent_means)
     sym_h = _symbols(model, inter).cpu()
-    flips = int((sym_h != sym_o).sum())
-    big = int(((sym_h - sym_o).abs() > 1).sum())
+    frac = out["y"] - hi.latent_means + 0.5
+    frac = frac - torch.floor(frac)
+    n_flips = _assert_tie_only(sym_h, sym_o, torch.minimum(frac, 1 - frac), "bf16 exact-index full size vs oracle")
+    y_err = _relerr(model.Hyperprior.debug_latents.cpu(), out["y"])
+    mu_err = _relerr(model.Hyperprior.debug_latent_means.cpu(), hi.latent_means)
     rec = inter.reconstruction.detach().float().cpu()
-    err_rec = _relerr(rec, out["reconstruction"])
-    print(f"\n[bf16 full size vs oracle] loss rel {_rel(float(losses['compression']), float(out['compression'])):.2e}, "
+    rec_ref = out["reconstruction"]
+    if n_flips:
+        with torch.no_grad():
+            rec_ref = O.generator_forward(fo["sd"], inter.latents_quantized.detach().float().cpu(), 9)
+    err_rec = _relerr(rec, rec_ref)
+    rms_rec = float((rec - rec_ref).pow(2).mean().sqrt() / rec_ref.pow(2).mean().sqrt())
+    print(f"\n[bf16 exact-index full size vs oracle] latents max-rel {y_err:.2e}, means max-rel {mu_err:.2e}, "
+          f"loss rel {_rel(float(losses['compression']), float(out['compression'])):.2e}, "
           f"n_bpp rel {_rel(float(inter.n_bpp), float(hi.total_nbpp)):.2e}, "
-          f"q_bpp rel {_rel(float(inter.q_bpp), float(hi.total_qbpp)):.2e}, reconstruction max-rel {err_rec:.2e}, "
-          f"index flips {flips}/{sym_o.numel()} ({100.0 * flips / sym_o.numel():.3f} %), off by >1: {big}")
-    # measured (round 2): loss 2.3e-4, bpp 3e-4, index flips 0.394 % (all by one step), reconstruction max-rel 0.12
-    # (flip-dominated: see the golden replay above)
-    assert _rel(float(losses["compression"]), float(out["compression"])) < 1e-2
-    assert _rel(float(inter.q_bpp), float(hi.total_qbpp)) < 1e-2
-    assert flips <= 0.02 * sym_o.numel() and big == 0
-    assert err_rec < 0.3
+          f"q_bpp rel {_rel(float(inter.q_bpp), float(hi.total_qbpp)):.2e}, "
+          f"reconstruction given equal indices: max-rel {err_rec:.2e}, rms-rel {rms_rec:.2e}")
+    assert y_err < 1e-4 and mu_err < 1e-4
+    assert _rel(float(inter.n_bpp), float(hi.total_nbpp)) < 3e-3
+    assert _rel(float(inter.q_bpp), float(hi.total_qbpp)) < 3e-3
+    assert _rel(float(losses["compression"]), float(out["compression"])) < 5e-3
+    # 20 bf16 convolutions deep: the reconstruction carries bf16 activation rounding (2^-9 per element per layer)
+    assert err_rec < 5e-2 and rms_rec < 1e-2
+
+
+def test_fullsize_plain_bf16_chain_is_what_the_exact_mode_fixes(hific, dev, fullsize_oracle):
+    """HIFIC_EXACT_INDEX=0 behaviour kept for comparison: plain bf16 Encoder / hyper nets flip ~0.4 % of the indices."""
+    from hific_amd import ops
+    fo = fullsize_oracle
+    out = fo["out"]
+    ops.set_exact_index(False)
+    try:
+        model, losses, inter = _run_fullsize(hific, dev, fo, torch.bfloat16)
+    finally:
+        ops.set_exact_index(True)
+    sym_o = O.quantized_indices(out["y"], out["hyperinfo"].latent_means)
+    sym_h = _symbols(model, inter).cpu()
+    flips = int((sym_h != sym_o).sum())
+    print(f"\n[plain bf16 chain] index flips {flips}/{sym_o.numel()} ({100.0 * flips / sym_o.numel():.3f} %)")
+    assert 0 < flips <= 0.02 * sym_o.numel() and int(((sym_h - sym_o).abs() > 1).sum()) == 0

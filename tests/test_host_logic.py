@@ -214,3 +214,36 @@ def test_option_variants_keep_the_reference_layout(hific):
     assert tuple(pl._t["features.28.weight"].shape) == (512, 512, 3, 3)
     with pytest.raises(NotImplementedError):
         PerceptualLoss(net='squeeze', use_gpu=False, allow_random_backbone=True)
+
+
+def test_arena_slots_written_by_autograd_are_tracked(hific):
+    """A parameter whose gradient comes from ATen (the InstanceNorm fallback's affine pair) is accumulated in place into
+    its arena slot by autograd: the slot must count as written (zero_unwritten keeps it, buckets see it) and must be
+    cleared by zero_grad() - otherwise the next step adds onto stale values."""
+    import torch
+    from hific_amd import optim
+    from hific_amd.normalisation import instance
+    torch.manual_seed(0)
+    norm = instance.InstanceNorm2D_wrap(6, fuse_relu=True)
+    arena = optim.ParamArena(list(norm.parameters()))
+    seen = []
+    arena.on_write = lambda slot: seen.append(slot.index)
+    x = torch.randn(2, 6, 5, 5)
+
+    def grads():
+        ref = torch.nn.InstanceNorm2d(6, affine=True)
+        ref.load_state_dict({"weight": norm.weight.detach().clone(), "bias": norm.bias.detach().clone()})
+        torch.relu(ref(x)).square().sum().backward()
+        return ref.weight.grad, ref.bias.grad
+
+    for step in range(3):
+        torch.relu(norm(x) if not norm.fuse_relu else norm(x)).square().sum().backward()
+        gw, gb = grads()
+        assert all(not s.fresh and s.autograd for s in arena.slots)
+        assert torch.allclose(arena.slots[0].grad, gw, atol=1e-5) and torch.allclose(arena.slots[1].grad, gb, atol=1e-5)
+        assert norm.weight.grad.data_ptr() == arena.flat_grad.data_ptr()
+        arena.zero_unwritten()                       # what FusedAdam.step does first: must not wipe these
+        assert torch.allclose(arena.slots[0].grad, gw, atol=1e-5)
+        arena.zero_grad()
+        assert float(arena.flat_grad.abs().max()) == 0.0 and all(s.fresh for s in arena.slots)
+    assert sorted(set(seen)) == [0, 1]
