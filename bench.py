@@ -19,8 +19,17 @@ The same JSON line also carries (N = 1 only, measured in the same process right 
     launch stream (in-library profiler; single-stream execution for these steps, see profile_kernels), algorithmic FLOPs on the op's real output domain, against the dense bf16
     MFMA peak; `traffic` = HBM bytes per launch of that kernel from two rocprofv3 --pmc passes (FETCH_SIZE,
     WRITE_SIZE) of a short child run of this script, or null
-  * `cpu_baseline`: the oracle (CPU restatement of the reference) on the host cores, bounded sample of the same
-    G-D cycle
+  * `parity`: the benchmarked mode against the oracle, measured in this process at the benchmarked shape (batch 16 x 256^2,
+    same weights / images / noise): quantised-index flip rate (+ worst distance of a flipped index from a rounding tie),
+    relative error of the loss and of both rates
+  * `f32`: the same cycle in float32 parity mode (images/s of the mode whose parity bar is 1e-3 everywhere)
+  * `config5_1gpu`: BASELINE configs[4] per-GPU shape (regime high, ONE 1024 x 1024 crop per turn)
+  * `cpu_baseline`: the REFERENCE's own modules (unpacked from oracle/_ref/reference_src.tar.gz; kind "reference") or, if
+    that archive is missing, the oracle port, on the host cores: bounded sample of the same G-D cycle at BASELINE
+    configs[0]'s batch 4, all-core and best thread count, plus the src.model smoke forward (batch 10) the reference
+    publishes a time for
+With N > 1: `rccl` = ranks, buckets per reducer and `exposed_comm_ms` (GPU time per step the compute stream waits in
+BucketedGradReducer.finish() for collectives the backward pass did not hide).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -60,7 +69,10 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--cpu-timeout", type=int, default=240)
+    ap.add_argument("--cpu-timeout", type=int, default=300)
+    ap.add_argument("--regime", default="low", choices=["low", "med", "high"])
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-process oracle comparison")
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -73,8 +85,8 @@ def build(args, dev, config):
     from hific_amd.default_config import make_args, mse_lpips_args, hific_args, ModelTypes
     hific_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     gan = config == "gan"
-    torch.manual_seed(0)
-    margs = make_args(hific_args if gan else mse_lpips_args, batch_size=args.batch,
+    torch.manual_seed(args.seed)                 # identical initial weights on every rank
+    margs = make_args(hific_args if gan else mse_lpips_args, regime=getattr(args, "regime", "low"), batch_size=args.batch,
                       image_dims=(3, args.size, args.size), latent_dims=(220, args.size // 16, args.size // 16))
     model = hific_amd.Model(margs, model_type=ModelTypes.COMPRESSION_GAN if gan else ModelTypes.COMPRESSION,
                             device_rate_select=True, allow_random_lpips_backbone=True)
@@ -92,6 +104,9 @@ def build(args, dev, config):
     # hyper (14 080 parameters, a module applied twice per forward) and disc (written by both turns): one
     # all-reduce in finish()
     reducers = {k: parallel.BucketedGradReducer(o.arena, eager=(k == "amort")) for k, o in opts.items()}
+    # weights are built: from here on the default generators (host and device) draw the quantisation noise
+    # (src/hyperprior.py:65) - a different stream on every rank (ranks must not share their noise)
+    torch.manual_seed(args.seed + 1000003 * (1 + int(os.environ.get("RANK", "0"))))
     return model, opts, reducers
 
 
@@ -271,18 +286,110 @@ def _cpu_baseline_worker(size, B, steps, threads, gan):
     print(json.dumps({"images_per_s": B * (2 if gan else 1) / t, "step_s": t}), flush=True)
 
 
+REF_TAR = os.path.join(ROOT, "oracle", "_ref", "reference_src.tar.gz")
+
+
+def _cpu_reference_worker(size, B, steps, thread_counts, gan, fwd_batch):
+    """Child process, no GPU: the REFERENCE's own modules (src.model.Model and everything under it, unpacked from
+    oracle/_ref/reference_src.tar.gz) driven the way train.py:119-141 drives them - G-turn (backward, Adam on the
+    amortisation + hyperprior-density groups), then D-turn on the next batch (Adam on the Discriminator), the three
+    torch.optim.Adam of train.py:287-301 - for each thread count; then the src.model smoke forward (model.py:443-463)."""
+    import tarfile
+    import numpy as np
+    import torch
+    from oracle import ref_loader
+    root = tempfile.mkdtemp(prefix="hific_ref_", dir="/tmp")
+    with tarfile.open(REF_TAR) as tar:
+        tar.extractall(root)
+    # the archive holds sources only: the LPIPS linear heads (6 KB, v0.1) are written from the package's copy of them
+    wdir = os.path.join(root, "src", "loss", "perceptual_similarity", "weights", "v0.1")
+    os.makedirs(wdir, exist_ok=True)
+    lw = np.load(os.path.join(ROOT, "high-fidelity-generative-compression_amd", "loss", "weights", "lpips_alex_lin_v0.1.npz"))
+    torch.save({f"lin{i}.model.1.weight": torch.from_numpy(lw[f"lin{i}"].copy()).reshape(1, -1, 1, 1) for i in range(5)},
+               os.path.join(wdir, "alex.pth"))
+    ns = ref_loader.load(root)
+    torch.manual_seed(0)
+    model = ref_loader.build_reference_model(ns, gan=gan, batch_size=B, image_dims=(3, size, size),
+                                             latent_dims=(220, size // 16, size // 16))
+    amort = [p for m in model.amortization_models for p in m.parameters()]
+    hyper = list(model.Hyperprior.hyperlatent_likelihood.parameters())
+    opt_a, opt_h = torch.optim.Adam(amort, lr=1e-4), torch.optim.Adam(hyper, lr=1e-4)
+    opt_d = torch.optim.Adam(model.Discriminator.parameters(), lr=1e-4) if gan else None
+    g = torch.Generator().manual_seed(1)
+
+    def cycle():
+        x = torch.rand((B, 3, size, size), generator=g)
+        losses = model(x, train_generator=True)
+        losses["compression"].backward()
+        opt_a.step(); opt_h.step(); opt_a.zero_grad(); opt_h.zero_grad()
+        if gan:
+            x = torch.rand((B, 3, size, size), generator=g)
+            losses = model(x, train_generator=False)
+            losses["disc"].backward()
+            opt_d.step(); opt_d.zero_grad()
+
+    res = {"per_threads": {}}
+    for th in thread_counts:
+        torch.set_num_threads(th)
+        cycle()                                              # warm-up at this thread count
+        ts = []
+        for _ in range(steps):
+            t0 = time.time(); cycle(); ts.append(time.time() - t0)
+        t = sorted(ts)[len(ts) // 2]
+        res["per_threads"][str(th)] = round(B * (2 if gan else 1) / t, 4)
+    best = max(res["per_threads"], key=lambda k: res["per_threads"][k])
+    res["best_threads"], res["images_per_s"] = int(best), res["per_threads"][best]
+    if fwd_batch:
+        torch.set_num_threads(int(best))
+        x = torch.randn((fwd_batch, 3, size, size), generator=g)
+        with torch.no_grad():
+            model(x)
+            t0 = time.time(); model(x); res["fwd_s"] = round(time.time() - t0, 3)
+    shutil.rmtree(root, ignore_errors=True)
+    print(json.dumps(res), flush=True)
+
+
 def cpu_baseline(args):
-    """The oracle ("port" of the reference's CPU path) timed on this box's host cores on a bounded sample of the
-    headline workload, in a child process with a hard time limit so the GPU line can never be lost to it."""
+    """the reference modules on this box's host cores - in a child process with a hard time limit so
+    the GPU line can never be lost to it.  kind "reference" (the reference's own src.model.Model, from oracle/_ref) or, when
+    that archive did not travel, "port" (the oracle restatement).  Bounded sample: batch 4 (BASELINE configs[0]), one
+    warm-up + `--cpu-steps` timed G-D cycles per thread count (all logical cores, half of them, 32)."""
     ncores = os.cpu_count() or 1
-    threads = min(ncores, int(os.environ.get("HIFIC_CPU_THREADS", "32")))
     gan = args.config == "gan"
+    what = "compression_gan G-turn + D-turn cycle" if gan else "compression training step"
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    env.pop("OMP_NUM_THREADS", None)
+    if os.path.exists(REF_TAR) and os.environ.get("HIFIC_CPU_BASELINE", "reference") == "reference":
+        ths = sorted({ncores, max(1, ncores // 2), min(ncores, 32)}, reverse=True)
+        cmd = [sys.executable, "-c",
+               f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
+               f"bench._cpu_reference_worker({args.size}, {args.cpu_batch}, {args.cpu_steps}, {ths}, {gan}, 10)"]
+        sample = (f"reference modules (src.model.Model from oracle/_ref, torch CPU float32) {what} as train.py:119-141 runs "
+                  f"it (fwd + bwd + 3x torch.optim.Adam), batch {args.cpu_batch} per turn (BASELINE configs[0] batch), "
+                  f"{args.size}x{args.size}, 1 warm-up + {args.cpu_steps} timed (median) at each of {ths} threads of "
+                  f"{ncores} logical cores; value = best")
+        try:
+            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_timeout)
+            r = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+            out = {"value": r["images_per_s"], "unit": "images/s", "cores": r["best_threads"], "kind": "reference",
+                   "sample": sample, "images_per_s_by_threads": r["per_threads"],
+                   "all_core_images_per_s": r["per_threads"].get(str(ncores))}
+            if "fwd_s" in r:
+                out["src_model_forward_b10_s"] = r["fwd_s"]
+                out["src_model_forward_b10_note"] = ("src/model.py:443-463 smoke forward (GAN model, batch 10 x 256^2, both "
+                                                     "losses); the reference publishes ~45 s on a 2.8 GHz Core i7 "
+                                                     "(src/README.md:112)")
+            return out
+        except Exception as e:
+            why = f"reference worker failed ({type(e).__name__}); "
+    else:
+        why = ""
+    threads = min(ncores, int(os.environ.get("HIFIC_CPU_THREADS", "32")))
     cmd = [sys.executable, "-c",
            f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
            f"bench._cpu_baseline_worker({args.size}, {args.cpu_batch}, {args.cpu_steps}, {threads}, {gan})"]
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
-    sample = (f"oracle (torch-CPU float32 restatement of the reference) "
-              f"{'compression_gan G-turn + D-turn cycle' if gan else 'compression training step'} (fwd + bwd + Adam), batch "
+    env["OMP_NUM_THREADS"] = str(threads)
+    sample = (f"{why}oracle (torch-CPU float32 restatement of the reference) {what} (fwd + bwd + Adam), batch "
               f"{args.cpu_batch} per turn, {args.size}x{args.size}, 1 warm-up + {args.cpu_steps} timed (median), "
               f"{threads} threads of {ncores} logical cores")
     try:
@@ -293,6 +400,71 @@ def cpu_baseline(args):
     except Exception as e:
         return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
                 "sample": sample + f" -- FAILED: {type(e).__name__}"}
+
+
+# ---- parity of the benchmarked mode, measured in this process ---------------------------------------------------------
+def parity_leg(args, dev):
+    """The benchmarked mode against the oracle (the checker, CPU float32) on the benchmark's own shape: same seeded
+    weights, images and quantisation noise through hific_amd.Model (G-turn forward of the headline model) and through
+    oracle.model_forward.  north_star: quantised latent indices bit-exact, outputs within 1e-3."""
+    import numpy as np
+    import torch
+    import hific_amd
+    from hific_amd import ops as hops
+    from hific_amd.default_config import make_args, mse_lpips_args, hific_args, ModelTypes
+    from oracle import hific_oracle as O
+    gan = args.config == "gan"
+    B, S = args.batch, args.size
+    hific_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    margs = make_args(hific_args if gan else mse_lpips_args, regime=args.regime, batch_size=B, image_dims=(3, S, S),
+                      latent_dims=(220, S // 16, S // 16))
+    model = hific_amd.Model(margs, model_type=ModelTypes.COMPRESSION_GAN if gan else ModelTypes.COMPRESSION,
+                            allow_random_lpips_backbone=True)
+    sd, bb = O.make_state_dict(seed=0, gan=gan), O.make_alex_backbone()
+    model.load_state_dict(sd, strict=True)
+    model.perceptual_loss.load_backbone_state_dict(bb)
+    model = model.to(dev).train()
+    model.Hyperprior.keep_debug = True
+    x = O.make_image(3, B, S, S)
+    nh, nl = O.make_noise(6, (B, 320, S // 64, S // 64)), O.make_noise(7, (B, 220, S // 16, S // 16))
+    noises = [nh.to(dev), nl.to(dev)]
+    model.Hyperprior._draw_noise = lambda t: noises.pop(0)
+    with torch.no_grad():
+        losses, inter = model(x.to(dev), train_generator=True, return_intermediates=True, writeout=False)
+    torch.cuda.synchronize()
+    sym = torch.round(inter.latents_quantized.float() - model.Hyperprior.debug_latent_means).cpu()
+    got = dict(loss=float(losses["compression"]), n_bpp=float(inter.n_bpp), q_bpp=float(inter.q_bpp))
+    rec = inter.reconstruction.float().cpu()
+    del model, losses, inter
+    hops.pack_cache.clear(); hops.split_weights.clear()
+    torch.cuda.empty_cache()
+    lw = np.load(os.path.join(ROOT, "high-fidelity-generative-compression_amd", "loss", "weights", "lpips_alex_lin_v0.1.npz"))
+    lins = [torch.from_numpy(lw[f"lin{i}"].copy()) for i in range(5)]
+    oargs = dict(lambda_A=margs.lambda_A, target_rate=margs.target_rate)
+    with torch.no_grad():
+        out = O.model_forward(sd, bb, lins, x, step_counter=1, training=True, gan=gan, train_generator=True,
+                              noise_hyper=nh, noise_latent=nl, args=oargs)
+    hi = out["hyperinfo"]
+    sym_o = torch.floor(out["y"] - hi.latent_means + 0.5)
+    flips = sym != sym_o
+    nflip = int(flips.sum())
+    frac = out["y"] - hi.latent_means + 0.5
+    frac = frac - torch.floor(frac)
+    tie = torch.minimum(frac, 1 - frac)
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-30)
+    res = {"against": "oracle (CPU float32 restatement of the reference), same weights / images / noise, "
+                      f"batch {B} x {S}x{S}, {'compression_gan' if gan else 'compression'} G-turn forward",
+           "mode": f"{args.dtype}" + (" + exact-index chain" if args.dtype == "bf16" and hops.exact_index_on() else ""),
+           "n_indices": flips.numel(), "index_flips": nflip, "index_flip_rate": nflip / flips.numel(),
+           "max_tie_distance_of_flips": float(tie[flips].max()) if nflip else 0.0,
+           "flips_by_more_than_one": int(((sym - sym_o).abs() > 1).sum()),
+           "loss_rel": rel(got["loss"], float(out["compression"])), "nbpp_rel": rel(got["n_bpp"], float(hi.total_nbpp)),
+           "qbpp_rel": rel(got["q_bpp"], float(hi.total_qbpp))}
+    if nflip == 0:
+        ref = out["reconstruction"]
+        res["reconstruction_rms_rel"] = float((rec - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        res["reconstruction_max_rel"] = float((rec - ref).abs().max() / ref.abs().max())
+    return {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in res.items()}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -336,11 +508,26 @@ def main():
     if args.traffic_child:                       # counter pass of measure_traffic(): a few steps, nothing else
         timed(step, args.steps, args.warmup, fence)
         return
+    if use_dist:
+        for r in reducers.values():
+            r.measure_exposed(True)              # two event records per finish(): read after the timed region
     elapsed = timed(step, args.steps, args.warmup, fence)
+    rccl = None
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # (warm-up steps are included in the event pairs: average over all measured steps)
+        exp_ms = sum(r.exposed_comm_ms() for r in reducers.values()) / (args.steps + args.warmup)
+        t = torch.tensor([exp_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rccl = {"backend": "nccl (RCCL)", "rccl_ranks": world,
+                "buckets": {k: len(r.buckets) for k, r in reducers.items()},
+                "bucket_mbytes": float(os.environ.get("HIFIC_BUCKET_MB", 128)),
+                "gradient_mbytes_per_step": {k: round(r.arena.numel * 4 / 2 ** 20, 1) for k, r in reducers.items()},
+                "exposed_comm_ms": round(float(t.item()), 3),
+                "exposed_comm_note": "GPU time per step the compute stream waits in BucketedGradReducer.finish() for "
+                                     "collectives the backward pass did not hide (max over ranks)"}
     imgs_per_step = args.batch * (2 if cfg == "gan" else 1)
     value = world * imgs_per_step * args.steps / elapsed
     ms_step = elapsed / args.steps * 1e3
@@ -352,7 +539,7 @@ def main():
         "metric": "training images/sec (256x256) HiFIC-low", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"HiFIC-low {what}, batch {args.batch}/GPU/turn, {args.size}x{args.size} RGB, "
+        "config": {"workload": f"HiFIC-{args.regime} {what}, batch {args.batch}/GPU/turn, {args.size}x{args.size} RGB, "
                                f"{args.dtype} MFMA compute, f32 master weights, fwd+bwd+Adam, random-init weights "
                                f"(BASELINE configs[{2 if cfg == 'gan' else 1}])",
                    "images_per_step": world * imgs_per_step, "global_batch": world * args.batch,
@@ -361,6 +548,11 @@ def main():
                        "whole_step_tflops_per_gpu": round(tflop_step / (ms_step * 1e-3), 1),
                        "whole_step_frac_of_mfma_peak": round(tflop_step / (ms_step * 1e-3) / peak, 4)},
     }
+    if args.dtype == "bf16":
+        from hific_amd import ops as _ops
+        out["config"]["exact_index_chain"] = bool(_ops.exact_index_on())
+    if rccl is not None:
+        out["rccl"] = rccl
     extras = world == 1 and not args.no_extras
     if extras:
         from hific_amd import ops as hific_ops
@@ -416,7 +608,47 @@ def main():
                       "ms_per_batch": round(per_img * args.batch, 3), "images_per_s": round(1e3 / per_img, 1),
                       "tflops": round(GFLOP_PER_IMAGE["forward"] * (args.size / 256.0) ** 2 / 1e3 / (per_img * 1e-3), 1)}
         del ev
+        hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
         torch.cuda.empty_cache()
+        default_shape = args.size == 256 and args.regime == "low"
+        # ---- the same cycle in float32 parity mode (f32 MFMA: exact fma chains) ---------------------------------------
+        if args.dtype == "bf16" and default_shape:
+            a32 = argparse.Namespace(**vars(args)); a32.dtype = "f32"
+            m3, o3, r3 = build(a32, dev, cfg)
+            s3 = make_step(a32, m3, o3, r3, dev, cfg)
+            n3 = max(2, min(args.steps, 4))
+            e3 = timed(s3, n3, 1, fence)
+            out["f32"] = {"value": round(imgs_per_step * n3 / e3, 3), "unit": "images/s", "ms_per_step": round(e3 / n3 * 1e3, 3),
+                          "workload": "the headline cycle in float32 parity mode (v_mfma_f32_32x32x2_f32, f32 activations): "
+                                      "every output within 1e-3 of the oracle (tests/test_gpu_golden.py, "
+                                      "tests/test_gpu_fullsize_backward.py)",
+                          "whole_step_frac_of_f32_mfma_peak": round(tflop_step / (e3 / n3) / MFMA_PEAK_TFLOPS["f32"], 4)}
+            del m3, o3, r3, s3
+            hific_amd.set_compute_dtype(torch.bfloat16)
+            hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
+            torch.cuda.empty_cache()
+        # ---- BASELINE configs[4] per-GPU shape: regime high, one 1024 x 1024 crop per turn ---------------------------
+        if cfg == "gan" and default_shape:
+            a5 = argparse.Namespace(**vars(args)); a5.size, a5.batch, a5.regime = 1024, 1, "high"
+            m5, o5, r5 = build(a5, dev, "gan")
+            s5 = make_step(a5, m5, o5, r5, dev, "gan")
+            n5 = max(3, min(args.steps, 10))
+            e5 = timed(s5, n5, 2, fence)
+            out["config5_1gpu"] = {"value": round(2 * n5 / e5, 3), "unit": "images/s (1024x1024)",
+                                   "ms_per_step": round(e5 / n5 * 1e3, 3),
+                                   "workload": f"BASELINE configs[4] on one GPU: compression_gan regime high, G-turn + D-turn "
+                                               f"cycle, 1 x 1024x1024 crop per turn, {args.dtype}, fwd+bwd+Adam",
+                                   "megapixels_per_s": round(2 * n5 * 1.048576 / e5, 2),
+                                   "whole_step_tflops": round(tflop_step / args.batch * 16 / (e5 / n5), 1)}
+            del m5, o5, r5, s5
+            hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
+            torch.cuda.empty_cache()
+        # ---- parity of the benchmarked mode vs the oracle, at the benchmarked shape ---------------------------------
+        if not args.no_parity:
+            try:
+                out["parity"] = parity_leg(args, dev)
+            except Exception as e:                      # the throughput line must survive a checker failure
+                out["parity"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_traffic and os.environ.get("HIFIC_BENCH_PMC", "1") != "0":
             traffic, why = measure_traffic(args, dom)
         out["roofline"]["traffic"] = traffic

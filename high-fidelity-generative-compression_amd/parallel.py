@@ -64,6 +64,9 @@ class BucketedGradReducer:
                 i = key if isinstance(key, int) else index_of[id(key)]
                 self.expected[i] = int(n)
         self.works = []
+        # exposed communication: GPU time the launching stream spends in finish() waiting for collectives that the backward
+        # pass did not hide (event pairs, read by exposed_comm_ms() after a synchronize); off unless measure_exposed(True)
+        self._measure, self._ev_pairs = False, []
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('HIFIC_FORCE_DIST') == '1')
         self.eager = bool(eager)
         self._reset()
@@ -118,11 +121,29 @@ class BucketedGradReducer:
             for b in range(len(self.buckets)):
                 if not self.launched[b]:
                     self._launch(b)
+            timed = self._measure and self.arena.flat_grad.is_cuda
+            if timed:
+                cur = torch.cuda.current_stream(self.arena.flat_grad.device)
+                e0 = torch.cuda.Event(enable_timing=True); e0.record(cur)
             for w in self.works:
                 w.wait()
+            if timed:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record(cur)
+                self._ev_pairs.append((e0, e1))
         self.works = []
         self._reset()
         return 1.0 / self.world
+
+
+    def measure_exposed(self, on=True):
+        self._measure, self._ev_pairs = bool(on), []
+
+    def exposed_comm_ms(self):
+        """Total GPU time (ms) the launching stream waited inside finish() since measure_exposed(True); call after a
+        device synchronize.  0.0 when nothing was measured."""
+        ms = sum(a.elapsed_time(b) for a, b in self._ev_pairs)
+        self._ev_pairs = []
+        return ms
 
 
 def allreduce_scalar_mean(t, process_group=None):

@@ -162,9 +162,12 @@ def latent_likelihood(x, mean, scale, likelihood_type="gaussian"):
 
 
 def hyperprior_forward(sd, latents, spatial_shape, training=True, noise_hyper=None, noise_latent=None,
-                       likelihood_type="gaussian", prefix="Hyperprior."):
+                       likelihood_type="gaussian", prefix="Hyperprior.", symbols_override=None):
     """src/hyperprior.py:277-330.  The two uniform(-.5,.5) noise tensors are explicit arguments (the reference
-    draws them from the global RNG, hyperlatent noise first: hyperprior.py:283,305)."""
+    draws them from the global RNG, hyperlatent noise first: hyperprior.py:283,305).
+    `symbols_override` (test harness only, default None = the reference's arithmetic): integer latent symbols to use in
+    place of floor(y - mu + 0.5) - lets a test compare everything DOWNSTREAM of the quantiser "given equal indices" when
+    the device decided a rounding tie (|frac - .5| < 1e-4, asserted by the caller) the other way."""
     z = hyper_analysis_forward(sd, latents, prefix + "analysis_net.")
     if noise_hyper is None:
         noise_hyper = torch.empty_like(z).uniform_(-0.5, 0.5)
@@ -179,11 +182,12 @@ def hyperprior_forward(sd, latents, spatial_shape, training=True, noise_hyper=No
         noise_latent = torch.empty_like(latents).uniform_(-0.5, 0.5)
     noisy_y = latents + noise_latent
     _, ny_bpp = estimate_entropy(latent_likelihood(noisy_y, means, scales, likelihood_type), spatial_shape)
-    quant_y = torch.floor(latents - means + 0.5) + means
+    sym = torch.floor(latents - means + 0.5) if symbols_override is None else symbols_override.to(latents.dtype)
+    quant_y = sym.detach() + means
     _, qy_bpp = estimate_entropy(latent_likelihood(quant_y, means, scales, likelihood_type), spatial_shape)
     # quantize_latents_st (hyperprior.py:108-122)
     vals = latents - means
-    decoded = vals + (torch.floor(vals + 0.5) - vals).detach() + means
+    decoded = vals + (sym - vals).detach() + means
     return HyperInfo(decoded, ny_bpp, nz_bpp, ny_bpp + nz_bpp, qy_bpp, qz_bpp, qy_bpp + qz_bpp, means, scales, z)
 
 
@@ -300,13 +304,13 @@ DEFAULT_ARGS = dict(k_M=0.075 * 2 ** (-5), k_P=1., beta=0.15, lambda_B=2 ** (-4)
 
 
 def model_forward(sd, backbone, lins, x, step_counter=1, training=True, gan=False, train_generator=True,
-                  noise_hyper=None, noise_latent=None, args=None, n_residual_blocks=9):
+                  noise_hyper=None, noise_latent=None, args=None, n_residual_blocks=9, symbols_override=None):
     """src/model.py:346-387 (TRAINING/VALIDATION modes): returns dict(losses..., intermediates...)."""
     a = dict(DEFAULT_ARGS)
     if args:
         a.update(args)
     y = encoder_forward(sd, x)
-    hi = hyperprior_forward(sd, y, x.shape[2:], training, noise_hyper, noise_latent)
+    hi = hyperprior_forward(sd, y, x.shape[2:], training, noise_hyper, noise_latent, symbols_override=symbols_override)
     x_gen = generator_forward(sd, hi.decoded, n_residual_blocks)
     x_l, xg_l = x, x_gen
     if a.get("normalize_input_image", False):                                     # model.py:155-156, 206-209

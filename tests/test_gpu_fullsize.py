@@ -17,6 +17,16 @@ CASES = {   # (N, C, H, W, K, R, stride, pads, mode): the Generator residual con
     "encoder_s2_240_480": (16, 240, 64, 64, 480, 3, 2, (1, 0, 0, 1), "reflect"),
     "encoder_7x7_3_60": (16, 3, 256, 256, 60, 7, 1, (3, 3, 3, 3), "reflect"),
     "generator_7x7_60_3": (16, 60, 256, 256, 3, 7, 1, (3, 3, 3, 3), "reflect"),
+    # the Discriminator's 4x4 stride-2 layers at the G+D batch (32 images), the hyper-analysis 5x5 stride 2, LPIPS 5x5
+    "disc_4x4s2_15_64": (32, 15, 256, 256, 64, 4, 2, (1, 1, 1, 1), "reflect"),
+    "disc_4x4s2_128_256": (32, 128, 64, 64, 256, 4, 2, (1, 1, 1, 1), "reflect"),
+    "hyper_5x5s2_320": (16, 320, 16, 16, 320, 5, 2, (2, 2, 2, 2), "reflect"),
+    "lpips_5x5_64_192": (32, 64, 31, 31, 192, 5, 1, (2, 2, 2, 2), "zeros"),
+}
+CASES_T = {   # (N, Ci, H, W, Co, R, stride, pad, outpad): Generator up-convolutions, hyper-synthesis 5x5 stride 2
+    "up_960_480": (16, 960, 16, 16, 480, 3, 2, 1, 1),
+    "up_120_60": (16, 120, 128, 128, 60, 3, 2, 1, 1),
+    "synthesis_5x5s2_320": (16, 320, 8, 8, 320, 5, 2, 2, 1),
 }
 
 
@@ -47,6 +57,32 @@ def test_conv_adjoint_identities_full_size(hific, dev, name, dt, tol):
     assert abs(_dot(wg.grad, w2) - rhs) <= tol * max(abs(rhs), abs(lhs)) + 1e-3, name
     # linearity in x
     y3 = ops.conv2d((x.float() * 0.5).to(dt), w, None, stride, pads, pm)
+    assert float((y3.float() - 0.5 * y.detach().float()).abs().max()) <= tol * float(y.detach().float().abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CASES_T))
+def test_conv_transpose_adjoint_identities_full_size(hific, dev, name, dt, tol):
+    """Same identities for the transposed convolutions at the benchmarked sizes (sub-pixel phase kernels, merged-phase
+    sp9 kernel, strided weight-gradient plans): <gy, convT(x; w)> = <dx, x> = <dw, w>, <dw, w2> = <gy, convT(x; w2)>."""
+    from hific_amd import ops
+    N, Ci, H, W, Co, R, stride, pad, outpad = CASES_T[name]
+    hific.set_compute_dtype(dt)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = (torch.rand((N, Ci, H, W), generator=g, device=dev) * 2 - 1).to(dt)
+    w = ((torch.rand((Ci, Co, R, R), generator=g, device=dev) * 2 - 1) / (Ci * R * R) ** 0.5).to(dt).float()
+    w2 = ((torch.rand((Ci, Co, R, R), generator=g, device=dev) * 2 - 1) / (Ci * R * R) ** 0.5).to(dt).float()
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = ops.conv_transpose2d(xg, wg, None, stride, pad, outpad)
+    gy = (torch.rand(y.shape, generator=g, device=dev) * 2 - 1).to(dt)
+    y.backward(gy)
+    lhs = _dot(gy, y.detach())
+    assert abs(_dot(xg.grad, x) - lhs) <= tol * abs(lhs) + 1e-3, name
+    assert abs(_dot(wg.grad, w) - lhs) <= tol * abs(lhs) + 1e-3, name
+    y2 = ops.conv_transpose2d(x, w2, None, stride, pad, outpad)
+    rhs = _dot(gy, y2)
+    assert abs(_dot(wg.grad, w2) - rhs) <= tol * max(abs(rhs), abs(lhs)) + 1e-3, name
+    y3 = ops.conv_transpose2d((x.float() * 0.5).to(dt), w, None, stride, pad, outpad)
     assert float((y3.float() - 0.5 * y.detach().float()).abs().max()) <= tol * float(y.detach().float().abs().max()) + 1e-6
 
 

@@ -15,6 +15,18 @@ def _relerr(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-20)
 
 
+def _gtol(tol):
+    """Gradient tolerance: float32 mode holds gradients to the forward bar (1e-3 of each tensor's scale); bf16 mode to 10x
+    its forward tolerance (two bf16-rounded operands per product, sums of 10^4..10^6 terms)."""
+    return 1e-3 if tol <= 1e-3 else tol * 10
+
+
+def _check_grad(got, want, tol, what):
+    e = _relerr(got, want)
+    print(f"  grad {what}: {e:.2e} (tol {tol:.0e})")
+    assert e < tol, (what, e)
+
+
 @pytest.fixture(scope="module")
 def sd():
     return O.make_state_dict(seed=0, gan=True, n_res=N_RES)
@@ -43,7 +55,7 @@ def test_encoder(hific, dev, sd, dt, tol):
     assert _relerr(y.detach().cpu(), yr.detach()) < tol
     for k in ("conv_block1.1.weight", "conv_block3.1.weight", "conv_block5.2.gamma", "conv_block_out.1.bias"):
         got = dict(enc.named_parameters())[k].grad.cpu()
-        assert _relerr(got, sdr["Encoder." + k].grad) < tol * 10, k
+        _check_grad(got, sdr["Encoder." + k].grad, _gtol(tol), k)
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)], ids=["f32", "bf16"])
@@ -62,10 +74,10 @@ def test_generator(hific, dev, sd, dt, tol):
     x.backward(g.to(dev).to(x.dtype))
     torch.cuda.synchronize()
     assert _relerr(x.detach().float().cpu(), xr.detach()) < tol
-    assert _relerr(yd.grad.cpu(), yr_in.grad) < tol * 10
+    _check_grad(yd.grad.cpu(), yr_in.grad, _gtol(tol), "input")
     for k in ("resblock_0.conv1.weight", "upconv_block2.0.weight", "conv_block_out.1.weight", "resblock_1.norm2.beta"):
         got = dict(gen.named_parameters())[k].grad.cpu()
-        assert _relerr(got, sdr["Generator." + k].grad) < tol * 10, k
+        _check_grad(got, sdr["Generator." + k].grad, _gtol(tol), k)
 
 
 @pytest.mark.parametrize("training", [True, False])
@@ -100,11 +112,11 @@ def test_hyperprior_fp32(hific, dev, sd, training):
         tie = torch.minimum(frac, 1 - frac)
         assert int(flips.sum()) <= 2 and float(tie[flips].max()) < 1e-4, (int(flips.sum()), float(tie[flips].max()))
         assert int(((idx_h - idx_o).abs() > 1).sum()) == 0
-    assert _relerr(yd.grad.cpu(), yr.grad) < 1e-2
+    _check_grad(yd.grad.cpu(), yr.grad, 1e-3, "latents")
     params = dict(hp.named_parameters())
     for k in ("analysis_net.conv1.weight", "synthesis_mu.conv2.weight", "synthesis_std.conv3.bias",
               "hyperlatent_likelihood.H_1", "hyperlatent_likelihood.a_0", "hyperlatent_likelihood.b_3"):
-        assert _relerr(params[k].grad.cpu(), sdr["Hyperprior." + k].grad) < 1e-2, k
+        _check_grad(params[k].grad.cpu(), sdr["Hyperprior." + k].grad, 1e-3, k)
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)], ids=["f32", "bf16"])
@@ -127,9 +139,9 @@ def test_discriminator(hific, dev, sd, dt, tol):
     assert _relerr(logits.detach().cpu(), logit_r.detach()) < tol
     assert _relerr(out.cpu(), out_r.detach()) < tol
     assert _relerr(D.conv2.weight_u.cpu(), new_uv["Discriminator.conv2.weight_u"]) < 1e-4
-    assert _relerr(xd.grad.cpu(), xr.grad) < tol * 10
+    _check_grad(xd.grad.cpu(), xr.grad, _gtol(tol), "input")
     for k in ("conv1.weight_orig", "conv4.weight_orig", "conv3.bias", "context_conv.weight", "conv_out.weight"):
-        assert _relerr(dict(D.named_parameters())[k].grad.cpu(), sdr["Discriminator." + k].grad) < tol * 10, k
+        _check_grad(dict(D.named_parameters())[k].grad.cpu(), sdr["Discriminator." + k].grad, _gtol(tol), k)
 
 
 @pytest.mark.parametrize("gan", [False, True], ids=["compression", "compression_gan"])
@@ -192,7 +204,7 @@ def test_model_losses_and_grads_fp32(hific, dev, sd, gan):
     assert _relerr(inter.reconstruction.detach().float().cpu(), rec_ref) < 1e-3
     params = dict(model.named_parameters())
     for k in watch:
-        assert _relerr(params[k].grad.cpu(), sdr[k].grad) < 1e-2, k
+        _check_grad(params[k].grad.cpu(), sdr[k].grad, 1e-3, k)
 
 
 def test_zz_hyperprior_compress_roundtrip(hific, dev, tmp_path):
