@@ -68,8 +68,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--cpu-timeout", type=int, default=300)
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-timeout", type=int, default=240)
     ap.add_argument("--regime", default="low", choices=["low", "med", "high"])
     ap.add_argument("--no-parity", action="store_true", help="skip the in-process oracle comparison")
     ap.add_argument("--seed", type=int, default=0)
@@ -139,7 +139,24 @@ def make_step(args, model, opts, reducers, dev, config):
             opts["amort"].zero_grad(); opts["hyper"].zero_grad()
         return losses
 
+    step.generators = (gen,)
     return step
+
+
+def graphed(args, step, world):
+    """The step as one hipGraph replay (hific_amd.graph.GraphedStep) - default at one rank; HIFIC_BENCH_GRAPH=0 keeps the
+    eager launch path, =1 forces capture also under torch.distributed (RCCL collectives inside the capture: untested)."""
+    flag = os.environ.get("HIFIC_BENCH_GRAPH", "")
+    if flag == "0" or (world > 1 and flag != "1") or os.environ.get("HIFIC_FORCE_DIST") == "1" and flag != "1":
+        return step, False
+    from hific_amd.graph import GraphedStep
+    try:
+        return GraphedStep(step, warmup=max(2, args.warmup), generators=step.generators), True
+    except Exception as e:                    # a capture failure must not cost the measurement
+        print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+        import torch
+        torch.cuda.synchronize()
+        return step, False
 
 
 def timed(step, steps, warmup, fence):
@@ -329,7 +346,13 @@ def _cpu_reference_worker(size, B, steps, thread_counts, gan, fwd_batch):
             opt_d.step(); opt_d.zero_grad()
 
     res = {"per_threads": {}}
-    for th in thread_counts:
+
+    def emit():                                              # a line per stage: the parent keeps the last one it got
+        best = max(res["per_threads"], key=lambda k: res["per_threads"][k])
+        res["best_threads"], res["images_per_s"] = int(best), res["per_threads"][best]
+        print(json.dumps(res), flush=True)
+
+    for i, th in enumerate(thread_counts):
         torch.set_num_threads(th)
         cycle()                                              # warm-up at this thread count
         ts = []
@@ -337,16 +360,14 @@ def _cpu_reference_worker(size, B, steps, thread_counts, gan, fwd_batch):
             t0 = time.time(); cycle(); ts.append(time.time() - t0)
         t = sorted(ts)[len(ts) // 2]
         res["per_threads"][str(th)] = round(B * (2 if gan else 1) / t, 4)
-    best = max(res["per_threads"], key=lambda k: res["per_threads"][k])
-    res["best_threads"], res["images_per_s"] = int(best), res["per_threads"][best]
-    if fwd_batch:
-        torch.set_num_threads(int(best))
-        x = torch.randn((fwd_batch, 3, size, size), generator=g)
-        with torch.no_grad():
-            model(x)
-            t0 = time.time(); model(x); res["fwd_s"] = round(time.time() - t0, 3)
+        emit()
+        if i == 0 and fwd_batch:
+            x = torch.randn((fwd_batch, 3, size, size), generator=g)
+            with torch.no_grad():
+                model(x)
+                t0 = time.time(); model(x); res["fwd_s"], res["fwd_threads"] = round(time.time() - t0, 3), th
+            emit()
     shutil.rmtree(root, ignore_errors=True)
-    print(json.dumps(res), flush=True)
 
 
 def cpu_baseline(args):
@@ -360,7 +381,7 @@ def cpu_baseline(args):
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     env.pop("OMP_NUM_THREADS", None)
     if os.path.exists(REF_TAR) and os.environ.get("HIFIC_CPU_BASELINE", "reference") == "reference":
-        ths = sorted({ncores, max(1, ncores // 2), min(ncores, 32)}, reverse=True)
+        ths = sorted({ncores, max(1, ncores // 2), min(ncores, 32)})      # the usual optimum first, all logical cores last
         cmd = [sys.executable, "-c",
                f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
                f"bench._cpu_reference_worker({args.size}, {args.cpu_batch}, {args.cpu_steps}, {ths}, {gan}, 10)"]
@@ -369,13 +390,18 @@ def cpu_baseline(args):
                   f"{args.size}x{args.size}, 1 warm-up + {args.cpu_steps} timed (median) at each of {ths} threads of "
                   f"{ncores} logical cores; value = best")
         try:
-            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_timeout)
-            r = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+            try:
+                stdout = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_timeout).stdout
+            except subprocess.TimeoutExpired as te:           # keep the stages that finished
+                stdout = te.stdout.decode() if isinstance(te.stdout, bytes) else (te.stdout or "")
+                sample += f" -- stopped at the {args.cpu_timeout} s limit, thread counts not reached are absent"
+            r = json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
             out = {"value": r["images_per_s"], "unit": "images/s", "cores": r["best_threads"], "kind": "reference",
                    "sample": sample, "images_per_s_by_threads": r["per_threads"],
                    "all_core_images_per_s": r["per_threads"].get(str(ncores))}
             if "fwd_s" in r:
                 out["src_model_forward_b10_s"] = r["fwd_s"]
+                out["src_model_forward_b10_threads"] = r.get("fwd_threads")
                 out["src_model_forward_b10_note"] = ("src/model.py:443-463 smoke forward (GAN model, batch 10 x 256^2, both "
                                                      "losses); the reference publishes ~45 s on a 2.8 GHz Core i7 "
                                                      "(src/README.md:112)")
@@ -511,7 +537,8 @@ def main():
     if use_dist:
         for r in reducers.values():
             r.measure_exposed(True)              # two event records per finish(): read after the timed region
-    elapsed = timed(step, args.steps, args.warmup, fence)
+    run_step, is_graph = graphed(args, step, world)
+    elapsed = timed(run_step, args.steps, args.warmup, fence)
     rccl = None
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -551,6 +578,7 @@ def main():
     if args.dtype == "bf16":
         from hific_amd import ops as _ops
         out["config"]["exact_index_chain"] = bool(_ops.exact_index_on())
+    out["config"]["launch"] = "one hipGraph replay per cycle" if is_graph else "eager (one launch per kernel)"
     if rccl is not None:
         out["rccl"] = rccl
     extras = world == 1 and not args.no_extras
@@ -570,13 +598,14 @@ def main():
                            sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "gemm_class_ms_per_step": round(sum(v["ms_per_step"] for v in prof.values()), 3),
         }
-        del model, opts, reducers, step
-        hific_ops.pack_cache.clear()
+        del model, opts, reducers, step, run_step
+        hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
         torch.cuda.empty_cache()
         # ---- configs[1]: compression (no GAN) training step ---------------------------------------------------
         if cfg == "gan":
             m2, o2, r2 = build(args, dev, "compression")
             s2 = make_step(args, m2, o2, r2, dev, "compression")
+            s2, _ = graphed(args, s2, world)
             e2 = timed(s2, args.steps, args.warmup, fence)
             out["compression"] = {"value": round(args.batch * args.steps / e2, 3), "unit": "images/s",
                                   "ms_per_step": round(e2 / args.steps * 1e3, 3),
@@ -584,7 +613,7 @@ def main():
                                   "whole_step_tflops": round(GFLOP_PER_IMAGE["compression"] * args.batch *
                                                              (args.size / 256.0) ** 2 / 1e3 / (e2 / args.steps), 1)}
             del m2, o2, r2, s2
-            hific_ops.pack_cache.clear()
+            hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
             torch.cuda.empty_cache()
         # ---- forward ms/image: EVALUATION-mode forward (model.py:357-366) ---------------------------------------
         import hific_amd
@@ -616,6 +645,7 @@ def main():
             a32 = argparse.Namespace(**vars(args)); a32.dtype = "f32"
             m3, o3, r3 = build(a32, dev, cfg)
             s3 = make_step(a32, m3, o3, r3, dev, cfg)
+            s3, _ = graphed(a32, s3, world)
             n3 = max(2, min(args.steps, 4))
             e3 = timed(s3, n3, 1, fence)
             out["f32"] = {"value": round(imgs_per_step * n3 / e3, 3), "unit": "images/s", "ms_per_step": round(e3 / n3 * 1e3, 3),
@@ -632,6 +662,7 @@ def main():
             a5 = argparse.Namespace(**vars(args)); a5.size, a5.batch, a5.regime = 1024, 1, "high"
             m5, o5, r5 = build(a5, dev, "gan")
             s5 = make_step(a5, m5, o5, r5, dev, "gan")
+            s5, _ = graphed(a5, s5, world)
             n5 = max(3, min(args.steps, 10))
             e5 = timed(s5, n5, 2, fence)
             out["config5_1gpu"] = {"value": round(2 * n5 / e5, 3), "unit": "images/s (1024x1024)",

@@ -455,6 +455,30 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Device-side step counter (hipGraph replays cannot change kernel arguments): adam_prep_kernel advances the step and
+// publishes the two bias-correction factors, adam_dev_kernel reads them.  Same arithmetic as the host path.
+__global__ void adam_prep_kernel(int* __restrict__ step, float* __restrict__ bc, float b1, float b2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int t = *step + 1;
+        *step = t;
+        bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+        bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+    }
+}
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                const float* __restrict__ bc, float grad_scale) {
+    const float bc1 = bc[0], bc2_sqrt = bc[1];
+    EW_LOOP(i, n) {
+        const float gi = g[i] * grad_scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Split-bf16 operands (exact-index mode).  A float32 value v is carried as hi = bf16(v) and
 // lo = bf16(v - hi) (v - hi is exact in f32); x*w ~= xh*wh + xl*wh + xh*wl (relative error ~2^-17 per product instead
@@ -775,6 +799,22 @@ int hific_adam_step(float* p, const float* g, float* m, float* v, long long n, f
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, EW_GRID(n), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
                        (float)sqrt(bc2), grad_scale);
+    return hific_launch_status();
+}
+
+// Graph-replayable form: the step count lives in device memory.  hific_adam_prepare: ++*step_dev, bc_dev[0] = 1 - b1^t,
+// bc_dev[1] = sqrt(1 - b2^t); hific_adam_apply: the update of one parameter range with those factors (a group may be
+// updated in several ranges / on several streams after ONE prepare).
+int hific_adam_prepare(int* step_dev, float* bc_dev, float beta1, float beta2, hipStream_t st) {
+    if (!step_dev || !bc_dev) return HIFIC_ERR_ARG;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, st, step_dev, bc_dev, beta1, beta2);
+    return hific_launch_status();
+}
+int hific_adam_apply(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                     float eps, const float* bc_dev, float grad_scale, hipStream_t st) {
+    if (!p || !g || !m || !v || !bc_dev || n <= 0) return HIFIC_ERR_ARG;
+    hipLaunchKernelGGL(adam_dev_kernel, EW_GRID(n), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, bc_dev,
+                       grad_scale);
     return hific_launch_status();
 }
 

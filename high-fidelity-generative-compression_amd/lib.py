@@ -59,6 +59,8 @@ SIGNATURES = {
     "hific_spectral_norm_fwd": (I, [P, P, P, P, I, I, I, F, P, Z, P]),
     "hific_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, I, P, Z, P]),
     "hific_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+    "hific_adam_prepare": (I, [P, P, F, F, P]),
+    "hific_adam_apply": (I, [P, P, P, P, L, F, F, F, F, P, F, P]),
     "hific_prior_symbols": (I, [P, P, P, P, I, F, P, P, L, P]),
     "hific_hyper_symbols": (I, [P, P, P, I, I, I, P]),
     "hific_round_f32": (I, [P, P, P, L, P]),

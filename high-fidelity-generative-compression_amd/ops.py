@@ -1229,6 +1229,18 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
          float(eps), int(step), float(grad_scale), stream())
 
 
+def adam_prepare(step_dev, bc_dev, beta1, beta2):
+    """++step (device int32), bias corrections -> bc_dev[0..1] (device float32): graph-replayable Adam (optim.FusedAdam)."""
+    require_gpu(step_dev, bc_dev)
+    call("hific_adam_prepare", ptr(step_dev), ptr(bc_dev), float(beta1), float(beta2), stream())
+
+
+def adam_apply(p, g, m, v, lr, beta1, beta2, eps, bc_dev, grad_scale=1.0):
+    require_gpu(p, g, m, v, bc_dev)
+    call("hific_adam_apply", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), ptr(bc_dev), float(grad_scale), stream())
+
+
 # ---- EVALUATION path: device half of `compress` (int32 symbols + table indices for the host rANS coder) -------------
 SCALES_MIN = 0.11        # src/compression/prior_model.py:19
 

@@ -24,7 +24,7 @@ class GradSlot:
         self.fresh = True
         self.arena = arena
         self.index = index
-        self.autograd = False     # gradient arrives through autograd's AccumulateGrad (no kernel writes this slot)
+        self.autograd = False     # a gradient from autograd's AccumulateGrad is in flight for this slot (see ParamArena)
 
     def take(self):
         """Returns the accumulate flag for the next write (0 = overwrite) and marks the slot written."""
@@ -66,29 +66,42 @@ class ParamArena:
                 p._hific_slot = slot
                 p.grad = gview
                 self.slots.append(slot)
-                p.register_post_accumulate_grad_hook(self._autograd_hook(i))
+                pre, post = self._autograd_hooks(i)
+                p.register_hook(pre)
+                p.register_post_accumulate_grad_hook(post)
 
-    def _autograd_hook(self, i):
+    def _autograd_hooks(self, i):
         """Parameters whose gradient is produced by ATen ops (the InstanceNorm fallback's affine pair, or any user module
-        mixed into a group) are accumulated IN PLACE into the slot view by autograd's AccumulateGrad, which knows nothing
-        of `fresh`: such slots are zeroed by zero_grad() (they are tiny) and marked written here, so zero_unwritten()
-        keeps them and data-parallel buckets count them."""
-        def hook(p):
+        mixed into a group) are accumulated IN PLACE into the slot view by autograd's AccumulateGrad, which knows nothing of
+        `fresh`.  The tensor hook sees the incoming gradient BEFORE that accumulation (it is None for every parameter whose
+        gradient a kernel wrote into the slot: those return None to autograd): on the first real gradient after zero_grad()
+        the slot is cleared and marked written, so the sum lands on zeros, zero_unwritten() keeps it and data-parallel
+        buckets count it once the accumulation has happened (post-accumulate hook)."""
+        def pre(grad):
+            if grad is None:
+                return None
             s = self.slots[i]
-            if p.grad is not s.grad and p.grad is not None and p.grad.data_ptr() != s.grad.data_ptr():
-                s.grad.copy_(p.grad)            # autograd replaced the view (grad was None): bring it home
-                p.grad = s.grad
+            if s.fresh:
+                s.grad.zero_()
+                s.fresh = False
             s.autograd = True
-            s.fresh = False
+            return None
+
+        def post(p):
+            s = self.slots[i]
+            if not s.autograd:
+                return
+            s.autograd = False
+            if p.grad is not None and p.grad.data_ptr() != s.grad.data_ptr():
+                s.grad.copy_(p.grad)            # autograd installed its own tensor (p.grad had been dropped): bring it home
+                p.grad = s.grad
             s.written()
-        return hook
+        return pre, post
 
     def zero_grad(self):
-        """Marks every slot fresh (next backward overwrites): no memset needed, except for autograd-written slots."""
+        """Marks every slot fresh (next backward overwrites): no memset needed."""
         for s in self.slots:
             s.fresh = True
-            if s.autograd:
-                s.grad.zero_()
 
     def slice_of(self, i):
         o = self.offsets[i]
@@ -155,7 +168,11 @@ class FusedAdam:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.exp_avg = torch.zeros_like(self.arena.flat)
         self.exp_avg_sq = torch.zeros_like(self.arena.flat)
-        self.step_count = 0
+        # the step count lives on the device (a captured hipGraph of the training step must be replayable: kernel arguments
+        # are frozen at capture); `step_count` reads it back
+        dev = self.arena.flat.device
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._bc_dev = torch.zeros(2, dtype=torch.float32, device=dev)
         self.grad_scale = 1.0
         # number of leading parameters updated on the current stream; the rest go to ops.opt_stream() (None: all here).
         # The caller must then use ops.wait_late_params() / synchronize() before touching the tail: hific_amd.Model does
@@ -167,27 +184,36 @@ class FusedAdam:
         a = self.arena
         a.rebind()
         a.zero_unwritten()
-        self.step_count += 1
         g = self.param_groups[0]
-        hyper = (g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count, self.grad_scale)
+        hyper = (g["lr"], g["betas"][0], g["betas"][1], g["eps"], self._bc_dev, self.grad_scale)
         off = 0
         if self.overlap_from and ops.opt_stream_on() and a.flat.is_cuda and 0 < self.overlap_from < len(a.params):
             off = a.offsets[self.overlap_from]
         if off:
             # head (what the next forward needs first) here, tail on the optimizer stream: see ops.opt_stream
-            ops.wait_late_params()                     # a previous tail nobody waited for
-            ops.adam_step(a.flat[:off], a.flat_grad[:off], self.exp_avg[:off], self.exp_avg_sq[:off], *hyper)
+            ops.wait_late_params()                     # a previous tail nobody waited for (it reads the bias corrections)
+            ops.adam_prepare(self._step_dev, self._bc_dev, g["betas"][0], g["betas"][1])
+            ops.adam_apply(a.flat[:off], a.flat_grad[:off], self.exp_avg[:off], self.exp_avg_sq[:off], *hyper)
             cur = torch.cuda.current_stream(a.flat.device)
             st = ops.opt_stream(a.flat.device)
             st.wait_stream(cur)                        # gradients (and the all-reduce) are complete on this stream
             with torch.cuda.stream(st):
-                ops.adam_step(a.flat[off:], a.flat_grad[off:], self.exp_avg[off:], self.exp_avg_sq[off:], *hyper)
+                ops.adam_apply(a.flat[off:], a.flat_grad[off:], self.exp_avg[off:], self.exp_avg_sq[off:], *hyper)
             a.late_start, a.late_event = off, st.record_event()
             ops.register_late(a)
         else:
-            ops.adam_step(a.flat, a.flat_grad, self.exp_avg, self.exp_avg_sq, *hyper)
+            ops.adam_prepare(self._step_dev, self._bc_dev, g["betas"][0], g["betas"][1])
+            ops.adam_apply(a.flat, a.flat_grad, self.exp_avg, self.exp_avg_sq, *hyper)
         a.epoch += 1
         ops.note_weights_changed()
+
+    @property
+    def step_count(self):
+        return int(self._step_dev.item())
+
+    @step_count.setter
+    def step_count(self, n):
+        self._step_dev.fill_(int(n))
 
     def synchronize(self):
         """Orders the current stream after a pending optimizer tail (overlap_from): call before reading the parameters

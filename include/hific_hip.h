@@ -146,6 +146,12 @@ int hific_spectral_norm_bwd(const float* dW, const float* Worig, const float* u,
 /* torch.optim.Adam step over a flat arena (train.py:287-301: lr 1e-4, betas (.9,.999), eps 1e-8, no decay) */
 int hific_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, int step, float grad_scale, hipStream_t stream);
+/* The same update with the step count in device memory, so that a captured hipGraph of the training step can be replayed
+ * (kernel arguments are frozen at capture): hific_adam_prepare advances *step_dev and writes the two bias-correction
+ * factors to bc_dev[0..1]; hific_adam_apply updates one parameter range with them. */
+int hific_adam_prepare(int* step_dev, float* bc_dev, float beta1, float beta2, hipStream_t stream);
+int hific_adam_apply(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                     float eps, const float* bc_dev, float grad_scale, hipStream_t stream);
 
 /* ---- entropy model (csrc/entropy.hip), all float32 ----------------------------------------------------------- */
 /* floor(x - mean + .5) + mean: src/hyperprior.py:68-74,108-122 (mean may be NULL) */

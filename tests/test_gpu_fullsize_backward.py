@@ -17,6 +17,7 @@ import pytest
 import torch
 
 from oracle import hific_oracle as O
+from gradcheck import check_grads
 
 pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 
@@ -57,40 +58,34 @@ def _device_symbols(model, inter):
     return torch.round(inter.latents_quantized.detach().float() - mu).cpu()
 
 
-def _oracle_turn(sdr, x, nh, nl, train_generator, sym_dev, oargs=None):
-    """Oracle forward for one turn; if the device's symbols differ, only at rounding ties - then re-run given equal ones."""
-    bb, lins = O.make_alex_backbone(), _lins()
+def _oracle_turn(sdr, x, nh, nl, train_generator, sym_dev, oargs=None, dt=torch.float32):
+    """Oracle forward for one turn in dtype `dt`, given the device's symbols wherever they differ from the oracle's own -
+    which is only allowed at rounding ties (asserted against the float32 oracle, the reference's arithmetic)."""
+    bb, lins = O.make_alex_backbone(dtype=dt), [l.to(dt) for l in _lins()]
+    x, nh, nl = x.to(dt), nh.to(dt), nl.to(dt)
     kw = dict(step_counter=1, training=True, gan=True, train_generator=train_generator, noise_hyper=nh, noise_latent=nl,
               args=oargs)
     with torch.no_grad():
         y = O.encoder_forward(sdr, x)
         hi = O.hyperprior_forward(sdr, y, x.shape[2:], True, nh, nl)
     sym_o = torch.floor(y - hi.latent_means + 0.5)
-    flips = sym_o != sym_dev
+    flips = sym_o != sym_dev.to(dt)
     n = int(flips.sum())
     override = None
     if n:
         frac = y - hi.latent_means + 0.5
         frac = frac - torch.floor(frac)
         tie = torch.minimum(frac, 1 - frac)
-        print(f"  rounding-tie flips: {n} of {flips.numel()}, max tie distance {float(tie[flips].max()):.2e}")
+        print(f"  rounding-tie flips vs the {dt} oracle: {n} of {flips.numel()}, max tie distance {float(tie[flips].max()):.2e}")
         assert n <= max(2, 1e-4 * flips.numel()) and float(tie[flips].max()) < 1e-4
-        assert float((sym_o - sym_dev).abs().max()) <= 1
+        assert float((sym_o - sym_dev.to(dt)).abs().max()) <= 1
         override = sym_dev
     return O.model_forward(sdr, bb, lins, x, symbols_override=override, **kw)
 
 
-def _compare(got, want, tol, what):
-    rows = []
-    for k, g in want.items():
-        a = got[k]
-        scale = max(float(g.abs().max()), 1e-30)
-        rows.append((float((a - g).abs().max()) / scale, k, scale))
-    rows.sort(reverse=True)
-    print(f"  [{what}] {len(rows)} tensors; worst: " + "; ".join(f"{k} {e:.2e}" for e, k, _ in rows[:6]))
-    bad = [(k, e) for e, k, _ in rows if not e < tol]
-    assert not bad, f"{what}: {len(bad)} of {len(rows)} gradients beyond {tol}: {bad[:8]}"
-    return rows[0][0]
+def _params_for_autograd(sd, names, dt):
+    return {k: (v.to(dt).clone().requires_grad_(True) if k in names else (v.to(dt) if v.dtype.is_floating_point else v.clone()))
+            for k, v in sd.items()}
 
 
 def test_gan_cycle_every_gradient_fullsize_f32(hific, dev):
@@ -124,26 +119,39 @@ def test_gan_cycle_every_gradient_fullsize_f32(hific, dev):
     del model, arenas, losses, inter
     torch.cuda.empty_cache()
 
-    # ---- oracle: the same two turns with torch autograd on the CPU -----------------------------------------------
-    sdr = {k: (v.clone().requires_grad_(True) if k in params else v.clone()) for k, v in sd.items()}
-    out = _oracle_turn(sdr, xs[0], *nz[0], True, sym_G)
-    out["compression"].backward()
-    assert abs(loss_G - float(out["compression"])) < 1e-3 * abs(float(out["compression"]))
-    ref_G = {k: sdr[k].grad.detach().clone() for k in params}
-    worst_G = _compare(dev_G, ref_G, 1e-3, "G-turn, all parameters")
-    for k in gen_keys:
-        sdr[k].grad = None
-    for k, v in out["new_uv"].items():             # spectral-norm power iteration state carries over (in-place buffers)
-        sdr[k] = v.detach()
-    out = _oracle_turn(sdr, xs[1], *nz[1], False, sym_D)
-    out["disc"].backward()
-    assert abs(loss_D - float(out["disc"])) < 1e-3 * abs(float(out["disc"]))
-    assert all(sdr[k].grad is None for k in gen_keys)
-    ref_D = {k: sdr[k].grad.detach().clone() for k in disc_keys}
-    worst_D = _compare(dev_D, ref_D, 1e-3, "D-turn, Discriminator (G-turn leftovers + D-turn)")
-    for k, v in out["new_uv"].items():
-        assert torch.allclose(uv_dev[k], v.detach(), atol=1e-5), k
-    print(f"  full-size f32 gradients vs oracle: worst G-turn {worst_G:.2e}, worst D-turn {worst_D:.2e}")
+    # ---- oracle: the same two turns with torch autograd on the CPU (float32 = the bar; float64 = the arbiter) ---------
+    def oracle_cycle(dt):
+        sdr = _params_for_autograd(sd, params, dt)
+        out = _oracle_turn(sdr, xs[0], *nz[0], True, sym_G, dt=dt)
+        out["compression"].backward()
+        res = dict(loss_G=float(out["compression"]), G={k: sdr[k].grad.detach().clone() for k in params})
+        for k in gen_keys:
+            sdr[k].grad = None
+        for k, v in out["new_uv"].items():         # spectral-norm power iteration state carries over (in-place buffers)
+            sdr[k] = v.detach()
+        out = _oracle_turn(sdr, xs[1], *nz[1], False, sym_D, dt=dt)
+        out["disc"].backward()
+        assert all(sdr[k].grad is None for k in gen_keys)
+        res.update(loss_D=float(out["disc"]), D={k: sdr[k].grad.detach().clone() for k in disc_keys},
+                   uv={k: v.detach() for k, v in out["new_uv"].items()})
+        return res
+
+    o32 = oracle_cycle(torch.float32)
+    assert abs(loss_G - o32["loss_G"]) < 1e-3 * abs(o32["loss_G"]) and abs(loss_D - o32["loss_D"]) < 1e-3 * abs(o32["loss_D"])
+    cache = {}
+
+    def o64():
+        if not cache:
+            cache.update(oracle_cycle(torch.float64))
+        return cache
+
+    worst_G, arb_G = check_grads(dev_G, o32["G"], lambda: o64()["G"], 1e-3, "G-turn, all parameters")
+    worst_D, arb_D = check_grads(dev_D, o32["D"], lambda: o64()["D"], 1e-3, "D-turn, Discriminator (G-turn leftovers + D-turn)")
+    for k, v in o32["uv"].items():
+        assert torch.allclose(uv_dev[k], v, atol=1e-5), k
+    print(f"  full-size f32 gradients vs oracle: worst G-turn {worst_G:.2e}, worst D-turn {worst_D:.2e}; judged on the "
+          f"float64 oracle: {arb_G + arb_D}")
+    assert len(arb_G) <= 8 and len(arb_D) <= 2, "too many tensors needed the float64 arbiter"
 
 
 def test_config5_one_1024_crop_regime_high(hific, dev):
@@ -171,16 +179,22 @@ def test_config5_one_1024_crop_regime_high(hific, dev):
         return res
 
     r32 = run(torch.float32)
-    sdr = {k: (v.clone().requires_grad_(True) if k in r32["grads"] else v.clone()) for k, v in r32["sd"].items()}
-    out = _oracle_turn(sdr, x, nh, nl, True, r32["sym"], oargs)
-    out["compression"].backward()
+
+    def oracle(dt):
+        sdr = _params_for_autograd(r32["sd"], r32["grads"], dt)
+        out = _oracle_turn(sdr, x, nh, nl, True, r32["sym"], oargs, dt=dt)
+        out["compression"].backward()
+        return out, {k: sdr[k].grad.detach() for k in r32["grads"]}
+
+    out, g32 = oracle(torch.float32)
     for name, a, b in (("compression", r32["loss"], float(out["compression"])), ("disc", r32["disc"], float(out["disc"])),
                        ("n_bpp", r32["n_bpp"], float(out["hyperinfo"].total_nbpp)),
                        ("q_bpp", r32["q_bpp"], float(out["hyperinfo"].total_qbpp))):
         assert abs(a - b) < 1e-3 * abs(b), (name, a, b)
     rec_ref = out["reconstruction"].detach()
     assert float((r32["rec"] - rec_ref).abs().max()) < 1e-3 * float(rec_ref.abs().max())
-    _compare(r32["grads"], {k: sdr[k].grad.detach() for k in r32["grads"]}, 1e-3, "config 5, f32, all parameters")
+    _, arb = check_grads(r32["grads"], g32, lambda: oracle(torch.float64)[1], 1e-3, "config 5, f32, all parameters")
+    assert len(arb) <= 8
     # the benchmarked mode at this shape: finite, bit-reproducible, same rate decision, aggregates near the f32 run
     b1, b2 = run(torch.bfloat16), run(torch.bfloat16)
     assert all(torch.isfinite(g).all() for g in b1["grads"].values()) and np.isfinite(b1["loss"])

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import hific_oracle as O
+from gradcheck import check_grads
 
 pytestmark = pytest.mark.gpu
 
@@ -16,15 +17,15 @@ def _relerr(a, b):
 
 
 def _gtol(tol):
-    """Gradient tolerance: float32 mode holds gradients to the forward bar (1e-3 of each tensor's scale); bf16 mode to 10x
-    its forward tolerance (two bf16-rounded operands per product, sums of 10^4..10^6 terms)."""
+    """Gradient tolerance: float32 mode holds gradients to the forward bar (1e-3 of each tensor's scale, with the float64
+    oracle as arbiter where the float32 oracle itself is noisier than that: tests/gradcheck.py); bf16 mode to 10x its
+    forward tolerance (two bf16-rounded operands per product, sums of 10^4..10^6 terms)."""
     return 1e-3 if tol <= 1e-3 else tol * 10
 
 
-def _check_grad(got, want, tol, what):
-    e = _relerr(got, want)
-    print(f"  grad {what}: {e:.2e} (tol {tol:.0e})")
-    assert e < tol, (what, e)
+def _check_grads(got, ref32, tol, what, exact=None):
+    """`exact`: callable -> {name: float64 oracle gradient}; only consulted in float32 mode for tensors beyond `tol`."""
+    check_grads(got, ref32, exact if tol <= 1e-3 else None, tol, what)
 
 
 @pytest.fixture(scope="module")
@@ -44,18 +45,23 @@ def test_encoder(hific, dev, sd, dt, tol):
     hific.set_compute_dtype(dt)
     enc = _load(Encoder((3, 128, 128), 2, C=220), sd, "Encoder.").to(dev)
     x = O.make_image(1, 2, 128, 128)
-    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("Encoder.")}
-    yr = O.encoder_forward(sdr, x)
-    g = O.make_noise(2, tuple(yr.shape)) * 2
-    yr.backward(g)
+    watch = ("conv_block1.1.weight", "conv_block3.1.weight", "conv_block5.2.gamma", "conv_block_out.1.bias")
+
+    def oracle(odt):
+        sdr = {k: v.to(odt).clone().requires_grad_(True) for k, v in sd.items() if k.startswith("Encoder.")}
+        yr = O.encoder_forward(sdr, x.to(odt))
+        g = O.make_noise(2, tuple(yr.shape)) * 2
+        yr.backward(g.to(odt))
+        return yr.detach(), g, {k: sdr["Encoder." + k].grad for k in watch}
+
+    yr, g, ref = oracle(torch.float32)
     y = enc(x.to(dev))
     assert y.dtype == torch.float32
     y.backward(g.to(dev))
     torch.cuda.synchronize()
-    assert _relerr(y.detach().cpu(), yr.detach()) < tol
-    for k in ("conv_block1.1.weight", "conv_block3.1.weight", "conv_block5.2.gamma", "conv_block_out.1.bias"):
-        got = dict(enc.named_parameters())[k].grad.cpu()
-        _check_grad(got, sdr["Encoder." + k].grad, _gtol(tol), k)
+    assert _relerr(y.detach().cpu(), yr) < tol
+    params = dict(enc.named_parameters())
+    _check_grads({k: params[k].grad.cpu() for k in watch}, ref, _gtol(tol), f"Encoder {dt}", lambda: oracle(torch.float64)[2])
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)], ids=["f32", "bf16"])
@@ -64,20 +70,28 @@ def test_generator(hific, dev, sd, dt, tol):
     hific.set_compute_dtype(dt)
     gen = _load(Generator((3, 128, 128), 2, C=220, n_residual_blocks=N_RES), sd, "Generator.").to(dev)
     y = O.make_noise(3, (2, 220, 8, 8)) * 4
-    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("Generator.")}
-    yr_in = y.clone().requires_grad_(True)
-    xr = O.generator_forward(sdr, yr_in, N_RES)
-    g = O.make_noise(4, tuple(xr.shape))
-    xr.backward(g)
+    watch = ("resblock_0.conv1.weight", "upconv_block2.0.weight", "conv_block_out.1.weight", "resblock_1.norm2.beta")
+
+    def oracle(odt):
+        sdr = {k: v.to(odt).clone().requires_grad_(True) for k, v in sd.items() if k.startswith("Generator.")}
+        yr_in = y.to(odt).clone().requires_grad_(True)
+        xr = O.generator_forward(sdr, yr_in, N_RES)
+        g = O.make_noise(4, tuple(xr.shape))
+        xr.backward(g.to(odt))
+        grads = {k: sdr["Generator." + k].grad for k in watch}
+        grads["input"] = yr_in.grad
+        return xr.detach(), g, grads
+
+    xr, g, ref = oracle(torch.float32)
     yd = y.to(dev).requires_grad_(True)
     x = gen(yd)
     x.backward(g.to(dev).to(x.dtype))
     torch.cuda.synchronize()
-    assert _relerr(x.detach().float().cpu(), xr.detach()) < tol
-    _check_grad(yd.grad.cpu(), yr_in.grad, _gtol(tol), "input")
-    for k in ("resblock_0.conv1.weight", "upconv_block2.0.weight", "conv_block_out.1.weight", "resblock_1.norm2.beta"):
-        got = dict(gen.named_parameters())[k].grad.cpu()
-        _check_grad(got, sdr["Generator." + k].grad, _gtol(tol), k)
+    assert _relerr(x.detach().float().cpu(), xr) < tol
+    params = dict(gen.named_parameters())
+    got = {k: params[k].grad.cpu() for k in watch}
+    got["input"] = yd.grad.cpu()
+    _check_grads(got, ref, _gtol(tol), f"Generator {dt}", lambda: oracle(torch.float64)[2])
 
 
 @pytest.mark.parametrize("training", [True, False])
@@ -87,11 +101,20 @@ def test_hyperprior_fp32(hific, dev, sd, training):
     hp = _load(Hyperprior(bottleneck_capacity=220), sd, "Hyperprior.").to(dev).train(training)
     y = O.make_noise(5, (2, 220, 8, 8)) * 6
     nh, nl = O.make_noise(6, (2, 320, 2, 2)), O.make_noise(7, (2, 220, 8, 8))
-    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("Hyperprior.")}
-    yr = y.clone().requires_grad_(True)
-    hr = O.hyperprior_forward(sdr, yr, (128, 128), training, nh, nl)
     gdec = O.make_noise(8, (2, 220, 8, 8))
-    (hr.total_nbpp * 3.0 + hr.total_qbpp * 0.5 + (hr.decoded * gdec).sum()).backward()
+    watch = ("analysis_net.conv1.weight", "synthesis_mu.conv2.weight", "synthesis_std.conv3.bias",
+             "hyperlatent_likelihood.H_1", "hyperlatent_likelihood.a_0", "hyperlatent_likelihood.b_3")
+
+    def oracle(odt, symbols=None):
+        sdr = {k: v.to(odt).clone().requires_grad_(True) for k, v in sd.items() if k.startswith("Hyperprior.")}
+        yr = y.to(odt).clone().requires_grad_(True)
+        hr = O.hyperprior_forward(sdr, yr, (128, 128), training, nh.to(odt), nl.to(odt), symbols_override=symbols)
+        (hr.total_nbpp * 3.0 + hr.total_qbpp * 0.5 + (hr.decoded * gdec.to(odt)).sum()).backward()
+        grads = {k: sdr["Hyperprior." + k].grad for k in watch}
+        grads["latents"] = yr.grad
+        return hr, grads
+
+    hr, ref = oracle(torch.float32)
     noises = [nh.to(dev), nl.to(dev)]
     hp._draw_noise = lambda t: noises.pop(0)
     yd = y.to(dev).requires_grad_(True)
@@ -112,11 +135,13 @@ def test_hyperprior_fp32(hific, dev, sd, training):
         tie = torch.minimum(frac, 1 - frac)
         assert int(flips.sum()) <= 2 and float(tie[flips].max()) < 1e-4, (int(flips.sum()), float(tie[flips].max()))
         assert int(((idx_h - idx_o).abs() > 1).sum()) == 0
-    _check_grad(yd.grad.cpu(), yr.grad, 1e-3, "latents")
     params = dict(hp.named_parameters())
-    for k in ("analysis_net.conv1.weight", "synthesis_mu.conv2.weight", "synthesis_std.conv3.bias",
-              "hyperlatent_likelihood.H_1", "hyperlatent_likelihood.a_0", "hyperlatent_likelihood.b_3"):
-        _check_grad(params[k].grad.cpu(), sdr["Hyperprior." + k].grad, 1e-3, k)
+    got = {k: params[k].grad.cpu() for k in watch}
+    got["latents"] = yd.grad.cpu()
+    sym = idx_h.to(torch.float32) if flips.any() else None
+    if sym is not None:
+        ref = oracle(torch.float32, sym)[1]                  # "given equal indices"
+    _check_grads(got, ref, 1e-3, f"Hyperprior f32 training={training}", lambda: oracle(torch.float64, sym)[1])
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)], ids=["f32", "bf16"])
@@ -126,22 +151,31 @@ def test_discriminator(hific, dev, sd, dt, tol):
     D = _load(Discriminator((3, 128, 128), (220, 8, 8), C=220), sd, "Discriminator.").to(dev).train()
     x = O.make_image(9, 4, 128, 128)
     y = O.make_noise(10, (4, 220, 8, 8)) * 4
-    sdr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "weight_u" not in k and "weight_v" not in k
-               else v.clone()) for k, v in sd.items() if k.startswith("Discriminator.")}
-    xr = x.clone().requires_grad_(True)
-    out_r, logit_r, new_uv = O.discriminator_forward(sdr, xr, y, training=True)
-    g = O.make_noise(11, tuple(logit_r.shape))
-    logit_r.backward(g)
+    watch = ("conv1.weight_orig", "conv4.weight_orig", "conv3.bias", "context_conv.weight", "conv_out.weight")
+
+    def oracle(odt):
+        sdr = {k: (v.to(odt).clone().requires_grad_(True) if "weight_u" not in k and "weight_v" not in k else v.to(odt))
+               for k, v in sd.items() if k.startswith("Discriminator.")}
+        xr = x.to(odt).clone().requires_grad_(True)
+        out_r, logit_r, new_uv = O.discriminator_forward(sdr, xr, y.to(odt), training=True)
+        g = O.make_noise(11, tuple(logit_r.shape))
+        logit_r.backward(g.to(odt))
+        grads = {k: sdr["Discriminator." + k].grad for k in watch}
+        grads["input"] = xr.grad
+        return out_r.detach(), logit_r.detach(), new_uv, g, grads
+
+    out_r, logit_r, new_uv, g, ref = oracle(torch.float32)
     xd = x.to(dev).requires_grad_(True)
     out, logits = D(xd, y.to(dev))
     logits.backward(g.to(dev))
     torch.cuda.synchronize()
-    assert _relerr(logits.detach().cpu(), logit_r.detach()) < tol
-    assert _relerr(out.cpu(), out_r.detach()) < tol
+    assert _relerr(logits.detach().cpu(), logit_r) < tol
+    assert _relerr(out.cpu(), out_r) < tol
     assert _relerr(D.conv2.weight_u.cpu(), new_uv["Discriminator.conv2.weight_u"]) < 1e-4
-    _check_grad(xd.grad.cpu(), xr.grad, _gtol(tol), "input")
-    for k in ("conv1.weight_orig", "conv4.weight_orig", "conv3.bias", "context_conv.weight", "conv_out.weight"):
-        _check_grad(dict(D.named_parameters())[k].grad.cpu(), sdr["Discriminator." + k].grad, _gtol(tol), k)
+    params = dict(D.named_parameters())
+    got = {k: params[k].grad.cpu() for k in watch}
+    got["input"] = xd.grad.cpu()
+    _check_grads(got, ref, _gtol(tol), f"Discriminator {dt}", lambda: oracle(torch.float64)[4])
 
 
 @pytest.mark.parametrize("gan", [False, True], ids=["compression", "compression_gan"])
@@ -179,10 +213,15 @@ def test_model_losses_and_grads_fp32(hific, dev, sd, gan):
              "Hyperprior.synthesis_std.conv1.weight", "Hyperprior.hyperlatent_likelihood.H_2"]
     if gan:
         watch.append("Discriminator.conv2.weight_orig")
-    sdr = {k: (v.clone().requires_grad_(True) if k in watch else v.clone()) for k, v in sd.items()}
-    out = O.model_forward(sdr, bb, lins, x, step_counter=1, training=True, gan=gan, train_generator=True,
-                          noise_hyper=nh, noise_latent=nl, n_residual_blocks=N_RES)
-    out["compression"].backward()
+    def oracle(odt):
+        sdr = {k: ((v.to(odt) if v.dtype.is_floating_point else v).clone().requires_grad_(k in watch)) for k, v in sd.items()}
+        out = O.model_forward(sdr, {k: v.to(odt) for k, v in bb.items()}, [l.to(odt) for l in lins], x.to(odt),
+                              step_counter=1, training=True, gan=gan, train_generator=True, noise_hyper=nh.to(odt),
+                              noise_latent=nl.to(odt), n_residual_blocks=N_RES)
+        out["compression"].backward()
+        return out, {k: sdr[k].grad for k in watch}
+
+    out, ref = oracle(torch.float32)
     a, b = float(losses["compression"]), float(out["compression"])
     assert abs(a - b) < 1e-3 * abs(b), (a, b)
     if gan:
@@ -203,8 +242,8 @@ def test_model_losses_and_grads_fp32(hific, dev, sd, gan):
         rec_ref = O.generator_forward(sd, dec_h, N_RES)
     assert _relerr(inter.reconstruction.detach().float().cpu(), rec_ref) < 1e-3
     params = dict(model.named_parameters())
-    for k in watch:
-        _check_grad(params[k].grad.cpu(), sdr[k].grad, 1e-3, k)
+    _check_grads({k: params[k].grad.cpu() for k in watch}, ref, 1e-3, f"Model f32 gan={gan}",
+                 lambda: oracle(torch.float64)[1])
 
 
 def test_zz_hyperprior_compress_roundtrip(hific, dev, tmp_path):

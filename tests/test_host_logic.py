@@ -218,14 +218,31 @@ def test_option_variants_keep_the_reference_layout(hific):
 
 def test_arena_slots_written_by_autograd_are_tracked(hific):
     """A parameter whose gradient comes from ATen (the InstanceNorm fallback's affine pair) is accumulated in place into
-    its arena slot by autograd: the slot must count as written (zero_unwritten keeps it, buckets see it) and must be
-    cleared by zero_grad() - otherwise the next step adds onto stale values."""
+    its arena slot by autograd: the slot must count as written (zero_unwritten keeps it, buckets see it exactly once) and the
+    first accumulation after zero_grad() must land on zeros, not on the previous step's values.  Slots
+    written by kernels (their Functions return None to autograd) must NOT be touched by this mechanism."""
     import torch
     from hific_amd import optim
     from hific_amd.normalisation import instance
     torch.manual_seed(0)
     norm = instance.InstanceNorm2D_wrap(6, fuse_relu=True)
-    arena = optim.ParamArena(list(norm.parameters()))
+    kernel_written = torch.nn.Parameter(torch.ones(6))
+
+    class KernelLike(torch.autograd.Function):          # what ops.Conv2dFn does: writes the slot itself, returns None
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.slot = w._hific_slot
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            acc = ctx.slot.take()
+            val = g.sum(dim=(0, 2, 3))
+            ctx.slot.grad.copy_(ctx.slot.grad + val if acc else val)
+            ctx.slot.written()
+            return g, None
+
+    arena = optim.ParamArena(list(norm.parameters()) + [kernel_written])
     seen = []
     arena.on_write = lambda slot: seen.append(slot.index)
     x = torch.randn(2, 6, 5, 5)
@@ -237,13 +254,14 @@ def test_arena_slots_written_by_autograd_are_tracked(hific):
         return ref.weight.grad, ref.bias.grad
 
     for step in range(3):
-        torch.relu(norm(x) if not norm.fuse_relu else norm(x)).square().sum().backward()
+        seen.clear()
+        KernelLike.apply(norm(x), kernel_written).square().sum().backward()
         gw, gb = grads()
-        assert all(not s.fresh and s.autograd for s in arena.slots)
-        assert torch.allclose(arena.slots[0].grad, gw, atol=1e-5) and torch.allclose(arena.slots[1].grad, gb, atol=1e-5)
+        assert all(not s.fresh for s in arena.slots)
+        assert torch.allclose(arena.slots[0].grad, gw, atol=1e-4) and torch.allclose(arena.slots[1].grad, gb, atol=1e-4)
         assert norm.weight.grad.data_ptr() == arena.flat_grad.data_ptr()
+        assert sorted(seen) == [0, 1, 2], seen          # each slot reported exactly once per backward
         arena.zero_unwritten()                       # what FusedAdam.step does first: must not wipe these
-        assert torch.allclose(arena.slots[0].grad, gw, atol=1e-5)
+        assert torch.allclose(arena.slots[0].grad, gw, atol=1e-4)
         arena.zero_grad()
-        assert float(arena.flat_grad.abs().max()) == 0.0 and all(s.fresh for s in arena.slots)
-    assert sorted(set(seen)) == [0, 1]
+        assert all(s.fresh for s in arena.slots)
