@@ -14,6 +14,22 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+// Dynamic-LDS opt-in per kernel function, raised monotonically (never lowered): a launch recorded in a hipGraph is
+// replayed later, when another layer's launch of the same function may have asked for less; and the attribute call
+// leaves the per-launch host path once a function has reached its maximum.
+#include <mutex>
+#include <unordered_map>
+static void gc_set_max_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> cur;
+    std::lock_guard<std::mutex> lock(mu);
+    int& c = cur[fn];
+    if (bytes > c) {
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        c = bytes;
+    }
+}
+
 // K-slice of one MFMA and LDS row padding per element type; BC (channels per chunk) is a kernel template parameter
 template <typename T> struct GcCfg;
 template <> struct GcCfg<bf16_t> { static constexpr int KS = 16, PAD = 16; };
@@ -2148,11 +2164,11 @@ extern "C" int hific_pack_batch(const void* jobs_dev, const int* prefix_dev, int
     if (!jobs_dev || !prefix_dev || njobs <= 0 || total_blocks <= 0) return HIFIC_ERR_ARG;
     if (dtype == HIFIC_BF16) {
         if (lds_bytes > 48 * 1024)
-            hipFuncSetAttribute((const void*)pack_batch_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            gc_set_max_lds((const void*)pack_batch_kernel<bf16_t>, (int)lds_bytes);
         hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, dim3(total_blocks), dim3(256), lds_bytes, st, (const PackJob*)jobs_dev, prefix_dev, njobs);
     } else if (dtype == HIFIC_F32) {
         if (lds_bytes > 48 * 1024)
-            hipFuncSetAttribute((const void*)pack_batch_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            gc_set_max_lds((const void*)pack_batch_kernel<float>, (int)lds_bytes);
         hipLaunchKernelGGL(pack_batch_kernel<float>, dim3(total_blocks), dim3(256), lds_bytes, st, (const PackJob*)jobs_dev, prefix_dev, njobs);
     } else return HIFIC_ERR_ARG;
     return hific_launch_status();
@@ -2475,11 +2491,11 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     if (ws.wcache_state != 2) {
         if (job.mode == 0) {
             if (job.lds_bytes > 48 * 1024)
-                hipFuncSetAttribute((const void*)pack_w2_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, job.lds_bytes);
+                gc_set_max_lds((const void*)pack_w2_kernel<T, 0>, job.lds_bytes);
             hipLaunchKernelGGL((pack_w2_kernel<T, 0>), dim3(job.gx, job.gy), dim3(256), job.lds_bytes, st, p, w, w_scale, sm, sc, job.RS, job.MB);
         } else if (job.mode == 1) {
             if (job.lds_bytes > 48 * 1024)
-                hipFuncSetAttribute((const void*)pack_w2_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, job.lds_bytes);
+                gc_set_max_lds((const void*)pack_w2_kernel<T, 1>, job.lds_bytes);
             hipLaunchKernelGGL((pack_w2_kernel<T, 1>), dim3(job.gx, job.gy), dim3(256), job.lds_bytes, st, p, w, w_scale, sm, sc, job.RS, job.MB);
         } else {
             hipLaunchKernelGGL(pack_w_kernel<T>, dim3(job.gx, p.nphase), dim3(256), 0, st, p, w, w_scale, sm, sc, sr, ss);
@@ -2520,7 +2536,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             if constexpr (nwp_ * 7 <= 8) { if (tps == 7) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 7>; } \
         }                                                                                                \
         if (lds > 48 * 1024)                                                                             \
-            hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            gc_set_max_lds((const void*)kfn, (int)lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);                                            \
     } while (0)
     bool sp_done = false;
@@ -2533,7 +2549,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                 const bool ks2 = env_int("HIFIC_SP9_KSPLIT", 2) == 2;
 #define SP9_LAUNCH(WM_, KSP_, RFX_, PHS_)                                                                           \
     do {                                                                                                            \
-        hipFuncSetAttribute((const void*)gconv_sp9_kernel<WM_, KSP_, RFX_, PHS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp); \
+        gc_set_max_lds((const void*)gconv_sp9_kernel<WM_, KSP_, RFX_, PHS_>, (int)lds_sp); \
         hipLaunchKernelGGL((gconv_sp9_kernel<WM_, KSP_, RFX_, PHS_>), grid, dim3(256 * KSP_), lds_sp, st, p);       \
     } while (0)
                 // shifted B fragments (DS): 16-pixel tile rows, taps (dy, dx) with dx ascending by one pixel
@@ -2547,7 +2563,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                 else if (phs == 2) SP9_LAUNCH(1, 1, false, 2);
                 else if (p.rfx) { if (bm == 128) SP9_LAUNCH(2, 2, true, 0); else SP9_LAUNCH(1, 1, true, 0); }
                 else if (bm == 128 && ks2 && ds) {
-                    hipFuncSetAttribute((const void*)gconv_sp9_kernel<2, 2, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
+                    gc_set_max_lds((const void*)gconv_sp9_kernel<2, 2, false, 0, true>, (int)lds_sp);
                     hipLaunchKernelGGL((gconv_sp9_kernel<2, 2, false, 0, true>), grid, dim3(512), lds_sp, st, p);
                 }
                 else if (bm == 128) { if (ks2) SP9_LAUNCH(2, 2, false, 0); else SP9_LAUNCH(2, 1, false, 0); }
@@ -3074,7 +3090,7 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
                     sh3 = sh3 && p.tap_dy[3 * d + j] == p.tap_dy[3 * d] && p.tap_dx[3 * d + j] == p.tap_dx[3 * d] + j;
 #define WGP_LAUNCH(TS_, SH_)                                                                                       \
     do {                                                                                                           \
-        hipFuncSetAttribute((const void*)wgrad_pipe_kernel<TS_, SH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe); \
+        gc_set_max_lds((const void*)wgrad_pipe_kernel<TS_, SH_>, (int)lds_pipe); \
         hipLaunchKernelGGL((wgrad_pipe_kernel<TS_, SH_>), grid, dim3(256 * TS_), lds_pipe, st, p);                 \
     } while (0)
             if (ts2) { if (sh3) WGP_LAUNCH(2, true); else WGP_LAUNCH(2, false); }
@@ -3089,7 +3105,7 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
             else if (p.wstage_a || p.wstage_b) kfn = wgrad_kernel<T, -1>;
         }
         if (lds > 48 * 1024)
-            hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            gc_set_max_lds((const void*)kfn, (int)lds);
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
     }
     prof_close(pslot, st);
@@ -3191,7 +3207,7 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     void (*kfn)(const WgParams) = (std::is_same<T, float>::value || p.b_f32) ? wgrad_im2col_kernel<T, true>
                                                                               : wgrad_im2col_kernel<T, false>;
     if (lds > 48 * 1024)
-        hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        gc_set_max_lds((const void*)kfn, (int)lds);
     char ptag[112];
     snprintf(ptag, sizeof(ptag), "wgrad_im2col K%d C%d N%d out%dx%d taps%d split%d", g.K, g.C, g.N, g.OH(), g.OW(), nt, p.nsplit);
     const int pslot = prof_open(std::is_same<T, float>::value ? "wgrad_im2col_kernel<f32>" : "wgrad_im2col_kernel<bf16>",
