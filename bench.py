@@ -153,10 +153,13 @@ def graphed(args, step, world):
     try:
         return GraphedStep(step, warmup=max(2, args.warmup), generators=step.generators), True
     except Exception as e:                    # a capture failure must not cost the measurement
-        print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-        import torch
-        torch.cuda.synchronize()
-        return step, False
+        # a failed capture leaves its streams in capture mode for the rest of the process: start over without graphs
+        print(f"[bench] hipGraph capture failed ({type(e).__name__}: {str(e).splitlines()[0]}); re-running eagerly",
+              file=sys.stderr, flush=True)
+        if world > 1:
+            raise
+        os.environ["HIFIC_BENCH_GRAPH"] = "0"
+        os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
 
 
 def timed(step, steps, warmup, fence):

@@ -35,6 +35,11 @@ class GraphedStep:
                 fn()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
+        # the device is idle: drop the cross-stream ordering events of the warm-up (a capturing stream may only wait on
+        # events recorded inside the capture)
+        from . import ops
+        ops.pack_cache.settle()
+        ops.wait_late_params()
         self.graph = torch.cuda.CUDAGraph()
         for g in generators:
             self.graph.register_generator_state(g)

@@ -100,6 +100,13 @@ class WeightPackCache:
         self.entries.clear(); self.prepared.clear()
         self.bytes = 0
 
+    def settle(self):
+        """Call after a device synchronize: every pack issued so far is complete, so no stream needs to order itself after
+        a pack event any more.  hific_amd.graph.GraphedStep does this before capturing - a stream inside a capture must not
+        wait on an event recorded before the capture began."""
+        for e in self.entries.values():
+            e.event, e.pack_sid, e.waited = None, None, set()
+
     def lookup(self, weight, kind, geom, cd, flags, transposed):
         """-> (wcache ptr, bytes, state) for the C-ABI call."""
         if not _PACK_CACHE_ON:

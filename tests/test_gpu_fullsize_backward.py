@@ -149,9 +149,9 @@ def test_gan_cycle_every_gradient_fullsize_f32(hific, dev):
     worst_D, arb_D = check_grads(dev_D, o32["D"], lambda: o64()["D"], 1e-3, "D-turn, Discriminator (G-turn leftovers + D-turn)")
     for k, v in o32["uv"].items():
         assert torch.allclose(uv_dev[k], v, atol=1e-5), k
-    print(f"  full-size f32 gradients vs oracle: worst G-turn {worst_G:.2e}, worst D-turn {worst_D:.2e}; judged on the "
-          f"float64 oracle: {arb_G + arb_D}")
-    assert len(arb_G) <= 8 and len(arb_D) <= 2, "too many tensors needed the float64 arbiter"
+    print(f"  full-size f32 gradients vs oracle: worst G-turn {worst_G:.2e}, worst D-turn {worst_D:.2e}; beyond the plain "
+          f"1e-3 bar and judged separately (tests/gradcheck.py): {sorted(arb_G) + sorted(arb_D)}")
+    assert len(arb_G) <= 8 and len(arb_D) <= 2, "too many tensors needed a second opinion"
 
 
 def test_config5_one_1024_crop_regime_high(hific, dev):
