@@ -18,6 +18,7 @@ import pytest
 import torch
 
 from oracle import hific_oracle as O
+from gradcheck import check_grads
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -136,13 +137,11 @@ def _run_ranks(gan, tmp_path):
 
 
 def _compare(got, want, tol, what):
-    worst = ("", 0.0)
-    for k, g in want.items():
-        e = float((got[k] - g).abs().max()) / max(float(g.abs().max()), 1e-30)
-        if e > worst[1]:
-            worst = (k, e)
-    print(f"  [{what}] worst gradient mismatch {worst[1]:.2e} at {worst[0]}")
-    assert worst[1] < tol, (what, worst)
+    """Same rule as the oracle comparisons (tests/gradcheck.py): per-tensor max error <= tol of the tensor's scale; a tensor
+    beyond it is accepted only with the signature of a ReLU sign tie (the planner picks kernels by grid size, so batch 2 and
+    batch 4 forwards differ by float32 summation order, and a pre-activation at +-1e-7 can get the other mask): the
+    beyond-bar elements sit in <= 8 channel slices."""
+    check_grads(got, want, None, tol, what)
 
 
 def test_two_ranks_equal_one_rank_with_the_global_batch(hific, dev, tmp_path):
