@@ -234,7 +234,7 @@ class Hyperprior(CodingModel):
             return (noisy_latent_bpp, noisy_hyperlatent_bpp, noisy_latent_bpp + noisy_hyperlatent_bpp,
                     quantized_latent_bpp, quantized_hyperlatent_bpp, quantized_latent_bpp + quantized_hyperlatent_bpp)
 
-        if ops.branch_streams_on() and latents.is_cuda:
+        if ops.branch_use(1) and latents.is_cuda:
             main = torch.cuda.current_stream(latents.device)
             s2 = ops.branch_stream(latents.device)
             s2.wait_stream(main)

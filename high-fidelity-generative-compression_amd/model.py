@@ -158,7 +158,8 @@ class Model(nn.Module):
         branch = ops.branch_streams_on() and x.is_cuda
         self.perceptual_loss.drop_prefetch()
         # (with normalize_input_image the loss sees a rescaled copy of x, which a prefetch on x could never match)
-        if branch and self.model_mode != ModelModes.EVALUATION and self.args.normalize_input_image is not True:
+        if branch and ops.branch_use(0) and self.model_mode != ModelModes.EVALUATION \
+                and self.args.normalize_input_image is not True:
             # the LPIPS features of the input image depend on nothing the networks compute: start them on the branch
             # stream now, next to the Encoder (perceptual_loss_wrapper below picks them up)
             main = torch.cuda.current_stream(x.device)
@@ -168,7 +169,8 @@ class Model(nn.Module):
             with torch.cuda.stream(s2):
                 self.perceptual_loss.prefetch_target(x, normalize=True)
         intermediates, hyperinfo = self.compression_forward(x)
-        if branch and not (self.use_discriminator and self.model_mode != ModelModes.EVALUATION):
+        if branch and ops.branch_use(1) and not (self.use_discriminator and ops.branch_use(2)
+                                                 and self.model_mode != ModelModes.EVALUATION):
             # rates were produced on the branch stream (Hyperprior.forward, deferred join); below they are used on this one
             torch.cuda.current_stream(x.device).wait_stream(ops.branch_stream(x.device))
         if self.model_mode == ModelModes.EVALUATION:
@@ -183,7 +185,7 @@ class Model(nn.Module):
             # the reconstruction feeds the compression losses and D: explicit fan-out
             rec_a, rec_b = ops.fork(intermediates.reconstruction)
             inter_c, inter_d = intermediates._replace(reconstruction=rec_a), intermediates._replace(reconstruction=rec_b)
-        if self.use_discriminator and ops.branch_streams_on() and x.is_cuda:
+        if self.use_discriminator and ops.branch_use(2) and x.is_cuda:
             # The distortion / LPIPS / rate branch and the Discriminator branch only meet again in the sum below: the
             # first runs on a second stream, concurrently with D.  autograd replays every op's backward on the stream
             # its forward ran on (and synchronises producers with consumers), so the two backward chains overlap too.

@@ -417,15 +417,30 @@ def set_side_stream(on):
     _SIDE_ON = bool(on)
 
 
+def _stream_capturing(st):
+    with torch.cuda.stream(st):
+        return torch.cuda.is_current_stream_capturing()
+
+
+def _may_wait(cur, other):
+    """Inside a hipGraph capture a stream may only wait for streams that are part of the same capture; one that took no work
+    in this capture has nothing to wait for anyway."""
+    return not torch.cuda.is_current_stream_capturing() or _stream_capturing(other)
+
+
 def join_side_stream():
     """Make the current stream wait for every weight-gradient kernel launched on the side stream so far."""
     if _side_state["pending"] or _branch_streams:
         for dev_index, side in _side_streams.items():
-            torch.cuda.current_stream(dev_index).wait_stream(side)
+            cur = torch.cuda.current_stream(dev_index)
+            if _may_wait(cur, side):
+                cur.wait_stream(side)
         # kernels of ops whose forward ran on the branch stream write parameter gradients (arena slots) from that stream in
         # backward; autograd's own end-of-backward synchronisation only covers gradients it accumulates itself
         for dev_index, br in _branch_streams.items():
             cur = torch.cuda.current_stream(dev_index)
+            if not _may_wait(cur, br):
+                continue
             if cur.cuda_stream != br.cuda_stream:
                 cur.wait_stream(br)
             else:
@@ -499,6 +514,20 @@ _branch_streams = {}
 
 def branch_streams_on():
     return _BRANCH_ON
+
+
+# which of the three branch-stream uses are active (bit 0: LPIPS target prefetch, bit 1: hyperprior rate side, bit 2: loss
+# branch next to the Discriminator branch); HIFIC_BRANCH_MASK for experiments
+_BRANCH_MASK = int(os.environ.get("HIFIC_BRANCH_MASK", "7"))
+
+
+def branch_use(bit):
+    return _BRANCH_ON and bool(_BRANCH_MASK & (1 << bit))
+
+
+def set_branch_mask(mask):
+    global _BRANCH_MASK
+    _BRANCH_MASK = int(mask)
 
 
 def set_branch_streams(on):

@@ -8,7 +8,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-CASES = ["add", "conv_fwd_small", "conv_fwd_sp9", "conv_fwd_bwd_1stream", "conv_fwd_bwd_side", "encoder_fwd",
+CASES = ["syn_fork_alloc", "syn_fork_twice", "syn_record_stream", "syn_event_later", "syn_fork_hific", "model_fwd_mask1",
+         "model_fwd_mask2", "model_fwd_mask4", "model_fwd_mask3", "gturn_mask1", "gturn_mask2", "gturn_mask4", "add", "conv_fwd_small", "conv_fwd_sp9", "conv_fwd_bwd_1stream", "conv_fwd_bwd_side", "encoder_fwd",
          "model_fwd_1stream", "model_fwd_branch", "gturn_1stream", "gturn_side", "gturn_branch", "gturn_all",
          "cycle_1stream", "cycle_all"]
 
@@ -26,7 +27,40 @@ def run_case(name):
     branch = name.endswith("_branch") or name.endswith("_all")
     ops.set_side_stream(side)
     ops.set_branch_streams(branch)
-    if name == "add":
+    if "_mask" in name:
+        ops.set_branch_streams(True)
+        ops.set_branch_mask(int(name.split("_mask")[1]))
+        name = name.split("_mask")[0] + "_x"
+    if name.startswith("syn_"):
+        s2 = torch.cuda.Stream()
+        a = torch.randn(1 << 20, device=dev)
+        keep = {}
+
+        def fn():
+            main = torch.cuda.current_stream()
+            s2.wait_stream(main)
+            if name == "syn_record_stream":
+                a.record_stream(s2)
+            with torch.cuda.stream(s2):
+                b = (a * 2.0 + 1.0) if name != "syn_fork_hific" else ops._add(a, a)
+                if name == "syn_event_later":
+                    keep["ev"] = torch.cuda.current_stream().record_event()
+            c = a + 3.0
+            if name == "syn_event_later":
+                main.wait_event(keep.pop("ev"))
+            else:
+                main.wait_stream(s2)
+            if name == "syn_record_stream":
+                b.record_stream(main)
+            out = b + c
+            if name == "syn_fork_twice":
+                s2.wait_stream(main)
+                with torch.cuda.stream(s2):
+                    d = out * 0.5
+                main.wait_stream(s2)
+                out = out + d
+            return out
+    elif name == "add":
         a = torch.randn(1 << 20, device=dev).bfloat16()
         fn = lambda: ops._add(a, a)
     elif name.startswith("conv_fwd_small") or name.startswith("conv_fwd_sp9") or name.startswith("conv_fwd_bwd"):
