@@ -109,6 +109,7 @@ class TargetFeatures:
         # `target` keeps the tensor alive, so its address cannot be recycled for another batch while this is pending, and
         # the consumer matches by identity of the storage (data_ptr + version + shape of a live tensor)
         self.key, self.feats, self.event, self.target = key, feats, event, target
+        self.stream_id = torch.cuda.current_stream(target.device).cuda_stream       # where `event` was recorded
 
 
 def _target_key(target, normalize, cd, net="alex"):
@@ -131,7 +132,10 @@ class LpipsFn(Function):
         ws = lib.workspace(pred.device)
         if pre is not None and pre.key == _target_key(target, normalize, cd, net):
             cur = torch.cuda.current_stream(pred.device)
-            cur.wait_event(pre.event)
+            # same stream (the loss branch runs on the stream the prefetch ran on): stream order already holds - and a
+            # stream waiting on its own event inside a hipGraph capture crashes hipStreamEndCapture (ROCm 7.2)
+            if cur.cuda_stream != pre.stream_id:
+                cur.wait_event(pre.event)
             feats = pre.feats
             for f in feats:
                 f.record_stream(cur)

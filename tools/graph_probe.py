@@ -9,7 +9,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CASES = ["syn_fork_alloc", "syn_fork_twice", "syn_record_stream", "syn_event_later", "syn_fork_hific", "model_fwd_mask1",
-         "model_fwd_mask2", "model_fwd_mask4", "model_fwd_mask3", "gturn_mask1", "gturn_mask2", "gturn_mask4", "add", "conv_fwd_small", "conv_fwd_sp9", "conv_fwd_bwd_1stream", "conv_fwd_bwd_side", "encoder_fwd",
+         "model_fwd_mask2", "model_fwd_mask4", "model_fwd_mask3", "gturn_mask1", "gturn_mask2", "gturn_mask4", "model_fwd_mask5", "model_fwd_mask6", "model_fwd_mask7", "gturn_mask7",
+         "add", "conv_fwd_small", "conv_fwd_sp9", "conv_fwd_bwd_1stream", "conv_fwd_bwd_side", "encoder_fwd",
          "model_fwd_1stream", "model_fwd_branch", "gturn_1stream", "gturn_side", "gturn_branch", "gturn_all",
          "cycle_1stream", "cycle_all"]
 
