@@ -143,11 +143,13 @@ def make_step(args, model, opts, reducers, dev, config):
     return step
 
 
-def graphed(args, step, world):
-    """The step as one hipGraph replay (hific_amd.graph.GraphedStep) - default at one rank; HIFIC_BENCH_GRAPH=0 keeps the
-    eager launch path, =1 forces capture also under torch.distributed (RCCL collectives inside the capture: untested)."""
+def graphed(args, step, world, force=False):
+    """The step as one hipGraph replay (hific_amd.graph.GraphedStep).  Measured (round 3, ROCm 7.2): the capture is
+    bit-identical to eager execution, but hipGraphLaunch of the ~1000-node cycle costs the host 21.6 ms per replay against
+    24.4 ms of eager enqueue, and the cycle is GPU-bound either way (29.8 vs 29.5 ms): eager stays the default for the
+    headline, HIFIC_BENCH_GRAPH=1 switches it, and the `graph` extras leg reports the replayed cycle next to it."""
     flag = os.environ.get("HIFIC_BENCH_GRAPH", "")
-    if flag == "0" or (world > 1 and flag != "1") or os.environ.get("HIFIC_FORCE_DIST") == "1" and flag != "1":
+    if flag != "1" and not force:
         return step, False
     from hific_amd.graph import GraphedStep
     try:
@@ -159,6 +161,7 @@ def graphed(args, step, world):
         if world > 1:
             raise
         os.environ["HIFIC_BENCH_GRAPH"] = "0"
+        os.environ["HIFIC_BENCH_NO_GRAPH_LEG"] = "1"
         os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
 
 
@@ -601,6 +604,23 @@ def main():
                            sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "gemm_class_ms_per_step": round(sum(v["ms_per_step"] for v in prof.values()), 3),
         }
+        # ---- the same cycle as ONE hipGraph replay (hific_amd.graph.GraphedStep; bit-identical: tests/test_gpu_zz_graph.py)
+        if not is_graph and os.environ.get("HIFIC_BENCH_NO_GRAPH_LEG") != "1":
+            gstep, ok = graphed(args, step, world, force=True)
+            if ok:
+                ng = max(3, min(args.steps, 10))
+                fence(); t0 = time.perf_counter()
+                for _ in range(ng):
+                    gstep()
+                t_host = time.perf_counter() - t0
+                fence(); eg = time.perf_counter() - t0
+                out["graph"] = {"value": round(world * imgs_per_step * ng / eg, 3), "unit": "images/s",
+                                "ms_per_step": round(eg / ng * 1e3, 3), "host_ms_per_replay": round(t_host / ng * 1e3, 3),
+                                "workload": "the headline cycle captured once into a hipGraph (side / branch streams and the "
+                                            "autograd backward included) and replayed; eager launch stays the headline "
+                                            "because hipGraphLaunch of ~1000 nodes costs the host about as much as enqueueing "
+                                            "them"}
+            del gstep
         del model, opts, reducers, step, run_step
         hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
         torch.cuda.empty_cache()
