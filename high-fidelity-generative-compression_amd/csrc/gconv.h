@@ -45,6 +45,8 @@ struct GcParams {
     int epi_wide;        // wide-store epilogue through LDS (gc_epilogue_wide): legality checked by the plan
     int wstage;          // wide-load staging (stage_W): bf16 NCHW input, IW % 8 == 0, 16-byte aligned (set by the plan)
     int rfx;             // gather-form reflect data gradient (gconv_sp9_kernel RFX): `in` is the extended gradient
+    int afrag;           // packed weights in MFMA A-fragment order (gc_wp_index): gconv_sp9_kernel AG streams them
+                         // global -> registers, bypassing LDS
     // reflect-padded data gradient: `out` is the f32 padded plane buffer (only its rim is written); pixels inside
     // [fold_pt, fold_pt+fold_h) x [fold_pl, fold_pl+fold_w) go straight to out2 = dx[N,K,fold_h,fold_w]
     void* out2;

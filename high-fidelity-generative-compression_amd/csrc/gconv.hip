@@ -705,12 +705,18 @@ __host__ __device__ constexpr int sp9_tap_in_phase(int phs, int t) {
 // row is exactly one 16-lane DPP row, so taps dx = 1, 2 of a kernel row take their fragments with `row_shl:1` from the
 // previous tap's and only the last pixel of each tile row (lanes 15, 31, 47, 63: the halo column) reads LDS.  B-side LDS
 // reads per kernel row: 3 KB -> 1.1 KB per fragment slice (the kernel is LDS-read bound).
-template <int WM, int KSP, bool RFX, int PHS, bool DS = false>
+// AG = true (128-row tiles, K-split): the packed weights are in MFMA A-fragment order (GcParams::afrag, gc_wp_index) and
+// every wave loads its own A operands global -> registers (one contiguous 1 KB per operand, two steps ahead) instead of
+// the workgroup staging a weight tile through LDS.  Per step and CU that removes the 16 KB tile write and 32 KB of A-fragment
+// reads from LDS (of 83 KB: the kernel was LDS-issue bound), frees the 55 KB weight ring, and leaves the
+// patch double buffer as the only shared state: ONE barrier per 64-channel chunk instead of one per tap.
+template <int WM, int KSP, bool RFX, int PHS, bool DS = false, bool AG = false>
 __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(PHS ? 1 : 2, PHS ? 1 : 2)))
 void gconv_sp9_kernel(const GcParams p) {
     typedef bf16_t T;
     static_assert(!(PHS && (RFX || KSP != 1)), "phase-merged mode: 4 waves, no reflect gather");
     static_assert(!(DS && (RFX || PHS)), "shifted fragments: plain 3x3 stride-1 forward type only");
+    static_assert(!AG || (WM == 2 && KSP == 2 && PHS == 0 && !DS), "A-from-global: 128-row K-split tiles");
     constexpr int NPH = PHS ? 4 : 1;
     constexpr int BC = 64, KS = 16, PITCH = 144, PPR = 8, WGN = 2, WN = 2, NT = 9, QJ = 3;
     constexpr int BM = 2 * WM * 32;
@@ -753,7 +759,7 @@ void gconv_sp9_kernel(const GcParams p) {
 
     int* toffs = (int*)smem;                                   // [16] byte offset of each tap inside the patch
     unsigned char* wbuf = smem + 64;                           // 3 x WBYTES
-    unsigned char* pbuf = wbuf + 3 * WBYTES;                   // 2 x patch_bytes
+    unsigned char* pbuf = wbuf + (AG ? 0 : 3 * WBYTES);        // 2 x patch_bytes (AG: no weight ring)
     if (tid < NT)
         toffs[tid] = (((int)p.tap_dy[tid] - ph.dy_min) * PW + ((int)p.tap_dx[tid] - ph.dx_min)) * PITCH;
     if (RFX && tid < 2 * (PITCH / 4))                          // the all-zero pixel row of both patch buffers
@@ -837,6 +843,12 @@ void gconv_sp9_kernel(const GcParams p) {
         }
     }
 
+    // AG: this wave's A operands in the fragment-ordered image: [(32-row block * NT + tap) * nchunks + chunk][4 slices][1 KB]
+    const unsigned char* abase[WM];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+        abase[mi] = (const unsigned char*)p.wp + ((size_t)((m0 >> 5) + wm * WM + mi) * NT * nchunks) * 4096 + lane * 16;
+    u32x4_t aS[3][WM][BC / KS / KSP];
     constexpr int PD = 2 / KSP;                                 // patch dword columns issued per step (steps 0..3)
     u32x4_t wS[3][NWP];
     unsigned short rlo[3][PD * QJ], rhi[3][PD * QJ];
@@ -854,6 +866,12 @@ void gconv_sp9_kernel(const GcParams p) {
          const size_t off_ = ((size_t)sp9_tap_in_phase(PHS, tt) * p.Cpad + (size_t)c_ * BC) * sizeof(T); \
          _Pragma("unroll") for (int i = 0; i < NWP; ++i)                                           \
              wS[SET][i] = *(const u32x4_t*)(wsrc[sp9_phase(PHS, tt)][i] + off_); } while (0)
+#define SP_AISSUE(SET, cc, tt)                                                                     \
+    do { const int c_ = (cc) < nchunks ? (cc) : nchunks - 1;                                       \
+         const size_t off_ = (((size_t)(tt) * nchunks + c_) * 4 + kgrp_k0) * 1024;                 \
+         _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                         \
+             _Pragma("unroll") for (int kq = 0; kq < BC / KS / KSP; ++kq)                          \
+                 aS[SET][mi][kq] = *(const u32x4_t*)(abase[mi] + off_ + kq * 1024); } while (0)
 #define SP_WRETIRE(SET, SLOT)                                                                      \
     do { _Pragma("unroll") for (int i = 0; i < NWP; ++i)                                           \
              *(u32x4_t*)(wbuf + (SLOT) * WBYTES + wdst[i]) = wS[SET][i]; } while (0)
@@ -897,8 +915,10 @@ void gconv_sp9_kernel(const GcParams p) {
         _Pragma("unroll") for (int kq = 0; kq < BC / KS / KSP; ++kq) {                                          \
             const int kk = kq + kgrp_k0;                                                                        \
             bf16x8_t a[WM], b[WN];                                                                              \
-            _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
-                a[mi] = *(const bf16x8_t*)(ab + mi * 32 * PITCH + kk * 32);                                     \
+            _Pragma("unroll") for (int mi = 0; mi < WM; ++mi) {                                                 \
+                if constexpr (AG) a[mi] = __builtin_bit_cast(bf16x8_t, aS[SLOT][mi][kq]);                       \
+                else a[mi] = *(const bf16x8_t*)(ab + mi * 32 * PITCH + kk * 32);                                \
+            }                                                                                                   \
             _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                                 \
                 if constexpr (DS) {                                                                             \
                     if ((tt) % 3 == 0) {                                                                        \
@@ -921,21 +941,40 @@ void gconv_sp9_kernel(const GcParams p) {
     } while (0)
     // step tt of the current chunk: tile (chunk, tt) sits in ring slot tt%3; issue into register set tt%3,
     // retire the set issued two steps ago ((tt+1)%3) = tile tt+1 -> slot (tt+1)%3
+    // AG: operands of step tt sit in register set tt%3 (requested two steps earlier); the patch double buffer is the only
+    // shared state - next chunk's rows are written in steps 2..5 and first read after the barrier of the next chunk's step 0,
+    // which also orders the last reads of the buffer that becomes `pnext` there before its first overwrite (step 2)
 #define SP_STEP(tt)                                                                         \
     do {                                                                                    \
-        __syncthreads();                                                                    \
-        if ((tt) + 3 < NT) SP_WISSUE((tt) % 3, chunk, (tt) + 3);                            \
-        else SP_WISSUE((tt) % 3, chunk + 1, (tt) + 3 - NT);                                 \
-        if ((tt) < 4) SP_PISSUE((tt) % 3, tt);                                              \
-        SP_COMPUTE((tt) % 3, tt);                                                           \
-        SP_WRETIRE(((tt) + 1) % 3, ((tt) + 1) % 3);                                         \
-        if ((tt) >= 2 && (tt) < 6) SP_PRETIRE(((tt) + 1) % 3, (tt) - 2);                    \
+        if constexpr (AG) {                                                                 \
+            if ((tt) == 0) __syncthreads();                                                 \
+            if ((tt) + 2 < NT) SP_AISSUE(((tt) + 2) % 3, chunk, (tt) + 2);                  \
+            else SP_AISSUE(((tt) + 2) % 3, chunk + 1, (tt) + 2 - NT);                       \
+            if ((tt) < 4) SP_PISSUE((tt) % 3, tt);                                          \
+            /* keep the requests HERE: the scheduler otherwise sinks each load to just above its MFMA two steps later */ \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            SP_COMPUTE((tt) % 3, tt);                                                       \
+            if ((tt) >= 2 && (tt) < 6) SP_PRETIRE(((tt) + 1) % 3, (tt) - 2);                \
+        } else {                                                                            \
+            __syncthreads();                                                                \
+            if ((tt) + 3 < NT) SP_WISSUE((tt) % 3, chunk, (tt) + 3);                        \
+            else SP_WISSUE((tt) % 3, chunk + 1, (tt) + 3 - NT);                             \
+            if ((tt) < 4) SP_PISSUE((tt) % 3, tt);                                          \
+            SP_COMPUTE((tt) % 3, tt);                                                       \
+            SP_WRETIRE(((tt) + 1) % 3, ((tt) + 1) % 3);                                     \
+            if ((tt) >= 2 && (tt) < 6) SP_PRETIRE(((tt) + 1) % 3, (tt) - 2);                \
+        }                                                                                   \
     } while (0)
 
-    SP_WISSUE(0, 0, 0);
-    SP_WRETIRE(0, 0);
-    SP_WISSUE(1, 0, 1);
-    SP_WISSUE(2, 0, 2);
+    if constexpr (AG) {
+        SP_AISSUE(0, 0, 0);
+        SP_AISSUE(1, 0, 1);
+    } else {
+        SP_WISSUE(0, 0, 0);
+        SP_WRETIRE(0, 0);
+        SP_WISSUE(1, 0, 1);
+        SP_WISSUE(2, 0, 2);
+    }
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const unsigned char* pcur = pbuf + (chunk & 1) * patch_bytes;
         unsigned char* pnext = pbuf + ((chunk + 1) & 1) * patch_bytes;
@@ -947,6 +986,7 @@ void gconv_sp9_kernel(const GcParams p) {
 #undef SP_PRETIRE
 #undef SP_PISSUE
 #undef SP_WRETIRE
+#undef SP_AISSUE
 #undef SP_WISSUE
 
     if constexpr (KSP == 2) {
@@ -1028,6 +1068,17 @@ __host__ __device__ __forceinline__ long long gc_weight_index(const GcParams& p,
     if (p.msplit) { s = p.vcol_s[m % p.msplit]; m = m / p.msplit; }
     return m * sm + c * sc + r * sr + s * ss;
 }
+// Destination element index of packed weight (row m, tap t of phase ph, reduction channel c).  Default: [m][t][c].
+// afrag (gconv_sp9_kernel AG): MFMA A-fragment order - for every (32-row block, tap, 64-channel chunk, 16-deep slice) the
+// 64 lanes' 16-byte operands are contiguous (lane = (c / 8 % 2) * 32 + m % 32 holds channels c..c+7 of row m), so one
+// wave-wide 16-byte-per-lane load brings a whole v_mfma_f32_32x32x16_bf16 A operand as 1 KB of consecutive bytes.
+__host__ __device__ __forceinline__ long long gc_wp_index(const GcParams& p, const GcPhase& ph, int m, int t, int c) {
+    if (!p.afrag) return ((long long)m * ph.ntaps + t) * p.Cpad + c;
+    const int nch = p.Cpad >> 6;
+    const long long blk = (((long long)(m >> 5) * ph.ntaps + t) * nch + (c >> 6)) * 4 + ((c >> 4) & 3);   // 1 KB operand
+    const int lane = ((c >> 3) & 1) * 32 + (m & 31);
+    return (blk * 64 + lane) * 8 + (c & 7);
+}
 template <typename T>
 __global__ void pack_w_kernel(const GcParams p, const float* __restrict__ w, const float* scale,
                               long long sm, long long sc, long long sr, long long ss) {
@@ -1046,7 +1097,7 @@ __global__ void pack_w_kernel(const GcParams p, const float* __restrict__ w, con
             const int r = p.tap_r[ph.tap0 + t], s = p.tap_s[ph.tap0 + t];
             v = w[gc_weight_index(p, m, c, r, s, sm, sc, sr, ss)] * sc_;
         }
-        DT<T>::st(dst + i, v);
+        DT<T>::st(dst + gc_wp_index(p, ph, m, t, c), v);
     }
 }
 
@@ -1135,7 +1186,7 @@ __device__ __forceinline__ void pack_w2_body(const GcParams& p, const float* __r
             const int rs = (int)p.tap_r[ph.tap0 + t] * p.tap_sw + (int)p.tap_s[ph.tap0 + t];
             const float* lp = pk_lds + ml * RS + rs;
             const float v0 = lp[(cq + 0) * pitch], v1 = lp[(cq + 1) * pitch], v2 = lp[(cq + 2) * pitch], v3 = lp[(cq + 3) * pitch];
-            T* d = dst + ((long long)m * ph.ntaps + t) * p.Cpad + c0 + cq;
+            T* d = dst + gc_wp_index(p, ph, m, t, c0 + cq);        // cq % 4 == 0: the 4 channels stay in one 8-group
             if constexpr (std::is_same<T, float>::value) {
                 *(float4*)d = make_float4(v0, v1, v2, v3);
             } else {
@@ -1184,7 +1235,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
                 const int r = p.tap_r[ph.tap0 + t], s2 = p.tap_s[ph.tap0 + t];
                 v = J.w[gc_weight_index(p, m, c, r, s2, J.sm, J.sc, J.sr, J.ss)] * sc_;
             }
-            DT<T>::st(dst + i, v);
+            DT<T>::st(dst + gc_wp_index(p, ph, m, t, c), v);
         }
     }
 }
@@ -2447,6 +2498,14 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         const bool ok = use_sp9 && p.NI == 1 && p.TH >= 2 && p.TW >= 2 && (p.OHf - 1) % p.TH != 0 && (p.OWf - 1) % p.TW != 0;
         if (!ok) return HIFIC_ERR_UNSUPPORTED;
     }
+    // A operands streamed global -> registers from a fragment-ordered packed image (gconv_sp9_kernel AG): the 128-row K-split
+    // instantiations (residual-block forward and gather-form data gradient); decided before the pack job is built
+    p.afrag = 0;
+    if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
+        if (use_sp9 && !phs && bm == 128 && env_int("HIFIC_SP9_KSPLIT", 2) == 2 && !env_int("HIFIC_SP9_DS", 0) &&
+            env_int("HIFIC_SP9_AG", 1))
+            p.afrag = 1;
+    }
     const size_t wp_bytes = (size_t)(wp_elems > 0 ? wp_elems : 1) * sizeof(T);
     // pack tiling (coalesced LDS-transposing kernel when the taps of a (m,c) pair are contiguous and one of m/c is adjacent)
     PackJob job; memset(&job, 0, sizeof(job));
@@ -2559,7 +2618,19 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                 for (int r = 0; r < 3 && ds; ++r)
                     for (int c = 0; c < 3; ++c)
                         ds = ds && p.tap_dy[3 * r + c] == p.tap_dy[3 * r] && p.tap_dx[3 * r + c] == p.tap_dx[3 * r] + c;
-                if (phs == 1) SP9_LAUNCH(1, 1, false, 1);
+                if (p.afrag) {
+                    // no weight ring; the K-split exchange (64 KB) is the larger LDS use for the usual 180-pixel patch
+                    size_t lds_ag = 64 + 2 * (((size_t)(npatch + 2) * PITCH + 15) & ~(size_t)15);
+                    if (lds_ag < 65536) lds_ag = 65536;
+                    if (p.rfx) {
+                        gc_set_max_lds((const void*)gconv_sp9_kernel<2, 2, true, 0, false, true>, (int)lds_ag);
+                        hipLaunchKernelGGL((gconv_sp9_kernel<2, 2, true, 0, false, true>), grid, dim3(512), lds_ag, st, p);
+                    } else {
+                        gc_set_max_lds((const void*)gconv_sp9_kernel<2, 2, false, 0, false, true>, (int)lds_ag);
+                        hipLaunchKernelGGL((gconv_sp9_kernel<2, 2, false, 0, false, true>), grid, dim3(512), lds_ag, st, p);
+                    }
+                }
+                else if (phs == 1) SP9_LAUNCH(1, 1, false, 1);
                 else if (phs == 2) SP9_LAUNCH(1, 1, false, 2);
                 else if (p.rfx) { if (bm == 128) SP9_LAUNCH(2, 2, true, 0); else SP9_LAUNCH(1, 1, true, 0); }
                 else if (bm == 128 && ks2 && ds) {
