@@ -710,13 +710,16 @@ __host__ __device__ constexpr int sp9_tap_in_phase(int phs, int t) {
 // the workgroup staging a weight tile through LDS.  Per step and CU that removes the 16 KB tile write and 32 KB of A-fragment
 // reads from LDS (of 83 KB: the kernel was LDS-issue bound), frees the 55 KB weight ring, and leaves the
 // patch double buffer as the only shared state: ONE barrier per 64-channel chunk instead of one per tap.
-template <int WM, int KSP, bool RFX, int PHS, bool DS = false, bool AG = false>
+// AG levels (HIFIC_SP9_AG): 1 = as described; 2 = + s_setprio(1) around each step's MFMA cluster (the waves of a workgroup
+// are no longer in lockstep, so the CU scheduler has something to arbitrate); 3 = + the B fragments of the next tap are read
+// from LDS before the current tap's MFMAs are issued (register double buffer; taps of one chunk share the patch buffer).
+template <int WM, int KSP, bool RFX, int PHS, bool DS = false, int AG = 0>
 __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(PHS ? 1 : 2, PHS ? 1 : 2)))
 void gconv_sp9_kernel(const GcParams p) {
     typedef bf16_t T;
     static_assert(!(PHS && (RFX || KSP != 1)), "phase-merged mode: 4 waves, no reflect gather");
     static_assert(!(DS && (RFX || PHS)), "shifted fragments: plain 3x3 stride-1 forward type only");
-    static_assert(!AG || (WM == 2 && KSP == 2 && PHS == 0 && !DS), "A-from-global: 128-row K-split tiles");
+    static_assert(AG == 0 || (WM == 2 && KSP == 2 && PHS == 0 && !DS), "A-from-global: 128-row K-split tiles");
     constexpr int NPH = PHS ? 4 : 1;
     constexpr int BC = 64, KS = 16, PITCH = 144, PPR = 8, WGN = 2, WN = 2, NT = 9, QJ = 3;
     constexpr int BM = 2 * WM * 32;
@@ -849,6 +852,7 @@ void gconv_sp9_kernel(const GcParams p) {
     for (int mi = 0; mi < WM; ++mi)
         abase[mi] = (const unsigned char*)p.wp + ((size_t)((m0 >> 5) + wm * WM + mi) * NT * nchunks) * 4096 + lane * 16;
     u32x4_t aS[3][WM][BC / KS / KSP];
+    u32x4_t bS[2][WN][BC / KS / KSP];                           // AG >= 3: B fragments of the current / next tap
     constexpr int PD = 2 / KSP;                                 // patch dword columns issued per step (steps 0..3)
     u32x4_t wS[3][NWP];
     unsigned short rlo[3][PD * QJ], rhi[3][PD * QJ];
@@ -916,7 +920,7 @@ void gconv_sp9_kernel(const GcParams p) {
             const int kk = kq + kgrp_k0;                                                                        \
             bf16x8_t a[WM], b[WN];                                                                              \
             _Pragma("unroll") for (int mi = 0; mi < WM; ++mi) {                                                 \
-                if constexpr (AG) a[mi] = __builtin_bit_cast(bf16x8_t, aS[SLOT][mi][kq]);                       \
+                if constexpr (AG != 0) a[mi] = __builtin_bit_cast(bf16x8_t, aS[SLOT][mi][kq]);                       \
                 else a[mi] = *(const bf16x8_t*)(ab + mi * 32 * PITCH + kk * 32);                                \
             }                                                                                                   \
             _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                                 \
@@ -941,19 +945,54 @@ void gconv_sp9_kernel(const GcParams p) {
     } while (0)
     // step tt of the current chunk: tile (chunk, tt) sits in ring slot tt%3; issue into register set tt%3,
     // retire the set issued two steps ago ((tt+1)%3) = tile tt+1 -> slot (tt+1)%3
+    // AG >= 3: B fragments of tap tt into register set SETB (same address rule as SP_COMPUTE)
+#define SP_BLOAD(SETB, tt)                                                                                      \
+    do {                                                                                                        \
+        /* tap offset from the kernel arguments (constant index: scalar loads hoisted out of the loop), not from the  \
+           LDS table: that read sat in front of every step's fragment reads as one more LDS round trip */       \
+        const unsigned toff = (unsigned)((((int)p.tap_dy[tt] - ph.dy_min) * PW + ((int)p.tap_dx[tt] - ph.dx_min)) * PITCH); \
+        _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                                     \
+            unsigned bo_;                                                                                       \
+            if constexpr (RFX) {                                                                                \
+                const int d_ = rfx_r[ni][(tt) / 3] + rfx_c[ni][(tt) % 3];                                       \
+                bo_ = d_ < RFX_ZERO / 2 ? rfx_zrow : (unsigned)((int)(brow[ni] + toff) + d_);                   \
+            } else bo_ = brow[ni] + toff;                                                                       \
+            _Pragma("unroll") for (int kq = 0; kq < BC / KS / KSP; ++kq)                                        \
+                bS[SETB][ni][kq] = *(const u32x4_t*)(pcur + bo_ + (kq + kgrp_k0) * 32);                         \
+        }                                                                                                       \
+    } while (0)
+#define SP_MFMA_REG(SLOT, SETB)                                                                                 \
+    do {                                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                          \
+        _Pragma("unroll") for (int kq = 0; kq < BC / KS / KSP; ++kq)                                            \
+            _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
+                _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                               \
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                   \
+                        __builtin_bit_cast(bf16x8_t, aS[SLOT][mi][kq]), __builtin_bit_cast(bf16x8_t, bS[SETB][ni][kq]), \
+                        acc[0][mi][ni], 0, 0, 0);                                                               \
+        __builtin_amdgcn_s_setprio(0);                                                                          \
+    } while (0)
     // AG: operands of step tt sit in register set tt%3 (requested two steps earlier); the patch double buffer is the only
     // shared state - next chunk's rows are written in steps 2..5 and first read after the barrier of the next chunk's step 0,
     // which also orders the last reads of the buffer that becomes `pnext` there before its first overwrite (step 2)
 #define SP_STEP(tt)                                                                         \
     do {                                                                                    \
-        if constexpr (AG) {                                                                 \
+        if constexpr (AG != 0) {                                                              \
             if ((tt) == 0) __syncthreads();                                                 \
             if ((tt) + 2 < NT) SP_AISSUE(((tt) + 2) % 3, chunk, (tt) + 2);                  \
             else SP_AISSUE(((tt) + 2) % 3, chunk + 1, (tt) + 2 - NT);                       \
             if ((tt) < 4) SP_PISSUE((tt) % 3, tt);                                          \
             /* keep the requests HERE: the scheduler otherwise sinks each load to just above its MFMA two steps later */ \
             __builtin_amdgcn_sched_barrier(0);                                              \
-            SP_COMPUTE((tt) % 3, tt);                                                       \
+            if constexpr (AG >= 3) {                                                        \
+                if ((tt) == 0) SP_BLOAD(0, 0);                                              \
+                if ((tt) + 1 < NT) SP_BLOAD(((tt) + 1) & 1, (tt) + 1);                      \
+                SP_MFMA_REG((tt) % 3, (tt) & 1);                                            \
+            } else {                                                                        \
+                if constexpr (AG == 2) __builtin_amdgcn_s_setprio(1);                       \
+                SP_COMPUTE((tt) % 3, tt);                                                   \
+                if constexpr (AG == 2) __builtin_amdgcn_s_setprio(0);                       \
+            }                                                                               \
             if ((tt) >= 2 && (tt) < 6) SP_PRETIRE(((tt) + 1) % 3, (tt) - 2);                \
         } else {                                                                            \
             __syncthreads();                                                                \
@@ -966,7 +1005,7 @@ void gconv_sp9_kernel(const GcParams p) {
         }                                                                                   \
     } while (0)
 
-    if constexpr (AG) {
+    if constexpr (AG != 0) {
         SP_AISSUE(0, 0, 0);
         SP_AISSUE(1, 0, 1);
     } else {
@@ -986,6 +1025,8 @@ void gconv_sp9_kernel(const GcParams p) {
 #undef SP_PRETIRE
 #undef SP_PISSUE
 #undef SP_WRETIRE
+#undef SP_MFMA_REG
+#undef SP_BLOAD
 #undef SP_AISSUE
 #undef SP_WISSUE
 
@@ -2622,13 +2663,15 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                     // no weight ring; the K-split exchange (64 KB) is the larger LDS use for the usual 180-pixel patch
                     size_t lds_ag = 64 + 2 * (((size_t)(npatch + 2) * PITCH + 15) & ~(size_t)15);
                     if (lds_ag < 65536) lds_ag = 65536;
-                    if (p.rfx) {
-                        gc_set_max_lds((const void*)gconv_sp9_kernel<2, 2, true, 0, false, true>, (int)lds_ag);
-                        hipLaunchKernelGGL((gconv_sp9_kernel<2, 2, true, 0, false, true>), grid, dim3(512), lds_ag, st, p);
-                    } else {
-                        gc_set_max_lds((const void*)gconv_sp9_kernel<2, 2, false, 0, false, true>, (int)lds_ag);
-                        hipLaunchKernelGGL((gconv_sp9_kernel<2, 2, false, 0, false, true>), grid, dim3(512), lds_ag, st, p);
-                    }
+                    const int agl = env_int("HIFIC_SP9_AG", 1);
+#define SP9_AG_LAUNCH(RFX_, L_)                                                                                         \
+    do {                                                                                                                \
+        gc_set_max_lds((const void*)gconv_sp9_kernel<2, 2, RFX_, 0, false, L_>, (int)lds_ag);                           \
+        hipLaunchKernelGGL((gconv_sp9_kernel<2, 2, RFX_, 0, false, L_>), grid, dim3(512), lds_ag, st, p);               \
+    } while (0)
+                    if (p.rfx) { if (agl >= 3) SP9_AG_LAUNCH(true, 3); else if (agl == 2) SP9_AG_LAUNCH(true, 2); else SP9_AG_LAUNCH(true, 1); }
+                    else { if (agl >= 3) SP9_AG_LAUNCH(false, 3); else if (agl == 2) SP9_AG_LAUNCH(false, 2); else SP9_AG_LAUNCH(false, 1); }
+#undef SP9_AG_LAUNCH
                 }
                 else if (phs == 1) SP9_LAUNCH(1, 1, false, 1);
                 else if (phs == 2) SP9_LAUNCH(1, 1, false, 2);
