@@ -604,6 +604,9 @@ def main():
                            sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "gemm_class_ms_per_step": round(sum(v["ms_per_step"] for v in prof.values()), 3),
         }
+        if os.environ.get("HIFIC_BENCH_ROOFLINE_ONLY") == "1":      # kernel experiments: headline + per-kernel table, nothing else
+            print(json.dumps(out), flush=True)
+            return
         # ---- the same cycle as ONE hipGraph replay (hific_amd.graph.GraphedStep; bit-identical: tests/test_gpu_zz_graph.py)
         if not is_graph and os.environ.get("HIFIC_BENCH_NO_GRAPH_LEG") != "1":
             gstep, ok = graphed(args, step, world, force=True)

@@ -45,6 +45,12 @@ struct GcParams {
     int epi_wide;        // wide-store epilogue through LDS (gc_epilogue_wide): legality checked by the plan
     int wstage;          // wide-load staging (stage_W): bf16 NCHW input, IW % 8 == 0, 16-byte aligned (set by the plan)
     int rfx;             // gather-form reflect data gradient (gconv_sp9_kernel RFX): `in` is the extended gradient
+    // split-K of the forward-type kernels (small-grid layers: the hyperprior's 4x4..16x16 planes give 40-320 workgroups of
+    // 50-400 serial steps): blockIdx.y takes `kchunks` channel chunks and writes raw float32 partial sums to
+    // kpart[blockIdx.y][N,K,OHf,OWf]; ksplit_reduce_kernel adds them, the bias and the activation
+    int ksplit, kchunks;
+    float* kpart;
+    long long kpart_stride;
     int afrag;           // packed weights in MFMA A-fragment order (gc_wp_index): gconv_sp9_kernel AG streams them
                          // global -> registers, bypassing LDS
     // reflect-padded data gradient: `out` is the f32 padded plane buffer (only its rim is written); pixels inside

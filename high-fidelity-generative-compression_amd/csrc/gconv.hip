@@ -292,6 +292,15 @@ __device__ __forceinline__ void gc_store_block(const GcParams& p, const GcPhase&
     if (!okp) return;
     size_t plane = (size_t)p.OHf * p.OWf;
     size_t pbase = (size_t)pn_ * p.K * plane + (size_t)oy * p.OWf + ox;
+    if (p.ksplit > 1) {       // split-K partial sums: raw accumulators, float32, this split's plane set (see GcParams)
+        float* part = p.kpart + (size_t)blockIdx.y * (size_t)p.kpart_stride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m < p.K) part[pbase + (size_t)m * plane] = a[r];
+        }
+        return;
+    }
     void* optr = p.out;
     bool of32 = out_f32;
     if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
@@ -527,7 +536,14 @@ void gconv_kernel(const GcParams p) {
     const int nt = ph.ntaps;
     const int ng = (nt + TPS - 1) / TPS;               // tap groups (steps) per channel chunk
     const int nchunks = p.Cpad / BC;
-    const int nsteps = nchunks * ng;
+    // split-K: this workgroup reduces over chunks [chunk_lo, chunk_hi); steps are numbered from 0 inside that range
+    int chunk_lo = 0, chunk_hi = nchunks;
+    if (p.ksplit > 1) {
+        chunk_lo = (int)blockIdx.y * p.kchunks;
+        chunk_hi = chunk_lo + p.kchunks < nchunks ? chunk_lo + p.kchunks : nchunks;
+    }
+    const int s_lo = chunk_lo * ng;
+    const int nsteps = (chunk_hi - chunk_lo) * ng;
     const unsigned char* wp_ph = (const unsigned char*)p.wp + (size_t)ph.wp_off * sizeof(T);
     const size_t wrow_bytes = (size_t)nt * p.Cpad * sizeof(T);   // one m-row of this phase
 
@@ -552,6 +568,7 @@ void gconv_kernel(const GcParams p) {
     // byte offset of tile j of step s = (tap (s % ng) * TPS + j, chunk s / ng); clamped to the last step / last tap
     auto tile_off = [&](int s_, int j_) -> size_t {
         if (s_ >= nsteps) s_ = nsteps - 1;
+        s_ += s_lo;
         const int c_ = s_ / ng;
         int t_ = (s_ - c_ * ng) * TPS + j_;
         if (t_ >= nt) t_ = nt - 1;
@@ -637,7 +654,7 @@ void gconv_kernel(const GcParams p) {
         GC_WLOAD(wA, 0);
         GC_WLOAD(wB, 1);
         GC_WSTORE(wA, wbuf);
-        int chunk = 0, g = 0, s = 0;
+        int chunk = chunk_lo, g = 0, s = 0;
         for (; s + 1 < nsteps; s += 2) {
             GC_STEP(s, wA, wB);
             GC_STEP(s + 1, wB, wA);
@@ -825,7 +842,13 @@ void gconv_sp9_kernel(const GcParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[f][mi][ni][r] = 0.f;
 
-    const int nchunks = p.Cpad / BC;
+    const int nchunks_all = p.Cpad / BC;
+    int chunk_lo = 0, chunk_hi = nchunks_all;          // split-K (GcParams::ksplit): this workgroup's channel chunks
+    if (p.ksplit > 1) {
+        chunk_lo = (int)blockIdx.y * p.kchunks;
+        chunk_hi = chunk_lo + p.kchunks < nchunks_all ? chunk_lo + p.kchunks : nchunks_all;
+    }
+    const int nchunks = chunk_hi;                       // bound used by the prefetch clamps below
     const unsigned plane = (unsigned)(p.IH * p.IW);
     const bf16_t* inb = (const bf16_t*)p.in;
 
@@ -850,7 +873,7 @@ void gconv_sp9_kernel(const GcParams p) {
     const unsigned char* abase[WM];
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi)
-        abase[mi] = (const unsigned char*)p.wp + ((size_t)((m0 >> 5) + wm * WM + mi) * NT * nchunks) * 4096 + lane * 16;
+        abase[mi] = (const unsigned char*)p.wp + ((size_t)((m0 >> 5) + wm * WM + mi) * NT * nchunks_all) * 4096 + lane * 16;
     u32x4_t aS[3][WM][BC / KS / KSP];
     u32x4_t bS[2][WN][BC / KS / KSP];                           // AG >= 3: B fragments of the current / next tap
     constexpr int PD = 2 / KSP;                                 // patch dword columns issued per step (steps 0..3)
@@ -862,7 +885,7 @@ void gconv_sp9_kernel(const GcParams p) {
     // prologue: patch of chunk 0 staged synchronously (by the first four waves: stage_T's thread map is 4 waves wide),
     // weight tiles 0..2 requested, tile 0 in ring slot 0
     if (KSP == 1 || tid < 256)
-        stage_T<T, 32, PITCH>(pbuf, p.in, 0, p.N, p.C, p.IH, p.IW, p.bmode, n0, p.NI, iy0, ix0, 0, PH, PW, 0, tid, 256);
+        stage_T<T, 32, PITCH>(pbuf, p.in, 0, p.N, p.C, p.IH, p.IW, p.bmode, n0, p.NI, iy0, ix0, 0, PH, PW, chunk_lo * BC, tid, 256);
 
     // weight tile (chunk cc, tap tt); tiles past the end re-read the last chunk (never consumed)
 #define SP_WISSUE(SET, cc, tt)                                                                     \
@@ -872,7 +895,7 @@ void gconv_sp9_kernel(const GcParams p) {
              wS[SET][i] = *(const u32x4_t*)(wsrc[sp9_phase(PHS, tt)][i] + off_); } while (0)
 #define SP_AISSUE(SET, cc, tt)                                                                     \
     do { const int c_ = (cc) < nchunks ? (cc) : nchunks - 1;                                       \
-         const size_t off_ = (((size_t)(tt) * nchunks + c_) * 4 + kgrp_k0) * 1024;                 \
+         const size_t off_ = (((size_t)(tt) * nchunks_all + c_) * 4 + kgrp_k0) * 1024;             \
          _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                         \
              _Pragma("unroll") for (int kq = 0; kq < BC / KS / KSP; ++kq)                          \
                  aS[SET][mi][kq] = *(const u32x4_t*)(abase[mi] + off_ + kq * 1024); } while (0)
@@ -986,7 +1009,7 @@ void gconv_sp9_kernel(const GcParams p) {
             __builtin_amdgcn_sched_barrier(0);                                              \
             if constexpr (AG >= 3) {                                                        \
                 if ((tt) == 0) SP_BLOAD(0, 0);                                              \
-                if ((tt) + 1 < NT) SP_BLOAD(((tt) + 1) & 1, (tt) + 1);                      \
+                if ((tt) + 1 < NT) SP_BLOAD(((tt) + 1) & 1, ((tt) + 1 < NT ? (tt) + 1 : 0));  \
                 SP_MFMA_REG((tt) % 3, (tt) & 1);                                            \
             } else {                                                                        \
                 if constexpr (AG == 2) __builtin_amdgcn_s_setprio(1);                       \
@@ -1006,17 +1029,17 @@ void gconv_sp9_kernel(const GcParams p) {
     } while (0)
 
     if constexpr (AG != 0) {
-        SP_AISSUE(0, 0, 0);
-        SP_AISSUE(1, 0, 1);
+        SP_AISSUE(0, chunk_lo, 0);
+        SP_AISSUE(1, chunk_lo, 1);
     } else {
-        SP_WISSUE(0, 0, 0);
+        SP_WISSUE(0, chunk_lo, 0);
         SP_WRETIRE(0, 0);
-        SP_WISSUE(1, 0, 1);
-        SP_WISSUE(2, 0, 2);
+        SP_WISSUE(1, chunk_lo, 1);
+        SP_WISSUE(2, chunk_lo, 2);
     }
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const unsigned char* pcur = pbuf + (chunk & 1) * patch_bytes;
-        unsigned char* pnext = pbuf + ((chunk + 1) & 1) * patch_bytes;
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+        const unsigned char* pcur = pbuf + ((chunk - chunk_lo) & 1) * patch_bytes;
+        unsigned char* pnext = pbuf + ((chunk - chunk_lo + 1) & 1) * patch_bytes;
         const int c0n = (chunk + 1 < nchunks ? chunk + 1 : chunk) * BC;     // last chunk: harmless re-load
         SP_STEP(0); SP_STEP(1); SP_STEP(2); SP_STEP(3); SP_STEP(4); SP_STEP(5); SP_STEP(6); SP_STEP(7); SP_STEP(8);
     }
@@ -2269,6 +2292,22 @@ extern "C" int hific_pack_batch(const void* jobs_dev, const int* prefix_dev, int
 // ===================================================================================================
 // Host-side planning
 // ===================================================================================================
+// Split-K epilogue of the forward-type kernels: out = act(sum_s part[s] + bias[k]) over [N, K, plane]
+template <typename TO>
+__global__ void ksplit_reduce_kernel(const float* __restrict__ part, long long stride, int nsplit, long long total, int K,
+                                     int plane, const float* __restrict__ bias, int act, TO* __restrict__ out) {
+    const float slope = act == ACT_RELU ? 0.f : (act == ACT_LEAKY ? 0.2f : 1.f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float v[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = part[(s < nsplit ? s : 0) * stride + i];     // independent loads in flight
+        float acc = bias ? bias[(int)((i / plane) % K)] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc += s < nsplit ? v[s] : 0.f;
+        DT<TO>::st(out + i, acc > 0.f ? acc : acc * slope);
+    }
+}
+
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s ? atoi(s) : dflt; }
 
 static const int kLdsBudget = 150 * 1024;
@@ -2509,6 +2548,26 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             if (need > lds) lds = need;
         }
     }
+    // Split-K for launches that cannot fill the chip (see GcParams::ksplit): enough splits for ~2.5 workgroups per CU, at
+    // least two channel chunks per split.  Partial sums and the reduce pass cost ~2 x 4 bytes per output element per split,
+    // nothing next to the 50-400 serial steps of one of these workgroups.
+    p.ksplit = 1; p.kchunks = 0; p.kpart = nullptr; p.kpart_stride = 0;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        const long long g0 = (long long)max_tiles * (p.Kpad / bm) * (phs ? 1 : p.nphase);
+        const int nch = p.Cpad / BC;
+        if (g0 < env_int("HIFIC_KSPLIT_MAXGRID", 384) && nch >= 4 && !p.fold_h && !p.resid && !p.msplit && !p.csplit &&
+            env_int("HIFIC_KSPLIT", 1)) {
+            int ks = (int)cdivl(env_int("HIFIC_KSPLIT_TARGET", 640), g0);
+            if (ks > nch / 2) ks = nch / 2;
+            if (ks > 16) ks = 16;
+            if (ks >= 2) {
+                p.kchunks = cdiv(nch, ks);
+                p.ksplit = cdiv(nch, p.kchunks);
+                p.kpart_stride = (long long)p.N * p.K * p.OHf * p.OWf;
+                p.epi_wide = 0;
+            }
+        }
+    }
     // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, bf16 input, halo patch <= 192 pixels
     bool use_sp9 = false;
     if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
@@ -2602,14 +2661,18 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         }
     }
     p.max_tiles = max_tiles;
-    dim3 grid(max_tiles * (p.Kpad / bm), 1, phs ? 1 : p.nphase);
+    if (p.ksplit > 1) {
+        p.kpart = (float*)ws.take((size_t)p.ksplit * (size_t)p.kpart_stride * sizeof(float));
+        if (!p.kpart) { p.ksplit = 1; p.kchunks = 0; }          // no room: one pass (epi_wide stays off: harmless)
+    }
+    dim3 grid(max_tiles * (p.Kpad / bm), p.ksplit, phs ? 1 : p.nphase);
     // algorithmic FLOPs of the op (set by the caller on the op's REAL output domain: a reflect-padded data gradient
     // computes on the padded plane, which is extra work, not extra useful FLOPs)
     const double aflops = p.aflops;
     char ptag[112];
     snprintf(ptag, sizeof(ptag), "gconv K%d C%d N%d in%dx%d out%dx%d ph%d taps%d ist%d ost%d tile%dx%dx%d bm%d tps%d grid%d",
              p.K, p.C, p.N, p.IH, p.IW, p.OHf, p.OWf, p.nphase, maxtaps, p.ist, p.ost, p.NI, p.TH, p.TW, bm, tps,
-             max_tiles * (p.Kpad / bm) * p.nphase);
+             max_tiles * (p.Kpad / bm) * p.nphase * p.ksplit);
     char kname[PROF_NAMELEN];
     if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d%s>", bm / 64,
                           phs ? 1 : p.rfx ? (bm == 128 ? 2 : 1)
@@ -2692,6 +2755,16 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     else if (bm == 64) GC_LAUNCH(2, 2, 1, 2);
     else GC_LAUNCH(1, 4, 1, 1);
 #undef GC_LAUNCH
+    if (p.ksplit > 1) {
+        const long long total = p.kpart_stride;
+        int gx = (int)cdivl(total, 256); if (gx > 8192) gx = 8192;
+        if (p.out_f32)
+            hipLaunchKernelGGL(ksplit_reduce_kernel<float>, dim3(gx), dim3(256), 0, st, p.kpart, p.kpart_stride, p.ksplit, total,
+                               p.K, p.OHf * p.OWf, p.bias, p.act, (float*)p.out);
+        else
+            hipLaunchKernelGGL(ksplit_reduce_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, p.kpart, p.kpart_stride, p.ksplit, total,
+                               p.K, p.OHf * p.OWf, p.bias, p.act, (bf16_t*)p.out);
+    }
     prof_close(pslot, st);
     return hific_launch_status();
 }
