@@ -292,17 +292,12 @@ __device__ __forceinline__ void gc_store_block(const GcParams& p, const GcPhase&
     if (!okp) return;
     size_t plane = (size_t)p.OHf * p.OWf;
     size_t pbase = (size_t)pn_ * p.K * plane + (size_t)oy * p.OWf + ox;
-    if (p.ksplit > 1) {       // split-K partial sums: raw accumulators, float32, this split's plane set (see GcParams)
-        float* part = p.kpart + (size_t)blockIdx.y * (size_t)p.kpart_stride;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m < p.K) part[pbase + (size_t)m * plane] = a[r];
-        }
-        return;
-    }
-    void* optr = p.out;
-    bool of32 = out_f32;
+    // split-K partial sums (GcParams::ksplit): the same store path with the destination redirected to this split's float32
+    // plane set; the caller passes no bias and slope 1.  (A separate store loop here spilled the accumulators of the
+    // 128-row sp9 instantiations to scratch: 320 B/lane, 12x slower.)
+    const bool part = p.ksplit > 1;
+    void* optr = part ? (void*)(p.kpart + (size_t)blockIdx.y * (size_t)p.kpart_stride) : p.out;
+    bool of32 = out_f32 || part;
     if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
         const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
         if ((unsigned)iy < (unsigned)p.fold_h && (unsigned)ix < (unsigned)p.fold_w) {
@@ -344,9 +339,9 @@ __device__ __forceinline__ void gc_epilogue(const GcParams& p, const GcPhase& ph
                                             const f32x16_t a10, const f32x16_t a11, int mbase, int lhi,
                                             const int (&pu)[WN], const int (&pv)[WN], const int (&pn)[WN],
                                             const bool (&pvalid)[WN]) {
-    const bool hb = p.bias != nullptr;
+    const bool hb = p.bias != nullptr && p.ksplit <= 1;          // split-K partials: bias and activation in the reduce pass
     const float* bp = hb ? p.bias : (const float*)p.in;          // always a readable address; masked in the block
-    const float slope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LEAKY ? 0.2f : 1.f);
+    const float slope = p.ksplit > 1 ? 1.f : (p.act == ACT_RELU ? 0.f : (p.act == ACT_LEAKY ? 0.2f : 1.f));
     if constexpr (NI_ONLY < 0 || NI_ONLY == 0) {
         gc_store_block<TF32>(p, ph, a00, 0, mbase, lhi, pu[0], pv[0], pn[0], pvalid[0], hb, bp, slope);
         if constexpr (WM == 2) gc_store_block<TF32>(p, ph, a10, 1, mbase, lhi, pu[0], pv[0], pn[0], pvalid[0], hb, bp, slope);
