@@ -2543,26 +2543,6 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             if (need > lds) lds = need;
         }
     }
-    // Split-K for launches that cannot fill the chip (see GcParams::ksplit): enough splits for ~2.5 workgroups per CU, at
-    // least two channel chunks per split.  Partial sums and the reduce pass cost ~2 x 4 bytes per output element per split,
-    // nothing next to the 50-400 serial steps of one of these workgroups.
-    p.ksplit = 1; p.kchunks = 0; p.kpart = nullptr; p.kpart_stride = 0;
-    if constexpr (std::is_same<T, bf16_t>::value) {
-        const long long g0 = (long long)max_tiles * (p.Kpad / bm) * (phs ? 1 : p.nphase);
-        const int nch = p.Cpad / BC;
-        if (g0 < env_int("HIFIC_KSPLIT_MAXGRID", 384) && nch >= 4 && !p.fold_h && !p.resid && !p.msplit && !p.csplit &&
-            env_int("HIFIC_KSPLIT", 1)) {
-            int ks = (int)cdivl(env_int("HIFIC_KSPLIT_TARGET", 640), g0);
-            if (ks > nch / 2) ks = nch / 2;
-            if (ks > 16) ks = 16;
-            if (ks >= 2) {
-                p.kchunks = cdiv(nch, ks);
-                p.ksplit = cdiv(nch, p.kchunks);
-                p.kpart_stride = (long long)p.N * p.K * p.OHf * p.OWf;
-                p.epi_wide = 0;
-            }
-        }
-    }
     // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, bf16 input, halo patch <= 192 pixels
     bool use_sp9 = false;
     if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
@@ -2600,6 +2580,28 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         if (use_sp9 && !phs && bm == 128 && env_int("HIFIC_SP9_KSPLIT", 2) == 2 && !env_int("HIFIC_SP9_DS", 0) &&
             env_int("HIFIC_SP9_AG", 1))
             p.afrag = 1;
+    }
+    // Split-K for launches that cannot fill the chip (see GcParams::ksplit): only where one workgroup's serial chain is
+    // long enough to pay for the float32 partials and the reduce pass (~10-15 us).  Measured (round 3, batch 16): 320<-960
+    // 5x5 s2 @8x8 (80 workgroups x 105 steps) 201 -> 59 us, its transposed sibling 162 -> 49, 220<-2880 3x3 @16x16 (64
+    // workgroups x 405 steps) 178 -> 108; launches of 128-256 workgroups or < ~60 us of chain got 10-40 % SLOWER.
+    p.ksplit = 1; p.kchunks = 0; p.kpart = nullptr; p.kpart_stride = 0;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        const long long g0 = (long long)max_tiles * (p.Kpad / bm) * (phs ? 1 : p.nphase);
+        const int nch = p.Cpad / BC;
+        const double chain_us = (double)nch * (use_sp9 ? 9 * 0.5 : cdiv(maxtaps, tps) * 1.5);
+        if (g0 <= env_int("HIFIC_KSPLIT_MAXGRID", 160) && nch >= 4 && chain_us >= env_int("HIFIC_KSPLIT_MIN_US", 60) &&
+            !p.fold_h && !p.resid && !p.msplit && !p.csplit && env_int("HIFIC_KSPLIT", 1)) {
+            int ks = (int)cdivl(env_int("HIFIC_KSPLIT_TARGET", 640), g0);
+            if (ks > nch / 2) ks = nch / 2;
+            if (ks > 16) ks = 16;
+            if (ks >= 2) {
+                p.kchunks = cdiv(nch, ks);
+                p.ksplit = cdiv(nch, p.kchunks);
+                p.kpart_stride = (long long)p.N * p.K * p.OHf * p.OWf;
+                p.epi_wide = 0;
+            }
+        }
     }
     const size_t wp_bytes = (size_t)(wp_elems > 0 ? wp_elems : 1) * sizeof(T);
     // pack tiling (coalesced LDS-transposing kernel when the taps of a (m,c) pair are contiguous and one of m/c is adjacent)
