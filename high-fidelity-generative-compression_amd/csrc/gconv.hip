@@ -2590,7 +2590,9 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         const long long g0 = (long long)max_tiles * (p.Kpad / bm) * (phs ? 1 : p.nphase);
         const int nch = p.Cpad / BC;
         const double chain_us = (double)nch * (use_sp9 ? 9 * 0.5 : cdiv(maxtaps, tps) * 1.5);
-        if (g0 <= env_int("HIFIC_KSPLIT_MAXGRID", 160) && nch >= 4 && chain_us >= env_int("HIFIC_KSPLIT_MIN_US", 60) &&
+        // (the generic kernel's step is a barrier + synchronous staging, ~1.5-2 us; the software-pipelined one ~0.5 us)
+        if (g0 <= env_int("HIFIC_KSPLIT_MAXGRID", 160) && nch >= 4 &&
+            chain_us >= (use_sp9 ? env_int("HIFIC_KSPLIT_MIN_US_SP", 60) : env_int("HIFIC_KSPLIT_MIN_US", 20)) &&
             !p.fold_h && !p.resid && !p.msplit && !p.csplit && env_int("HIFIC_KSPLIT", 1)) {
             int ks = (int)cdivl(env_int("HIFIC_KSPLIT_TARGET", 640), g0);
             if (ks > nch / 2) ks = nch / 2;
