@@ -2591,10 +2591,14 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         const int nch = p.Cpad / BC;
         const double chain_us = (double)nch * (use_sp9 ? 9 * 0.5 : cdiv(maxtaps, tps) * 1.5);
         // (the generic kernel's step is a barrier + synchronous staging, ~1.5-2 us; the software-pipelined one ~0.5 us)
-        if (g0 <= env_int("HIFIC_KSPLIT_MAXGRID", 160) && nch >= 4 &&
+        // (up to 400 workgroups of 32-row tiles - several co-reside per CU: 320<-960 5x5 s2 @16x16, 320 workgroups, 232 -> 170 us;
+        //  256 workgroups of 128-row tiles are one per CU and lose 15-35 % when split)
+        const long long gmax = use_sp9 ? env_int("HIFIC_KSPLIT_MAXGRID_SP", 160)
+                                       : (bm <= 32 ? env_int("HIFIC_KSPLIT_MAXGRID_32", 400) : env_int("HIFIC_KSPLIT_MAXGRID", 160));
+        if (g0 <= gmax && nch >= 4 &&
             chain_us >= (use_sp9 ? env_int("HIFIC_KSPLIT_MIN_US_SP", 60) : env_int("HIFIC_KSPLIT_MIN_US", 20)) &&
             !p.fold_h && !p.resid && !p.msplit && !p.csplit && env_int("HIFIC_KSPLIT", 1)) {
-            int ks = (int)cdivl(env_int("HIFIC_KSPLIT_TARGET", 640), g0);
+            int ks = (int)cdivl(env_int("HIFIC_KSPLIT_TARGET", 800), g0);
             if (ks > nch / 2) ks = nch / 2;
             if (ks > 16) ks = 16;
             if (ks >= 2) {
