@@ -2,20 +2,23 @@
 # Build libhific_hip.so for gfx950 (cross-compiles without a GPU).  Output lands next to the package.
 set -e
 cd "$(dirname "$0")"
-OUT=../libhific_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
+# A/B builds: EXTRA="-DGC_TOFF_EARLY=0" OUT=../libhific_hip_ab.so OBJDIR=/tmp/ab bash build.sh ; run with HIFIC_LIB_PATH=<that .so>
+OUT=${OUT:-../libhific_hip.so}
+OBJDIR=${OBJDIR:-.}
+mkdir -p $OBJDIR
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value $EXTRA"
 SRCS="gconv elementwise norm entropy lpips augment capi"
 OBJS=""
 PIDS=""
 NAMES=""
 for f in $SRCS; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ gconv.h -nt $f.o ]; then
-    rm -f $f.o                                    # a failed compile must never leave a stale object to link
-    hipcc $FLAGS -c $f.hip -o $f.o &
+  if [ ! -f $OBJDIR/$f.o ] || [ $f.hip -nt $OBJDIR/$f.o ] || [ common.h -nt $OBJDIR/$f.o ] || [ gconv.h -nt $OBJDIR/$f.o ]; then
+    rm -f $OBJDIR/$f.o                            # a failed compile must never leave a stale object to link
+    hipcc $FLAGS -c $f.hip -o $OBJDIR/$f.o &
     PIDS="$PIDS $!"
     NAMES="$NAMES $f"
   fi
-  OBJS="$OBJS $f.o"
+  OBJS="$OBJS $OBJDIR/$f.o"
 done
 # a bare `wait` always returns 0: collect every compile's status
 i=0

@@ -14,6 +14,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+// build-time A/B switches (csrc/build.sh EXTRA=-D...; lib.py loads $HIFIC_LIB_PATH when set)
+#ifndef GC_TOFF_EARLY
+#define GC_TOFF_EARLY 1     // gconv_kernel: tap offsets of a step are read from LDS before the step's barriers
+#endif
+#ifndef SP9_TOFF_ARG
+#define SP9_TOFF_ARG 1      // gconv_sp9_kernel: tap offsets from the kernel arguments instead of the LDS table
+#endif
+
 // Dynamic-LDS opt-in per kernel function, raised monotonically (never lowered): a launch recorded in a hipGraph is
 // replayed later, when another layer's launch of the same function may have asked for less; and the attribute call
 // leaves the per-launch host path once a function has reached its maximum.
@@ -502,6 +510,7 @@ void gconv_kernel(const GcParams p) {
     unsigned char* patch = wbuf + 2 * TPS * WBYTES;   // npatch x PITCH
     if (tid < ph.ntaps)
         toffs[tid] = ((int)p.tap_dy[ph.tap0 + tid] - ph.dy_min) * PWs + ((int)p.tap_dx[ph.tap0 + tid] - ph.dx_min);
+    if (GC_TOFF_EARLY) __syncthreads();               // GC_STEP reads the table before its own barriers
 
     // per-lane pixel decode for the B (pixel) operand and the epilogue
     int qb[WN], pu[WN], pv[WN], pn[WN];
@@ -589,9 +598,9 @@ void gconv_kernel(const GcParams p) {
         }                                                                                   \
     } while (0)
     // one GEMM step on the tile in `wb` with tap `t`
-#define GC_COMPUTE(wb, t)                                                                                       \
+#define GC_COMPUTE(wb, t, TOFFV)                                                                                \
     do {                                                                                                        \
-        const int toff = toffs[t];                                                                              \
+        const int toff = GC_TOFF_EARLY ? (TOFFV) : toffs[t];                                                    \
         const unsigned char* arow = (wb) + (wm * WM * 32 + l31) * PITCH;                                        \
         _Pragma("unroll") for (int kk = 0; kk < BC / KS; ++kk) {                                                \
             if constexpr (std::is_same<T, float>::value) {                                                      \
@@ -623,6 +632,15 @@ void gconv_kernel(const GcParams p) {
     // step s: RL = register set that receives the tiles of step s+2, RS = register set holding those of step s+1
 #define GC_STEP(s, RL, RS)                                                                  \
     do {                                                                                    \
+        /* this step's tap offsets: requested before the barriers / weight loads instead of in front of each tap's   \
+           fragment reads (one exposed LDS round trip per tap otherwise; the table never changes) */                \
+        int toffv[TPS];                                                                     \
+        if (GC_TOFF_EARLY) {                                                                \
+            _Pragma("unroll") for (int j = 0; j < TPS; ++j) {                               \
+                const int t_ = g * TPS + j;                                                 \
+                toffv[j] = toffs[t_ < nt ? t_ : nt - 1];                                    \
+            }                                                                               \
+        }                                                                                   \
         if (g == 0 && !((p.dbg & 1) && chunk > 0) && !(p.dbg & 64)) {                       \
             __syncthreads();                                                                \
             if constexpr (WIDE)                                                             \
@@ -637,7 +655,7 @@ void gconv_kernel(const GcParams p) {
         if (!(p.dbg & 2)) {                                                                 \
             _Pragma("unroll") for (int j = 0; j < TPS; ++j) {                               \
                 const int t = g * TPS + j;                                                  \
-                if (TPS == 1 || t < nt) GC_COMPUTE(wbuf + (((s) & 1) * TPS + j) * WBYTES, t); \
+                if (TPS == 1 || t < nt) GC_COMPUTE(wbuf + (((s) & 1) * TPS + j) * WBYTES, t, toffv[j]); \
             }                                                                               \
         }                                                                                   \
         if (!(p.dbg & 4)) GC_WSTORE(RS, wbuf + (((s) + 1) & 1) * TPS * WBYTES);             \
@@ -724,7 +742,8 @@ __host__ __device__ constexpr int sp9_tap_in_phase(int phs, int t) {
 // patch double buffer as the only shared state: ONE barrier per 64-channel chunk instead of one per tap.
 // AG levels (HIFIC_SP9_AG): 1 = as described; 2 = + s_setprio(1) around each step's MFMA cluster (the waves of a workgroup
 // are no longer in lockstep, so the CU scheduler has something to arbitrate); 3 = + the B fragments of the next tap are read
-// from LDS before the current tap's MFMAs are issued (register double buffer; taps of one chunk share the patch buffer).
+// from LDS before the current tap's MFMAs are issued (register double buffer; taps of one chunk share the patch buffer);
+// 4 = level 3 without the priority hints.
 template <int WM, int KSP, bool RFX, int PHS, bool DS = false, int AG = 0>
 __global__ __launch_bounds__(256 * KSP) __attribute__((amdgpu_waves_per_eu(PHS ? 1 : 2, PHS ? 1 : 2)))
 void gconv_sp9_kernel(const GcParams p) {
@@ -925,7 +944,9 @@ void gconv_sp9_kernel(const GcParams p) {
     } while (0)
 #define SP_COMPUTE(SLOT, tt)                                                                                    \
     do {                                                                                                        \
-        const unsigned toff = (unsigned)toffs[tt];                                                              \
+        const unsigned toff = SP9_TOFF_ARG                                                                      \
+            ? (unsigned)((((int)p.tap_dy[tt] - ph.dy_min) * PW + ((int)p.tap_dx[tt] - ph.dx_min)) * PITCH)      \
+            : (unsigned)toffs[tt];                                                                              \
         const unsigned char* ab = wbuf + (SLOT) * WBYTES + arow;                                                \
         unsigned bo[WN];                                                                                        \
         _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                                     \
@@ -981,14 +1002,14 @@ void gconv_sp9_kernel(const GcParams p) {
     } while (0)
 #define SP_MFMA_REG(SLOT, SETB)                                                                                 \
     do {                                                                                                        \
-        __builtin_amdgcn_s_setprio(1);                                                                          \
+        if constexpr (AG == 3) __builtin_amdgcn_s_setprio(1);                                                   \
         _Pragma("unroll") for (int kq = 0; kq < BC / KS / KSP; ++kq)                                            \
             _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                                   \
                 _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                               \
                     acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                   \
                         __builtin_bit_cast(bf16x8_t, aS[SLOT][mi][kq]), __builtin_bit_cast(bf16x8_t, bS[SETB][ni][kq]), \
                         acc[0][mi][ni], 0, 0, 0);                                                               \
-        __builtin_amdgcn_s_setprio(0);                                                                          \
+        if constexpr (AG == 3) __builtin_amdgcn_s_setprio(0);                                                   \
     } while (0)
     // AG: operands of step tt sit in register set tt%3 (requested two steps earlier); the patch double buffer is the only
     // shared state - next chunk's rows are written in steps 2..5 and first read after the barrier of the next chunk's step 0,
@@ -2735,8 +2756,8 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         gc_set_max_lds((const void*)gconv_sp9_kernel<2, 2, RFX_, 0, false, L_>, (int)lds_ag);                           \
         hipLaunchKernelGGL((gconv_sp9_kernel<2, 2, RFX_, 0, false, L_>), grid, dim3(512), lds_ag, st, p);               \
     } while (0)
-                    if (p.rfx) { if (agl >= 3) SP9_AG_LAUNCH(true, 3); else if (agl == 2) SP9_AG_LAUNCH(true, 2); else SP9_AG_LAUNCH(true, 1); }
-                    else { if (agl >= 3) SP9_AG_LAUNCH(false, 3); else if (agl == 2) SP9_AG_LAUNCH(false, 2); else SP9_AG_LAUNCH(false, 1); }
+                    if (p.rfx) { if (agl >= 4) SP9_AG_LAUNCH(true, 4); else if (agl == 3) SP9_AG_LAUNCH(true, 3); else if (agl == 2) SP9_AG_LAUNCH(true, 2); else SP9_AG_LAUNCH(true, 1); }
+                    else { if (agl >= 4) SP9_AG_LAUNCH(false, 4); else if (agl == 3) SP9_AG_LAUNCH(false, 3); else if (agl == 2) SP9_AG_LAUNCH(false, 2); else SP9_AG_LAUNCH(false, 1); }
 #undef SP9_AG_LAUNCH
                 }
                 else if (phs == 1) SP9_LAUNCH(1, 1, false, 1);

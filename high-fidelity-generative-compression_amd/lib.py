@@ -9,7 +9,7 @@ import os
 from ctypes import c_int, c_float, c_void_p, c_size_t, c_longlong, c_char_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhific_hip.so")
+LIB_PATH = os.environ.get("HIFIC_LIB_PATH") or os.path.join(_HERE, "libhific_hip.so")   # (override: A/B builds of the library)
 
 HIFIC_F32, HIFIC_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
