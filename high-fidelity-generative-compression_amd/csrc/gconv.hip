@@ -16,10 +16,11 @@
 
 // build-time A/B switches (csrc/build.sh EXTRA=-D...; lib.py loads $HIFIC_LIB_PATH when set)
 #ifndef GC_TOFF_EARLY
-#define GC_TOFF_EARLY 1     // gconv_kernel: tap offsets of a step are read from LDS before the step's barriers
+#define GC_TOFF_EARLY 0     // gconv_kernel: tap offsets of a step read from LDS before the step's barriers - measured
+                            // (round 3, A/B libraries in one run): 1-3 % SLOWER on every generic instantiation: off
 #endif
 #ifndef SP9_TOFF_ARG
-#define SP9_TOFF_ARG 1      // gconv_sp9_kernel: tap offsets from the kernel arguments instead of the LDS table
+#define SP9_TOFF_ARG 1      // gconv_sp9_kernel: tap offsets from the kernel arguments instead of the LDS table (-1..2 %)
 #endif
 
 // Dynamic-LDS opt-in per kernel function, raised monotonically (never lowered): a launch recorded in a hipGraph is
