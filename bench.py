@@ -434,6 +434,63 @@ def cpu_baseline(args):
                 "sample": sample + f" -- FAILED: {type(e).__name__}"}
 
 
+# ---- Model.compress / Model.decompress at ~1 megapixel -------------------------------------------
+def codec_leg(args, dev):
+    """EVALUATION path end to end: x -> Encoder -> hyperprior nets -> symbols (device, csrc/entropy.hip) -> rANS coder
+    (host C++, csrc/host_rans.cpp) and back through the Generator.  One 1024 x 1024 image (the reference quotes "2-3
+    seconds" for decoding ~megapixel images on a GPU *without* running the rANS coder, src/README.md:87).  Host time is the
+    time spent inside compression.rans.ans_compress / ans_decompress (wrapped here), device time the rest."""
+    import torch
+    import hific_amd
+    from hific_amd.compression import rans, codec
+    from hific_amd.default_config import make_args, hific_args, ModelTypes, ModelModes
+    S = 1024
+    hific_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    margs = make_args(hific_args, batch_size=1, image_dims=(3, S, S), latent_dims=(220, S // 16, S // 16))
+    torch.manual_seed(0)
+    model = hific_amd.Model(margs, model_type=ModelTypes.COMPRESSION_GAN, model_mode=ModelModes.EVALUATION,
+                            allow_random_lpips_backbone=True, build_tables=True).to(dev).eval()
+    x = torch.rand((1, 3, S, S), generator=torch.Generator(device=dev).manual_seed(11), device=dev)
+    host = {"t": 0.0}
+
+    def timed_fn(fn):
+        def wrap(*a, **k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            host["t"] += time.perf_counter() - t0
+            return r
+        return wrap
+    orig = (rans.ans_compress, rans.ans_decompress)
+    rans.ans_compress, rans.ans_decompress = timed_fn(orig[0]), timed_fn(orig[1])
+    codec.rans = rans
+    try:
+        res = {}
+        out = model.compress(x, silent=True)                      # warm-up (packs, tables on the device)
+        model.decompress(out)
+        n = 3
+        for name, fn in (("compress", lambda: model.compress(x, silent=True)), ("decompress", lambda: model.decompress(out))):
+            host["t"] = 0.0
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n):
+                r = fn()
+            torch.cuda.synchronize()
+            tot = (time.perf_counter() - t0) / n
+            res[f"{name}_ms"] = round(tot * 1e3, 2)
+            res[f"{name}_host_rans_ms"] = round(host["t"] / n * 1e3, 2)
+            res[f"{name}_device_ms"] = round((tot - host["t"] / n) * 1e3, 2)
+        nbytes = 4 * (len(out.hyperlatents_encoded) + len(out.latents_encoded))
+        res.update(workload=f"Model.compress / Model.decompress, one {S}x{S} RGB image ({S * S / 1e6:.2f} MP), {args.dtype} "
+                            f"device half, vectorised rANS on the host (random-init weights: the bitstream is incompressible "
+                            f"noise, {nbytes / 1e3:.0f} kB)",
+                   bpp=round(8.0 * nbytes / (S * S), 3),
+                   reference_note="the reference reports 2-3 s to decode a ~megapixel image on a GPU without the rANS coder "
+                                  "(src/README.md:87)")
+        return res
+    finally:
+        rans.ans_compress, rans.ans_decompress = orig
+
+
 # ---- parity of the benchmarked mode, measured in this process ---------------------------------------------------------
 def parity_leg(args, dev):
     """The benchmarked mode against the oracle (the checker, CPU float32) on the benchmark's own shape: same seeded
@@ -662,6 +719,13 @@ def main():
                                   f"reconstruction + q_bpp), no-grad, batch {args.batch}, {args.dtype}",
                       "ms_per_batch": round(per_img * args.batch, 3), "images_per_s": round(1e3 / per_img, 1),
                       "tflops": round(GFLOP_PER_IMAGE["forward"] * (args.size / 256.0) ** 2 / 1e3 / (per_img * 1e-3), 1)}
+        if args.dtype == "bf16" and hific_ops.exact_index_on():
+            hific_ops.set_exact_index(False)                     # for comparison: the plain bf16 chain (0.39 % index flips)
+            try:
+                ef2 = timed(fwd, max(args.steps, 10), 2, fence)
+            finally:
+                hific_ops.set_exact_index(True)
+            out["fwd"]["plain_bf16_chain_ms_per_image"] = round(ef2 / max(args.steps, 10) / args.batch * 1e3, 4)
         del ev
         hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
         torch.cuda.empty_cache()
@@ -698,6 +762,14 @@ def main():
                                    "megapixels_per_s": round(2 * n5 * 1.048576 / e5, 2),
                                    "whole_step_tflops": round(tflop_step / args.batch * 16 / (e5 / n5), 1)}
             del m5, o5, r5, s5
+            hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
+            torch.cuda.empty_cache()
+        # ---- the EVALUATION path around the hot path: compress / decompress of one megapixel image ---------------------
+        if default_shape and os.environ.get("HIFIC_BENCH_NO_CODEC") != "1":
+            try:
+                out["codec_1mp"] = codec_leg(args, dev)
+            except Exception as e:
+                out["codec_1mp"] = {"error": f"{type(e).__name__}: {e}"}
             hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
             torch.cuda.empty_cache()
         # ---- parity of the benchmarked mode vs the oracle, at the benchmarked shape ---------------------------------
