@@ -216,8 +216,9 @@ def profile_kernels(step, nsteps):
 
 # ---- HBM traffic of one kernel function: rocprofv3 --pmc child runs ---------------------------------------------
 def _rocpd_counter(dbdir, counter, kernel_substr):
+    """-> (average counter value per launch of the kernels matching `kernel_substr`, sum over ALL launches)."""
     import sqlite3
-    tot, n = 0.0, 0
+    tot, n, everything = 0.0, 0, 0.0
     for db in glob.glob(os.path.join(dbdir, "**", "*.db"), recursive=True):
         cur = sqlite3.connect(db).cursor()
         try:
@@ -226,9 +227,10 @@ def _rocpd_counter(dbdir, counter, kernel_substr):
         except Exception:
             continue
         for name, c, v in rows:
+            everything += v
             if kernel_substr in name:
                 tot += v; n += c
-    return (tot / n) if n else None
+    return ((tot / n) if n else None), everything
 
 
 def measure_traffic(args, kernel_name):
@@ -243,7 +245,7 @@ def measure_traffic(args, kernel_name):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="hific_pmc_", dir="/tmp")
         cmd = [rocprof, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-               "--traffic-child", "--steps", "1", "--warmup", "1", "--batch", str(args.batch), "--size", str(args.size),
+               "--traffic-child", "--steps", "3", "--warmup", "1", "--batch", str(args.batch), "--size", str(args.size),
                "--config", args.config, "--dtype", args.dtype]
         # counters are per dispatch: single-stream execution in the child, like the timing leg (profile_kernels)
         env = dict(os.environ, TMPDIR="/tmp", HIFIC_SIDE_WGRAD="0", HIFIC_BRANCH_STREAMS="0")
@@ -258,15 +260,26 @@ def measure_traffic(args, kernel_name):
                 os.killpg(p.pid, 9)
                 return None, f"{counter} pass timed out"
             # exact template instance when it is unambiguous in the trace, else the function family
-            v = _rocpd_counter(d, counter, kernel_name) or _rocpd_counter(d, counter, sub)
+            v, everything = _rocpd_counter(d, counter, kernel_name)
+            if v is None:
+                v, everything = _rocpd_counter(d, counter, sub)
         finally:
             shutil.rmtree(d, ignore_errors=True)
         if v is None:
             return None, f"{counter}: kernel not found in the counter database"
         vals[counter] = v
+        vals[counter + "_all"] = everything
     rd, wr = 2.0 * vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
+    # every kernel of the child's 4 cycles (1 warm-up + 3): whole-step HBM traffic against the SURVEY section 8(d) estimate
+    whole = (2.0 * vals["FETCH_SIZE_all"] + vals["WRITE_SIZE_all"]) * 1024 / 4.0
+    alg = (32 * 0.275 + 6.9) * 1e9 * (args.batch / 16.0) * (args.size / 256.0) ** 2 if args.config == "gan" else \
+        (16 * 0.216 + 6.9) * 1e9 * (args.batch / 16.0) * (args.size / 256.0) ** 2
     return {"bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "write_bytes": round(wr),
-            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KB x 1024, FETCH x 2 (gfx950)"}, None
+            "whole_step_hbm_gbytes": round(whole / 1e9, 2), "whole_step_algorithmic_gbytes": round(alg / 1e9, 2),
+            "whole_step_traffic_ratio": round(whole / alg, 2),
+            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KB x 1024, FETCH x 2 (gfx950); whole "
+                   "step = all kernels of 4 cycles / 4; algorithmic = activations 5 passes x 2 B + 38 B per parameter "
+                   "(SURVEY section 8d)"}, None
 
 
 # ---- CPU baseline -----------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """Per-kernel table for profiles/: time from a rocprofv3 kernel trace, HBM traffic and MFMA-busy from separate --pmc
 passes of the same command.
-usage: kernel_table.py <trace.db> <fetch.db> <write.db> <mfma.db> <steps> > table.md
+usage: kernel_table.py <trace.db> <fetch.db> <write.db> <mfma.db> <warm-up cycles to skip> > table.md
 
   HBM GB/s   = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / avg duration      (KB counters; FETCH_SIZE counts 64 B per
                128-B request of a wide stream on gfx950, MI355X_MICROARCH.md "HBM": doubled)
@@ -12,12 +12,25 @@ import sqlite3
 import sys
 
 
-def trace(db):
+def trace(db, skip_cycles=0, adam_per_cycle=3):
+    """-> ({kernel: (count, total us, avg us)}, number of cycles counted).  Steady state only: the first `skip_cycles`
+    training cycles (cache creation, pack-entry set-up) are dropped; a cycle ends with its `adam_per_cycle`-th Adam launch
+    (three optimizer groups per G+D cycle)."""
     cur = sqlite3.connect(db).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    return {n: (c, s / 1e3, a / 1e3) for n, c, s, a in cur.execute(
-        f"select {name}, count(*), sum(end-start), avg(end-start) from kernels group by {name}")}
+    rows = cur.execute(f"select {name}, start, end from kernels order by start").fetchall()
+    out, adam, cycles = {}, 0, 0
+    for n, st, en in rows:
+        cyc = adam // adam_per_cycle
+        if "adam" in n:
+            adam += 1
+        if cyc < skip_cycles:
+            continue
+        c, s = out.get(n, (0, 0.0))
+        out[n] = (c + 1, s + (en - st) / 1e3)
+    total_cycles = adam // adam_per_cycle
+    return {n: (c, s, s / c) for n, (c, s) in out.items()}, max(1, total_cycles - skip_cycles)
 
 
 def counters(db, names):
@@ -31,11 +44,12 @@ def counters(db, names):
 
 
 def main():
-    tr = trace(sys.argv[1])
+    skip = int(sys.argv[5]) if len(sys.argv) > 5 else 0          # warm-up cycles to drop from the trace
+    tr, steps = trace(sys.argv[1], skip_cycles=skip)
     f = counters(sys.argv[2], ("FETCH_SIZE",))
     w = counters(sys.argv[3], ("WRITE_SIZE",))
     m = counters(sys.argv[4], ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"))
-    steps = float(sys.argv[5])
+    steps = float(steps)
     total = sum(v[1] for v in tr.values())
     print("| kernel | launches/step | avg us | ms/step | % of step | HBM MB/launch (2xFETCH+WRITE) | HBM GB/s | MFMA busy % |")
     print("|---|---|---|---|---|---|---|---|")
@@ -51,7 +65,13 @@ def main():
         print(f"| `{short}` | {c / steps:.1f} | {avg_us:.1f} | {tot_us / steps / 1e3:.3f} | {100 * tot_us / total:.1f} | "
               f"{'-' if mb is None else f'{mb:.1f}'} | {'-' if gbps is None else f'{gbps:.0f}'} | "
               f"{'-' if pct is None else f'{pct:.1f}'} |")
-    print(f"\nkernel time per step: {total / steps / 1e3:.3f} ms over {steps:.0f} steps")
+    hbm = 0.0
+    for n, (c, tot_us, avg_us) in tr.items():
+        fs, wsz = f.get(n, {}).get("FETCH_SIZE"), w.get(n, {}).get("WRITE_SIZE")
+        if fs is not None and wsz is not None:
+            hbm += (2 * fs + wsz) * 1024 * c / steps
+    print(f"\nkernel time per step: {total / steps / 1e3:.3f} ms over {steps:.0f} steady-state steps ({skip} warm-up cycles dropped); "
+          f"HBM traffic per step (counter averages x launches): {hbm / 1e9:.2f} GB")
 
 
 if __name__ == "__main__":
