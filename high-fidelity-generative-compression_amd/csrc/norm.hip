@@ -5,6 +5,7 @@
 // 128 B (bf16) / 256 B (f32) coalesced run; the three channel passes after the first hit L2.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // Workgroup = 64 consecutive pixels x all C channels, NW waves: wave w owns channels w, w+NW, ...  Loads are issued
 // 8 at a time per thread (clamped index + select instead of branches) so that the three channel passes are
@@ -270,7 +271,10 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict
 
 // dx as in cn_bwd_dx_kernel; part[blk][0][c] = sum_px dy'*xhat, part[blk][1][c] = sum_px dy' over the PIT pixel groups
 // of workgroup blk (dy' = dy masked by the fused ReLU).
-template <typename T, int PXB, int NW, int CPT>
+// DB: also part[blk][2][c] = sum_px dx (as stored, i.e. rounded to T): the bias gradient of the convolution whose output
+// is this norm's input (every conv -> ChannelNorm pair of the Encoder / Generator), so that layer needs no separate
+// channel-sum pass over its 8 MB gradient tensor (two launches per layer, src/network/generator.py:28-42).
+template <typename T, int PXB, int NW, int CPT, bool DB>
 __global__ __launch_bounds__(NW * 64) void cn_bwd_reg_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -283,10 +287,12 @@ __global__ __launch_bounds__(NW * 64) void cn_bwd_reg_kernel(const T* __restrict
     int bx, n;
     cn_block_remap(bx, n, remap);
     float pg[CPT], pb[CPT], gm[CPT], bt[CPT];
+    float pd[DB ? CPT : 1];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int c = g + G * k; const int ci = c < C ? c : C - 1;
         pg[k] = 0.f; pb[k] = 0.f; gm[k] = gamma[ci]; bt[k] = beta[ci];      // loaded once, unconditionally
+        if constexpr (DB) pd[k] = 0.f;
     }
     for (int it = 0; it < pit; ++it) {
         const int hw0 = (bx * pit + it) * PXB + px;
@@ -329,24 +335,35 @@ __global__ __launch_bounds__(NW * 64) void cn_bwd_reg_kernel(const T* __restrict
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int c = g + G * k;
-            if (ok && c < C) DT<T>::st(dxb + ((unsigned)c * (unsigned)HW + (unsigned)hw), r * (gv[k] - S1) - xv[k] * S2);
+            const float dxv = r * (gv[k] - S1) - xv[k] * S2;
+            if (ok && c < C) {
+                DT<T>::st(dxb + ((unsigned)c * (unsigned)HW + (unsigned)hw), dxv);
+                if constexpr (DB) pd[k] += std::is_same<T, float>::value ? dxv : bf2f(f2bf(dxv));   // what the tensor holds
+            }
         }
     }
+    constexpr int NR = DB ? 3 : 2;
     const size_t blk = (size_t)n * gridDim.x + bx;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const float a = cn_sum_px<PXB>(pg[k]), b = cn_sum_px<PXB>(pb[k]);
         const int c = g + G * k;
-        if (px == 0 && c < C) { part[(blk * 2 + 0) * C + c] = a; part[(blk * 2 + 1) * C + c] = b; }
+        if (px == 0 && c < C) { part[(blk * NR + 0) * C + c] = a; part[(blk * NR + 1) * C + c] = b; }
+        if constexpr (DB) {
+            const float d = cn_sum_px<PXB>(pd[k]);
+            if (px == 0 && c < C) part[(blk * NR + 2) * C + c] = d;
+        }
     }
 }
 
 // dgamma/dbeta (=|+=) column sums of part[nblk][2][C]: 64 columns x 16 row lanes per workgroup, coalesced rows
+// (nr = 3: third row block = the producing convolution's bias gradient -> dprev, with its own accumulate flag)
 __global__ __launch_bounds__(1024) void cn_param_colsum_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, int C, int nblk, int accumulate) {
+                                                               float* __restrict__ dbeta, int C, int nblk, int accumulate,
+                                                               int nr, float* __restrict__ dprev, int accumulate_prev) {
     __shared__ float red[16][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    const int W2 = 2 * C;
+    const int W2 = nr * C;
     float s = 0.f;
     if (col < W2) {
         int r = rl;
@@ -364,8 +381,8 @@ __global__ __launch_bounds__(1024) void cn_param_colsum_kernel(const float* __re
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x & 63];
-        float* d = col < C ? dgamma + col : dbeta + (col - C);
-        if (accumulate) *d += t; else *d = t;
+        float* d = col < C ? dgamma + col : (col < 2 * C ? dbeta + (col - C) : dprev + (col - 2 * C));
+        if (col < 2 * C ? accumulate : accumulate_prev) *d += t; else *d = t;
     }
 }
 
@@ -450,15 +467,21 @@ size_t hific_channelnorm_bwd_ws_bytes(int N, int C, int HW) {
     CnCfg cfg;
     if (C >= 2 && N > 0 && HW > 0 && cn_pick(N, C, HW, cfg, true)) {
         const size_t nblk = (size_t)cdiv(cdiv(HW, cfg.pxb), cn_pit(N, HW, cfg)) * N;
-        const size_t r = nblk * 2 * C * sizeof(float);
+        const size_t r = nblk * 3 * C * sizeof(float);
         if (r > b) b = r;
     }
     return b;
 }
 
+extern "C" int hific_channel_sum(const void* x, float* out, int N, int C, int HW, int accumulate, int dtype, void* ws,
+                                 size_t ws_bytes, hipStream_t st);
+
+// dprev_bias (may be null): float32 [C], receives (=|+= by accumulate_prev) sum_{n,hw} dx - the bias gradient of the
+// convolution that produced x (its only consumer is this norm)
 int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* mean,
                           const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int C, int HW, int relu,
-                          int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+                          int accumulate, int dtype, void* ws, size_t ws_bytes, float* dprev_bias, int accumulate_prev,
+                          hipStream_t st) {
     if (C < 2 || N <= 0 || HW <= 0) return HIFIC_ERR_ARG;
     if (dtype != HIFIC_F32 && dtype != HIFIC_BF16) return HIFIC_ERR_ARG;
     CnCfg cfg;
@@ -466,10 +489,16 @@ int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, con
         const int pit = cn_pit(N, HW, cfg);
         dim3 rgrid(cdiv(cdiv(HW, cfg.pxb), pit), N);
         const size_t nblk = (size_t)rgrid.x * rgrid.y;
-        if (nblk * 2 * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
+        const int nr = dprev_bias ? 3 : 2;
+        if (nblk * nr * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
         float* rpart = (float*)ws;
-#define CN_BWD_R(TT, PXB, NWV, CPT) hipLaunchKernelGGL((cn_bwd_reg_kernel<TT, PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, \
-                                           (const TT*)x, (const TT*)dy, gamma, beta, mean, rstd, (TT*)dx, rpart, C, HW, relu, pit, cn_remap_flag(2))
+#define CN_BWD_R(TT, PXB, NWV, CPT)                                                                                    \
+        do {                                                                                                           \
+            if (dprev_bias) hipLaunchKernelGGL((cn_bwd_reg_kernel<TT, PXB, NWV, CPT, true>), rgrid, dim3(NWV * 64), 0, st, \
+                (const TT*)x, (const TT*)dy, gamma, beta, mean, rstd, (TT*)dx, rpart, C, HW, relu, pit, cn_remap_flag(2)); \
+            else hipLaunchKernelGGL((cn_bwd_reg_kernel<TT, PXB, NWV, CPT, false>), rgrid, dim3(NWV * 64), 0, st,       \
+                (const TT*)x, (const TT*)dy, gamma, beta, mean, rstd, (TT*)dx, rpart, C, HW, relu, pit, cn_remap_flag(2)); \
+        } while (0)
 #define CN_BWD_C(TT, CPT)                                                                     \
         do {                                                                                  \
             if (cfg.pxb == 64 && cfg.nw == 4) CN_BWD_R(TT, 64, 4, CPT);                       \
@@ -482,8 +511,8 @@ int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, con
         else { if (cfg.cpt == 16) CN_BWD_C(bf16_t, 16); else CN_BWD_C(bf16_t, 32); }
 #undef CN_BWD_C
 #undef CN_BWD_R
-        hipLaunchKernelGGL(cn_param_colsum_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, rpart, dgamma, dbeta, C,
-                           (int)nblk, accumulate);
+        hipLaunchKernelGGL(cn_param_colsum_kernel, dim3(cdiv(nr * C, 64)), dim3(1024), 0, st, rpart, dgamma, dbeta, C,
+                           (int)nblk, accumulate, nr, dprev_bias, accumulate_prev);
         return hific_launch_status();
     }
     int nsplit = cdiv(1024, C);
@@ -508,6 +537,8 @@ int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, con
 #undef CN_BWD
     hipLaunchKernelGGL(cn_bwd_param_reduce_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, part, dgamma, dbeta, C,
                        nsplit, accumulate);
+    if (dprev_bias)        // shapes outside the register-resident kernel: the plain channel sum over dx (stream-ordered re-use of ws)
+        return hific_channel_sum(dx, dprev_bias, N, C, HW, accumulate_prev, dtype, ws, ws_bytes, st);
     return hific_launch_status();
 }
 

@@ -47,6 +47,8 @@ class Encoder(nn.Module):
             nn.Identity(),
             HipConv2d(filters[4], C, kernel_dim, stride=1, pads=(1, 1, 1, 1), pad_mode="reflect", out_f32=True),
         )
+        for blk in (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4, self.conv_block5):
+            channel.fuse_bias_grad(blk[1], blk[2])          # conv -> norm: the norm's backward also yields the conv's db
         # the latents are floored into the entropy coder's indices (src/hyperprior.py:68-74): split-bf16 forward
         mark_exact_index_chain(self)
 

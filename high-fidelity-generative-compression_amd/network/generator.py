@@ -30,6 +30,8 @@ class ResidualBlock(nn.Module):
         self.conv2 = HipConv2d(in_channels, in_channels, kernel_size, stride=stride, pads=(p, p, p, p), pad_mode="reflect")
         self.norm1 = norm(in_channels, relu=True)
         self.norm2 = norm(in_channels)
+        channel.fuse_bias_grad(self.conv1, self.norm1)
+        channel.fuse_bias_grad(self.conv2, self.norm2)
 
     def forward(self, x):
         x_conv, identity_map = ops.fork(x)
@@ -59,6 +61,7 @@ class Generator(nn.Module):
             HipConv2d(C, filters[0], (3, 3), stride=1, pads=(1, 1, 1, 1), pad_mode="reflect"),
             norm(filters[0]),
         )
+        channel.fuse_bias_grad(self.conv_block_init[2], self.conv_block_init[3])
         if sample_noise is True:
             filters[0] += self.noise_dim            # noise is concatenated to the head (generator.py:105-107, 149-152)
         for m in range(n_residual_blocks):
@@ -70,6 +73,9 @@ class Generator(nn.Module):
                 norm(filters[i + 1], relu=True),
                 nn.Identity(),
             ))
+        for i in range(4):
+            blk = getattr(self, f'upconv_block{i + 1}')
+            channel.fuse_bias_grad(blk[0], blk[1])
         self.conv_block_out = nn.Sequential(
             nn.Identity(),
             HipConv2d(filters[-1], 3, (7, 7), stride=1, pads=(3, 3, 3, 3), pad_mode="reflect"),

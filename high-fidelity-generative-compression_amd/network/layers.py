@@ -17,11 +17,13 @@ class HipConv2d(nn.Conv2d):
         self.act = act
         self.out_f32 = out_f32
         self.exact_index_chain = False     # set by the owner: this layer feeds the floor() of the latent indices
+        self.bias_grad_in_norm = False     # set by normalisation.channel.fuse_bias_grad: the norm behind this layer owns db
 
     def forward(self, x):
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], pads=self.pads,
                           pad_mode=self.hip_pad_mode, act=self.act, out_f32=self.out_f32,
-                          exact=self.exact_index_chain and ops.exact_index_on())
+                          exact=self.exact_index_chain and ops.exact_index_on(),
+                          bias_grad=not self.bias_grad_in_norm)
 
     def extra_repr(self):
         return super().extra_repr() + f", pads(t,l,b,r)={self.pads}, hip_act={self.act}"
@@ -37,11 +39,13 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
         self.act = act
         self.out_f32 = out_f32
         self.exact_index_chain = False
+        self.bias_grad_in_norm = False
 
     def forward(self, x):
         return ops.conv_transpose2d(x, self.weight, self.bias, self.stride[0], self.padding[0],
                                     self.output_padding[0], act=self.act, out_f32=self.out_f32,
-                                    exact=self.exact_index_chain and ops.exact_index_on())
+                                    exact=self.exact_index_chain and ops.exact_index_on(),
+                                    bias_grad=not self.bias_grad_in_norm)
 
 
 def mark_exact_index_chain(module, on=True):

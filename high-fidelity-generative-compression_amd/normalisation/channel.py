@@ -33,4 +33,19 @@ class ChannelNorm2D(nn.Module):
             self.register_buffer("beta", torch.zeros(1, input_channels, 1, 1), persistent=False)
 
     def forward(self, x):
-        return ops.channel_norm(x, self.gamma, self.beta, self.eps, relu=self.fuse_relu)
+        prod = self.__dict__.get("_bias_producer")
+        prev_bias = prod.bias if (prod is not None and prod.bias is not None and prod.bias_grad_in_norm) else None
+        return ops.channel_norm(x, self.gamma, self.beta, self.eps, relu=self.fuse_relu, prev_bias=prev_bias)
+
+
+def fuse_bias_grad(conv, norm):
+    """`norm` is the ONLY consumer of `conv`'s output (every conv -> ChannelNorm pair of encoder.py:56-93 and
+    generator.py:28-42,98-137): the bias gradient of `conv` is sum_{n,h,w} of the norm's input gradient, which the norm's
+    backward kernel already has in registers - it writes it, and the conv skips its own reduction pass (two launches over
+    an 8 MB tensor per residual-block conv).  No-op for the InstanceNorm fallback.  The reference is held in the norm's
+    __dict__ (not as a sub-module: the state_dict layout must stay the reference's)."""
+    import os
+    if not isinstance(norm, ChannelNorm2D) or conv.bias is None or os.environ.get("HIFIC_FUSE_BIAS_GRAD", "1") == "0":
+        return
+    norm.__dict__["_bias_producer"] = conv
+    conv.bias_grad_in_norm = True

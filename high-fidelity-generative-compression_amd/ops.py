@@ -564,9 +564,10 @@ class Conv2dFn(Function):
     """y = act(conv2d(pad(x)) + b).  geom = (stride, pt, pl, pb, pr, pad_mode)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, act, out_f32, w_scale, exact=False):
+    def forward(ctx, x, weight, bias, geom, act, out_f32, w_scale, exact=False, bias_grad=True):
         require_gpu(x, weight, bias)
         cd = _cd()
+        ctx.bias_grad = bool(bias_grad)      # False: the ChannelNorm behind this layer produces it (ChannelNormFn prev_bias)
         stride, pt, pl, pb, pr, pad_mode = geom
         N, C, H, W = x.shape
         K, Cw, R, S = weight.shape
@@ -615,7 +616,7 @@ class Conv2dFn(Function):
             dy = dz
         dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
         dx = dw = db = None
-        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_grad
         side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
         ev = torch.cuda.current_stream(x.device).record_event() if side else None       # dy is ready here
         if ctx.needs_input_grad[0]:
@@ -642,28 +643,29 @@ class Conv2dFn(Function):
                 param_grads()
         else:
             param_grads()
-        _written(ctx.w_slot if ctx.needs_input_grad[1] else None,
-                 ctx.b_slot if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
-        return dx, dw, db, None, None, None, None, None
+        _written(ctx.w_slot if ctx.needs_input_grad[1] else None, ctx.b_slot if want_b else None)
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride=1, pads=(0, 0, 0, 0), pad_mode=lib.PAD_ZERO, act=None, out_f32=False, w_scale=None,
-           exact=False):
+           exact=False, bias_grad=True):
     """`exact=True` (bf16 compute mode only): split-bf16 forward on float32 activations, float32 output - the exact-index
     chain (see set_exact_index); the backward pass is the ordinary bf16 one."""
     pt, pl, pb, pr = pads
     if exact and _compute_dtype == torch.bfloat16 and x.dtype != torch.float32:
         x = cast_grad(x, torch.float32)
-    return Conv2dFn.apply(x.contiguous(), weight, bias, (stride, pt, pl, pb, pr, pad_mode), act, out_f32, w_scale, exact)
+    return Conv2dFn.apply(x.contiguous(), weight, bias, (stride, pt, pl, pb, pr, pad_mode), act, out_f32, w_scale, exact,
+                          bias_grad)
 
 
 class ConvTranspose2dFn(Function):
     """nn.ConvTranspose2d semantics: weight [Cin, Cout, R, S]; geom = (stride, pad, outpad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, act, out_f32, exact=False):
+    def forward(ctx, x, weight, bias, geom, act, out_f32, exact=False, bias_grad=True):
         require_gpu(x, weight, bias)
         cd = _cd()
+        ctx.bias_grad = bool(bias_grad)
         stride, pad, outpad = geom
         N, Ci, H, W = x.shape
         Ciw, Co, R, S = weight.shape
@@ -710,7 +712,7 @@ class ConvTranspose2dFn(Function):
             dy = dz
         dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
         dx = dw = db = None
-        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_grad
         side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
         ev = torch.cuda.current_stream(x.device).record_event() if side else None
         if ctx.needs_input_grad[0]:
@@ -737,21 +739,24 @@ class ConvTranspose2dFn(Function):
                 param_grads()
         else:
             param_grads()
-        _written(ctx.w_slot if ctx.needs_input_grad[1] else None,
-                 ctx.b_slot if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
-        return dx, dw, db, None, None, None, None
+        _written(ctx.w_slot if ctx.needs_input_grad[1] else None, ctx.b_slot if want_b else None)
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv_transpose2d(x, weight, bias, stride, pad, outpad, act=None, out_f32=False, exact=False):
+def conv_transpose2d(x, weight, bias, stride, pad, outpad, act=None, out_f32=False, exact=False, bias_grad=True):
     if exact and _compute_dtype == torch.bfloat16 and x.dtype != torch.float32:
         x = cast_grad(x, torch.float32)
-    return ConvTranspose2dFn.apply(x.contiguous(), weight, bias, (stride, pad, outpad), act, out_f32, exact)
+    return ConvTranspose2dFn.apply(x.contiguous(), weight, bias, (stride, pad, outpad), act, out_f32, exact, bias_grad)
 
 
 # ------------------------------------------------------------------------------------------------------
 class ChannelNormFn(Function):
+    """`prev_bias`: the bias of the convolution that produced `x` when this norm is its only consumer (see
+    normalisation.channel.fuse_bias_grad): its gradient, sum_{n,hw} dx, then comes out of the norm's backward kernel and that
+    convolution skips its own channel-sum pass."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, prev_bias=None):
         require_gpu(x, gamma, beta)
         N, C, H, W = x.shape
         y = torch.empty_like(x)
@@ -761,6 +766,7 @@ class ChannelNormFn(Function):
              float(eps), int(relu), lib.dtype_code(x), stream())
         ctx.relu = int(relu)
         ctx.g_slot, ctx.b_slot = _slot(gamma), _slot(beta)
+        ctx.has_prev, ctx.p_slot = prev_bias is not None, _slot(prev_bias)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         return y
 
@@ -775,15 +781,18 @@ class ChannelNormFn(Function):
         dgt, acc_g, dg = _grad_target(ctx.g_slot, gamma)
         dbt, acc_b, db = _grad_target(ctx.b_slot, beta)
         assert acc_g == acc_b
+        dpt, acc_p, dp = (None, 0, None)
+        if ctx.has_prev and ctx.needs_input_grad[5]:
+            dpt, acc_p, dp = _grad_target(ctx.p_slot, gamma.new_empty(C))
         wsp, wsb = _ws(x)
         call("hific_channelnorm_bwd", ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dgt),
-             ptr(dbt), N, C, H * W, ctx.relu, acc_g, lib.dtype_code(x), wsp, wsb, stream())
-        _written(ctx.g_slot, ctx.b_slot)
-        return dx, dg, db, None, None
+             ptr(dbt), N, C, H * W, ctx.relu, acc_g, lib.dtype_code(x), wsp, wsb, ptr(dpt), acc_p, stream())
+        _written(ctx.g_slot, ctx.b_slot, ctx.p_slot if dpt is not None else None)
+        return dx, dg, db, None, None, dp
 
 
-def channel_norm(x, gamma, beta, eps=1e-3, relu=False):
-    return ChannelNormFn.apply(x.contiguous(), gamma, beta, eps, relu)
+def channel_norm(x, gamma, beta, eps=1e-3, relu=False, prev_bias=None):
+    return ChannelNormFn.apply(x.contiguous(), gamma, beta, eps, relu, prev_bias)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -79,9 +79,13 @@ int hific_conv_transpose2d_bwd_weight(const void* x, const void* dy, float* dw, 
 int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                           int N, int C, int HW, float eps, int relu, int dtype, hipStream_t stream);
 size_t hific_channelnorm_bwd_ws_bytes(int N, int C, int HW);
+/* dprev_bias (nullable, f32 [C]): additionally (=|+= by accumulate_prev) sum_{n,hw} dx, i.e. the bias gradient of the
+ * convolution whose output is x when this norm is its only consumer (encoder.py:56-93, generator.py:28-42,115-137): saves
+ * that layer's separate reduction pass over its gradient tensor. */
 int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* mean,
                           const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int C, int HW, int relu,
-                          int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t stream);
+                          int accumulate, int dtype, void* ws, size_t ws_bytes, float* dprev_bias, int accumulate_prev,
+                          hipStream_t stream);
 
 /* ---- elementwise / reductions (csrc/elementwise.hip) -------------------------------------------------------- */
 /* dx = y>0 ? dy : slope*dy — backward of F.relu (src/network/hyper.py:59-60,91-92) / LeakyReLU */

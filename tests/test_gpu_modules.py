@@ -45,7 +45,9 @@ def test_encoder(hific, dev, sd, dt, tol):
     hific.set_compute_dtype(dt)
     enc = _load(Encoder((3, 128, 128), 2, C=220), sd, "Encoder.").to(dev)
     x = O.make_image(1, 2, 128, 128)
-    watch = ("conv_block1.1.weight", "conv_block3.1.weight", "conv_block5.2.gamma", "conv_block_out.1.bias")
+    # (conv_block2.1.bias: produced by the ChannelNorm backward kernel, normalisation.channel.fuse_bias_grad)
+    watch = ("conv_block1.1.weight", "conv_block3.1.weight", "conv_block5.2.gamma", "conv_block_out.1.bias",
+             "conv_block2.1.bias", "conv_block5.1.bias")
 
     def oracle(odt):
         sdr = {k: v.to(odt).clone().requires_grad_(True) for k, v in sd.items() if k.startswith("Encoder.")}
@@ -70,7 +72,8 @@ def test_generator(hific, dev, sd, dt, tol):
     hific.set_compute_dtype(dt)
     gen = _load(Generator((3, 128, 128), 2, C=220, n_residual_blocks=N_RES), sd, "Generator.").to(dev)
     y = O.make_noise(3, (2, 220, 8, 8)) * 4
-    watch = ("resblock_0.conv1.weight", "upconv_block2.0.weight", "conv_block_out.1.weight", "resblock_1.norm2.beta")
+    watch = ("resblock_0.conv1.weight", "upconv_block2.0.weight", "conv_block_out.1.weight", "resblock_1.norm2.beta",
+             "resblock_0.conv1.bias", "resblock_1.conv2.bias", "upconv_block2.0.bias", "conv_block_init.2.bias")
 
     def oracle(odt):
         sdr = {k: v.to(odt).clone().requires_grad_(True) for k, v in sd.items() if k.startswith("Generator.")}
