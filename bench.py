@@ -400,7 +400,9 @@ def cpu_baseline(args):
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     env.pop("OMP_NUM_THREADS", None)
     if os.path.exists(REF_TAR) and os.environ.get("HIFIC_CPU_BASELINE", "reference") == "reference":
-        ths = sorted({ncores, max(1, ncores // 2), min(ncores, 32)})      # the usual optimum first, all logical cores last
+        # the usual optimum (32) first, then ALL logical cores (SURVEY section 8d asks for it; on the 256-thread EPYC box it is
+        # 3-10x slower than 32 threads - torch's CPU kernels oversubscribe), then half of them if the time limit allows
+        ths = [min(ncores, 32)] + [t for t in (ncores, max(1, ncores // 2)) if t > 32]
         cmd = [sys.executable, "-c",
                f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
                f"bench._cpu_reference_worker({args.size}, {args.cpu_batch}, {args.cpu_steps}, {ths}, {gan}, 10)"]
