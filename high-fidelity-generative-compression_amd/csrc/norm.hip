@@ -269,6 +269,77 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict
     }
 }
 
+// Exact-index chain: the norm between two split-bf16 convolutions.  Input = the float32 output z of
+// the exact convolution; from the float32 result y = relu?(gamma * (z - mu) * rstd + beta) it writes
+//   y   bf16 [N,C,HW]   - the NOMINAL activation: what the (plain bf16) backward pass of the next layer reads,
+//   x3  bf16 [N,3C,HW]  - (hi, lo, hi) of y, hi = bf16(y), lo = bf16(y - hi): the next exact convolution's operand,
+//   zb  bf16 [N,C,HW]   - bf16(z), saved for this norm's own backward (cn_bwd_reg_kernel<bf16>),
+// so the autograd graph of the chain is the plain bf16 one and no float32 activation is kept or re-read
+// (float32 norm + separate split pass: 18 bytes per element and a float32 backward; this: 14 and a bf16 backward).
+template <int PXB, int NW, int CPT>
+__global__ __launch_bounds__(NW * 64) void cn_fwd_exact_kernel(const float* __restrict__ z, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, bf16_t* __restrict__ zb,
+                                                               bf16_t* __restrict__ y, bf16_t* __restrict__ x3,
+                                                               float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                               int C, int HW, float eps, int relu, int remap) {
+    constexpr int SUBS = 64 / PXB, G = NW * SUBS;
+    __shared__ float red[2][NW][PXB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane % PXB, g = wave * SUBS + lane / PXB;
+    int bx, n;
+    cn_block_remap(bx, n, remap);
+    const int hw0 = bx * PXB + px;
+    const bool ok = hw0 < HW;
+    const int hw = ok ? hw0 : HW - 1;
+    const float* xb = z + (size_t)n * C * HW;
+    bf16_t* zbb = zb + (size_t)n * C * HW;
+    bf16_t* yb = y + (size_t)n * C * HW;
+    bf16_t* x3b = x3 + (size_t)n * 3 * C * HW;
+    float v[CPT], gm[CPT], bt[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = g + G * k; const int ci = c < C ? c : C - 1;
+        v[k] = xb[(unsigned)ci * (unsigned)HW + (unsigned)hw];
+        gm[k] = gamma[ci]; bt[k] = beta[ci];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) s += (g + G * k < C) ? v[k] : 0.f;
+    s = cn_sum_subs<PXB>(s);
+    if (lane < PXB) red[0][wave][px] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[0][w][px];
+    const float mu = tot / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { const float d = v[k] - mu; q += (g + G * k < C) ? d * d : 0.f; }
+    q = cn_sum_subs<PXB>(q);
+    if (lane < PXB) red[1][wave][px] = q;
+    __syncthreads();
+    float tq = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tq += red[1][w][px];
+    const float r = rsqrtf(tq / (float)(C - 1) + eps);
+    if (ok && threadIdx.x < PXB) { mean_out[(size_t)n * HW + hw] = mu; rstd_out[(size_t)n * HW + hw] = r; }
+    const unsigned chw = (unsigned)C * (unsigned)HW;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = g + G * k;
+        if (ok && c < C) {
+            float o = gm[k] * ((v[k] - mu) * r) + bt[k];
+            if (relu) o = o > 0.f ? o : 0.f;
+            const unsigned off = (unsigned)c * (unsigned)HW + (unsigned)hw;
+            const bf16_t h = f2bf(o);
+            const bf16_t l = f2bf(o - bf2f(h));
+            zbb[off] = f2bf(v[k]);
+            yb[off] = h;
+            x3b[off] = h; x3b[off + chw] = l; x3b[off + 2u * chw] = h;
+        }
+    }
+}
+
 // dx as in cn_bwd_dx_kernel; part[blk][0][c] = sum_px dy'*xhat, part[blk][1][c] = sum_px dy' over the PIT pixel groups
 // of workgroup blk (dy' = dy masked by the fused ReLU).
 // DB: also part[blk][2][c] = sum_px dx (as stored, i.e. rounded to T): the bias gradient of the convolution whose output
@@ -458,6 +529,32 @@ int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, 
     else if (dtype == HIFIC_BF16) { if (nw == 16) CN_FWD(bf16_t, 16); else if (nw == 8) CN_FWD(bf16_t, 8); else CN_FWD(bf16_t, 4); }
     else return HIFIC_ERR_ARG;
 #undef CN_FWD
+    return hific_launch_status();
+}
+
+// Exact-index chain norm (cn_fwd_exact_kernel): z f32 [N,C,HW] -> zb, y bf16 [N,C,HW], x3 bf16 [N,3C,HW], mean/rstd f32.
+// HIFIC_ERR_UNSUPPORTED when the shape has no register-resident configuration (the caller then runs the float32 norm and
+// hific_split3 instead).
+int hific_channelnorm_fwd_exact(const float* z, const float* gamma, const float* beta, void* zb, void* y, void* x3,
+                                float* mean, float* rstd, int N, int C, int HW, float eps, int relu, hipStream_t st) {
+    if (C < 2 || N <= 0 || HW <= 0 || !z || !zb || !y || !x3) return HIFIC_ERR_ARG;
+    if ((long long)3 * C * HW >= (1ll << 31)) return HIFIC_ERR_UNSUPPORTED;
+    CnCfg cfg;
+    if (!cn_pick(N, C, HW, cfg)) return HIFIC_ERR_UNSUPPORTED;
+    dim3 rgrid(cdiv(HW, cfg.pxb), N);
+#define CN_FWD_X(PXB, NWV, CPT) hipLaunchKernelGGL((cn_fwd_exact_kernel<PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, z, gamma, \
+                                       beta, (bf16_t*)zb, (bf16_t*)y, (bf16_t*)x3, mean, rstd, C, HW, eps, relu, cn_remap_flag(1))
+#define CN_FWD_XC(CPT)                                                                    \
+    do {                                                                                  \
+        if (cfg.pxb == 64 && cfg.nw == 4) CN_FWD_X(64, 4, CPT);                           \
+        else if (cfg.pxb == 64 && cfg.nw == 8) CN_FWD_X(64, 8, CPT);                      \
+        else if (cfg.pxb == 64) CN_FWD_X(64, 16, CPT);                                    \
+        else if (cfg.pxb == 32) CN_FWD_X(32, 16, CPT);                                    \
+        else CN_FWD_X(16, 16, CPT);                                                       \
+    } while (0)
+    if (cfg.cpt == 16) CN_FWD_XC(16); else CN_FWD_XC(32);
+#undef CN_FWD_XC
+#undef CN_FWD_X
     return hific_launch_status();
 }
 

@@ -52,7 +52,27 @@ class Encoder(nn.Module):
         # the latents are floored into the entropy coder's indices (src/hyperprior.py:68-74): split-bf16 forward
         mark_exact_index_chain(self)
 
+    def _forward_exact_chain(self, x):
+        """bf16 mode with the exact-index chain: every conv -> ChannelNorm -> ReLU block is ONE op (ops.ExactConvNormFn) that
+        reads the split-bf16 image of its input and emits the nominal bf16 activation plus the next block's split image, so
+        the forward values are float32-accurate while the stored activations and the whole backward pass are plain bf16."""
+        from .. import ops
+        x3 = ops.split3_act(x)
+        h = x
+        for blk in (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4, self.conv_block5):
+            conv, norm = blk[1], blk[2]
+            h, x3 = ops.exact_conv_norm(h, x3, conv.weight, conv.bias, conv.stride[0], conv.pads, conv.hip_pad_mode,
+                                        norm.gamma, norm.beta, norm.eps, norm.fuse_relu)
+        out = self.conv_block_out[1]
+        return ops.conv2d(h, out.weight, out.bias, stride=out.stride[0], pads=out.pads, pad_mode=out.hip_pad_mode,
+                          out_f32=True, exact=True, x3=x3)
+
     def forward(self, x):
+        from .. import ops
+        import torch
+        if (ops.exact_index_on() and ops.get_compute_dtype() == torch.bfloat16 and x.is_cuda and self.conv_block1[1].exact_index_chain
+                and isinstance(self.conv_block1[2], channel.ChannelNorm2D) and ops.fused_exact_blocks_on()):
+            return self._forward_exact_chain(x)
         x = self.conv_block1(x)
         x = self.conv_block2(x)
         x = self.conv_block3(x)

@@ -290,6 +290,15 @@ def exact_index_on():
     return _EXACT_INDEX
 
 
+# Encoder blocks of the exact chain as one op each (ExactConvNormFn: bf16 autograd graph, split images handed from norm to
+# conv); HIFIC_EXACT_FUSED=0: the round-3 first version (float32 activations + hific_split3 passes, float32 backward)
+_EXACT_FUSED = os.environ.get("HIFIC_EXACT_FUSED", "1") not in ("0", "")
+
+
+def fused_exact_blocks_on():
+    return _EXACT_FUSED
+
+
 class _SplitEntry:
     __slots__ = ("weight", "w3", "token", "addr", "transposed")
 
@@ -564,7 +573,7 @@ class Conv2dFn(Function):
     """y = act(conv2d(pad(x)) + b).  geom = (stride, pt, pl, pb, pr, pad_mode)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, act, out_f32, w_scale, exact=False, bias_grad=True):
+    def forward(ctx, x, weight, bias, geom, act, out_f32, w_scale, exact=False, bias_grad=True, x3=None):
         require_gpu(x, weight, bias)
         cd = _cd()
         ctx.bias_grad = bool(bias_grad)      # False: the ChannelNorm behind this layer produces it (ChannelNormFn prev_bias)
@@ -582,7 +591,9 @@ class Conv2dFn(Function):
         wsp, wsb = _ws(x)
         if exact:
             # split-bf16 forward: 3C reduction channels of (hi, lo, hi) x (hi, hi, lo); flags bit2 = count C (not 3C) FLOPs
-            x3, w3 = _split3_act(x), split_weights.get(weight, transposed=False)
+            # x3 given (ExactConvNormFn chain): x is the nominal bf16 activation, only saved for the weight gradient
+            x3 = x3 if x3 is not None else _split3_act(x)
+            w3 = split_weights.get(weight, transposed=False)
             flags = (1 << 1) | (1 << 2)
             wc = _wcache(w3, 0, (N, 3 * C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None)
             call("hific_conv2d_fwd", ptr(x3), ptr(w3), None, ptr(bias), None, ptr(y),
@@ -644,18 +655,19 @@ class Conv2dFn(Function):
         else:
             param_grads()
         _written(ctx.w_slot if ctx.needs_input_grad[1] else None, ctx.b_slot if want_b else None)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride=1, pads=(0, 0, 0, 0), pad_mode=lib.PAD_ZERO, act=None, out_f32=False, w_scale=None,
-           exact=False, bias_grad=True):
+           exact=False, bias_grad=True, x3=None):
     """`exact=True` (bf16 compute mode only): split-bf16 forward on float32 activations, float32 output - the exact-index
-    chain (see set_exact_index); the backward pass is the ordinary bf16 one."""
+    chain (see set_exact_index); the backward pass is the ordinary bf16 one.  `x3`: the (hi, lo, hi) image of `x` when the
+    caller already has it (then `x` may be the nominal bf16 activation)."""
     pt, pl, pb, pr = pads
-    if exact and _compute_dtype == torch.bfloat16 and x.dtype != torch.float32:
+    if exact and x3 is None and _compute_dtype == torch.bfloat16 and x.dtype != torch.float32:
         x = cast_grad(x, torch.float32)
     return Conv2dFn.apply(x.contiguous(), weight, bias, (stride, pt, pl, pb, pr, pad_mode), act, out_f32, w_scale, exact,
-                          bias_grad)
+                          bias_grad, x3)
 
 
 class ConvTranspose2dFn(Function):
@@ -789,6 +801,109 @@ class ChannelNormFn(Function):
              ptr(dbt), N, C, H * W, ctx.relu, acc_g, lib.dtype_code(x), wsp, wsb, ptr(dpt), acc_p, stream())
         _written(ctx.g_slot, ctx.b_slot, ctx.p_slot if dpt is not None else None)
         return dx, dg, db, None, None, dp
+
+
+class ExactConvNormFn(Function):
+    """One Encoder block of the exact-index chain with a plain-bf16 autograd graph:
+        (y, x3_next) = ChannelNorm[+ReLU]( conv_exact(x3; W) + b ).
+    `x` is the block's NOMINAL input (bf16 NCHW activation, or the float32 image) - saved for the weight gradient only;
+    `x3` is its split-bf16 image (hi, lo, hi) that the forward contraction really reads (hific_split3 layout, produced by
+    the previous block's norm kernel).  The convolution writes float32 z to a temporary; hific_channelnorm_fwd_exact turns
+    it into the nominal bf16 output y, the next block's x3 and bf16(z) for the norm's backward.  Backward = exactly what the
+    plain bf16 mode runs (ChannelNorm backward with the conv's bias gradient fused, data gradient, weight gradient on the
+    side stream): no float32 activation is stored, re-read or back-propagated."""
+
+    @staticmethod
+    def forward(ctx, x, x3, weight, bias, geom, gamma, beta, eps, relu):
+        require_gpu(x, x3, weight, bias, gamma, beta)
+        stride, pt, pl, pb, pr, pad_mode = geom
+        N, C, H, W = x.shape
+        K, Cw, R, S = weight.shape
+        assert Cw == C and tuple(x3.shape) == (N, 3 * C, H, W) and x3.dtype == torch.bfloat16
+        OH = (H + pt + pb - R) // stride + 1
+        OW = (W + pl + pr - S) // stride + 1
+        z = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
+        w3 = split_weights.get(weight, transposed=False)
+        flags = (1 << 1) | (1 << 2)
+        wsp, wsb = _ws(x)
+        wc = _wcache(w3, 0, (N, 3 * C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), HIFIC_BF16, flags, None)
+        call("hific_conv2d_fwd", ptr(x3), ptr(w3), None, ptr(bias), None, ptr(z), N, 3 * C, H, W, K, R, S, stride, pt, pl, pb,
+             pr, pad_mode, lib.ACT_NONE, HIFIC_BF16, flags, wsp, wsb, *wc, stream())
+        zb = torch.empty((N, K, OH, OW), dtype=torch.bfloat16, device=x.device)
+        y = torch.empty_like(zb)
+        x3n = torch.empty((N, 3 * K, OH, OW), dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty((N, OH * OW), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("hific_channelnorm_fwd_exact", ptr(z), ptr(gamma), ptr(beta), ptr(zb), ptr(y), ptr(x3n), ptr(mean), ptr(rstd),
+             N, K, OH * OW, float(eps), int(relu), stream())
+        ctx.geom, ctx.relu, ctx.has_bias = geom, int(relu), bias is not None
+        ctx.w_slot, ctx.b_slot, ctx.g_slot, ctx.be_slot = _slot(weight), _slot(bias), _slot(gamma), _slot(beta)
+        ctx.save_for_backward(x, weight, zb, gamma, beta, mean, rstd)
+        ctx.mark_non_differentiable(x3n)
+        return y, x3n
+
+    @staticmethod
+    def backward(ctx, dy, _unused):
+        x, weight, zb, gamma, beta, mean, rstd = ctx.saved_tensors
+        stride, pt, pl, pb, pr, pad_mode = ctx.geom
+        N, C, H, W = x.shape
+        K, _, R, S = weight.shape
+        OH, OW = zb.shape[2], zb.shape[3]
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = cast(dy, torch.bfloat16)
+        cd = HIFIC_BF16
+        # ---- ChannelNorm backward (bf16) with the convolution's bias gradient out of the same kernel ----------------
+        dz = torch.empty_like(zb)
+        dgt, acc_g, dg = _grad_target(ctx.g_slot, gamma)
+        dbt, acc_b, dbe = _grad_target(ctx.be_slot, beta)
+        assert acc_g == acc_b
+        want_b = ctx.has_bias and ctx.needs_input_grad[3]
+        dpt, acc_p, db = (None, 0, None)
+        if want_b:
+            dpt, acc_p, db = _grad_target(ctx.b_slot, gamma.new_empty(K))
+        wsp, wsb = _ws(x)
+        call("hific_channelnorm_bwd", ptr(zb), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dz), ptr(dgt),
+             ptr(dbt), N, K, OH * OW, ctx.relu, acc_g, HIFIC_BF16, wsp, wsb, ptr(dpt), acc_p, stream())
+        _written(ctx.g_slot, ctx.be_slot, ctx.b_slot if want_b else None)
+        # ---- convolution backward: plain bf16 kernels on (x, dz) -------------------------------------------------
+        dx = dw = None
+        want_w = ctx.needs_input_grad[2]
+        side = want_w and _use_side(ctx.w_slot)
+        ev = torch.cuda.current_stream(x.device).record_event() if side else None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            flags = (_is_f32(dx) << 1)
+            wc = _wcache(weight, 1, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None)
+            call("hific_conv2d_bwd_data", ptr(dz), ptr(weight), None, ptr(dx), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                 pad_mode, cd, flags, wsp, wsb, *wc, stream())
+
+        def wgrad():
+            nonlocal dw
+            wsp_, wsb_ = _ws(x)
+            dwt, acc, dw = _grad_target(ctx.w_slot, weight)
+            call("hific_conv2d_bwd_weight", ptr(x), ptr(dz), ptr(dwt), N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode,
+                 acc, cd, _is_f32(x), wsp_, wsb_, stream())
+        if want_w:
+            if side:
+                with _SideLaunch(ev, x, dz):
+                    wgrad()
+            else:
+                wgrad()
+        _written(ctx.w_slot if want_w else None)
+        return dx, None, dw, db, None, dg, dbe, None, None
+
+
+def exact_conv_norm(x, x3, weight, bias, stride, pads, pad_mode, gamma, beta, eps, relu):
+    pt, pl, pb, pr = pads
+    return ExactConvNormFn.apply(x.contiguous(), x3, weight, bias, (stride, pt, pl, pb, pr, pad_mode), gamma, beta, eps, relu)
+
+
+def split3_act(x):
+    """float32 [N,C,H,W] -> bf16 [N,3C,H,W] (hi, lo, hi): the operand image of the first exact convolution."""
+    if x.dtype != torch.float32:
+        x = cast(x.contiguous(), torch.float32)
+    return _split3_act(x.contiguous())
 
 
 def channel_norm(x, gamma, beta, eps=1e-3, relu=False, prev_bias=None):

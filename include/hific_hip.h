@@ -78,6 +78,12 @@ int hific_conv_transpose2d_bwd_weight(const void* x, const void* dy, float* dw, 
 /* ---- ChannelNorm2D (csrc/norm.hip) — src/normalisation/channel.py:48-59 (+ the ReLU after it) ------------- */
 int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                           int N, int C, int HW, float eps, int relu, int dtype, hipStream_t stream);
+/* The norm between two split-bf16 convolutions of the exact-index chain (encoder.py:56-93 blocks in bf16 mode): z is the
+ * float32 output of the exact convolution; writes zb = bf16(z) (for this norm's backward), y = bf16 of the float32 result
+ * (the nominal activation of the bf16 autograd graph) and x3 [N,3C,HW] = (hi, lo, hi) of that result (operand of the next
+ * exact convolution, hific_split3 layout).  Returns -4 when the shape has no register-resident configuration. */
+int hific_channelnorm_fwd_exact(const float* z, const float* gamma, const float* beta, void* zb, void* y, void* x3,
+                                float* mean, float* rstd, int N, int C, int HW, float eps, int relu, hipStream_t stream);
 size_t hific_channelnorm_bwd_ws_bytes(int N, int C, int HW);
 /* dprev_bias (nullable, f32 [C]): additionally (=|+= by accumulate_prev) sum_{n,hw} dx, i.e. the bias gradient of the
  * convolution whose output is x when this norm is its only consumer (encoder.py:56-93, generator.py:28-42,115-137): saves
