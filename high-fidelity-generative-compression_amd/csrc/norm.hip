@@ -269,6 +269,94 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict
     }
 }
 
+// Forward twin of cn_bwd_v8_kernel (below): a lane owns 8 consecutive pixels of a channel (16-byte load / store), 256 threads
+// own all channels of one 8-pixel group; the per-pixel mean and variance cross lanes (butterfly + one LDS hop).
+template <int CPT>
+__global__ __launch_bounds__(256) void cn_fwd_v8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                        int C, int HW, float eps, int relu, int remap) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ float red[2][4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, n;
+    cn_block_remap(bx, n, remap);
+    const int hw0 = bx * 8;
+    const size_t img = (size_t)n * C * HW + hw0;
+    u32x4_t xr[CPT];
+    float gm[CPT], bt[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + 256 * k; const int ci = c < C ? c : C - 1;
+        xr[k] = *(const u32x4_t*)(x + img + (size_t)ci * HW);
+        gm[k] = gamma[ci]; bt[k] = beta[ci];
+    }
+    float v[CPT][8], s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const bool okc = tid + 256 * k < C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned xw = xr[k][j >> 1];
+            v[k][j] = __uint_as_float((j & 1) ? (xw & 0xffff0000u) : (xw << 16));
+            s[j] += okc ? v[k][j] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s[j] += __shfl_xor(s[j], m);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[0][wave][j] = s[j];
+    }
+    __syncthreads();
+    float mu[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = ((red[0][0][j] + red[0][1][j]) + (red[0][2][j] + red[0][3][j])) / (float)C;
+        q[j] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const bool okc = tid + 256 * k < C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mu[j]; v[k][j] = d; q[j] += okc ? d * d : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) q[j] += __shfl_xor(q[j], m);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[1][wave][j] = q[j];
+    }
+    __syncthreads();
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        r[j] = rsqrtf(((red[1][0][j] + red[1][1][j]) + (red[1][2][j] + red[1][3][j])) / (float)(C - 1) + eps);
+    if (tid < 8) { mean_out[(size_t)n * HW + hw0 + tid] = mu[tid]; rstd_out[(size_t)n * HW + hw0 + tid] = r[tid]; }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C) {
+            u32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                float a = gm[k] * (v[k][j] * r[j]) + bt[k], b = gm[k] * (v[k][j + 1] * r[j + 1]) + bt[k];
+                if (relu) { a = a > 0.f ? a : 0.f; b = b > 0.f ? b : 0.f; }
+                o[j >> 1] = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+            }
+            *(u32x4_t*)(y + img + (size_t)c * HW) = o;
+        }
+    }
+}
+
 // Exact-index chain: the norm between two split-bf16 convolutions.  Input = the float32 output z of
 // the exact convolution; from the float32 result y = relu?(gamma * (z - mu) * rstd + beta) it writes
 //   y   bf16 [N,C,HW]   - the NOMINAL activation: what the (plain bf16) backward pass of the next layer reads,
@@ -427,6 +515,108 @@ __global__ __launch_bounds__(NW * 64) void cn_bwd_reg_kernel(const T* __restrict
     }
 }
 
+// Narrow planes with many channels (the 960-channel 16x16 residual blocks): cn_bwd_reg_kernel reaches its channel groups
+// with 8-pixel runs, i.e. 16 useful bytes per channel row and one 2-byte load per element (48 memory instructions per
+// thread and pixel group; 25 us for 24 MB).  Here a LANE owns 8 consecutive pixels of a channel - one 16-byte load per
+// tensor, one 16-byte store - and a workgroup of 256 threads owns all channels (c = tid + 256 k, k < CPT) of ONE 8-pixel
+// group: the per-channel sums (dgamma, dbeta, producer bias) stay in the thread, only the 2 x 8 per-pixel sums over the
+// channels cross lanes (DPP/permute butterfly + one LDS hop between the four waves).  bf16, HW % 8 == 0.
+// part[] layout as cn_bwd_reg_kernel with PXB = 8, pit = 1 (same workspace size, same column-sum pass).
+template <int CPT, bool DB>
+__global__ __launch_bounds__(256) void cn_bwd_v8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        bf16_t* __restrict__ dx, float* __restrict__ part,
+                                                        int C, int HW, int relu, int remap) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ float red[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, n;
+    cn_block_remap(bx, n, remap);                          // the 8 groups of a 128-byte line on one XCD
+    const int hw0 = bx * 8;
+    float mu[8], r[8];
+    {
+        const float4* mp = (const float4*)(mean + (size_t)n * HW + hw0);
+        const float4* rp = (const float4*)(rstd + (size_t)n * HW + hw0);
+        const float4 m0 = mp[0], m1 = mp[1], r0 = rp[0], r1 = rp[1];
+        mu[0] = m0.x; mu[1] = m0.y; mu[2] = m0.z; mu[3] = m0.w; mu[4] = m1.x; mu[5] = m1.y; mu[6] = m1.z; mu[7] = m1.w;
+        r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
+    }
+    const size_t img = (size_t)n * C * HW + hw0;
+    u32x4_t xr[CPT], gr[CPT];
+    float gm[CPT], bt[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {                       // every load issued up front, clamped index instead of a branch
+        const int c = tid + 256 * k; const int ci = c < C ? c : C - 1;
+        xr[k] = *(const u32x4_t*)(x + img + (size_t)ci * HW);
+        gr[k] = *(const u32x4_t*)(dy + img + (size_t)ci * HW);
+        gm[k] = gamma[ci]; bt[k] = beta[ci];
+    }
+    float dv[CPT][8], gv[CPT][8];                          // x - mu and gamma * dy' of this thread's elements
+    float pg[CPT], pb[CPT];
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const bool okc = tid + 256 * k < C;
+        pg[k] = 0.f; pb[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned xw = xr[k][j >> 1], gw = gr[k][j >> 1];
+            const float xv = __uint_as_float((j & 1) ? (xw & 0xffff0000u) : (xw << 16));
+            float g0 = __uint_as_float((j & 1) ? (gw & 0xffff0000u) : (gw << 16));
+            const float d = xv - mu[j], xh = d * r[j];
+            if (relu && !(gm[k] * xh + bt[k] > 0.f)) g0 = 0.f;
+            if (!okc) g0 = 0.f;
+            pg[k] += g0 * xh; pb[k] += g0;
+            const float gg = g0 * gm[k];
+            s1[j] += gg; s2[j] += gg * d;
+            dv[k][j] = d; gv[k][j] = gg;
+        }
+    }
+    // per-pixel sums over all channels: butterfly inside the wave, then across the four waves through LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { s1[j] += __shfl_xor(s1[j], m); s2[j] += __shfl_xor(s2[j], m); }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[wave][j] = s1[j]; red[wave][8 + j] = s2[j]; }
+    }
+    __syncthreads();
+    float S1[8], S2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float t1 = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+        const float t2 = (red[0][8 + j] + red[1][8 + j]) + (red[2][8 + j] + red[3][8 + j]);
+        S1[j] = t1 / (float)C;
+        S2[j] = t2 * r[j] * r[j] * r[j] / (float)(C - 1);
+    }
+    constexpr int NR = DB ? 3 : 2;
+    const size_t blk = (size_t)n * gridDim.x + bx;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C) {
+            u32x4_t o;
+            float pd = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const bf16_t lo = f2bf(r[j] * (gv[k][j] - S1[j]) - dv[k][j] * S2[j]);
+                const bf16_t hi = f2bf(r[j + 1] * (gv[k][j + 1] - S1[j + 1]) - dv[k][j + 1] * S2[j + 1]);
+                o[j >> 1] = (unsigned)lo | ((unsigned)hi << 16);
+                if constexpr (DB) pd += bf2f(lo) + bf2f(hi);              // what the tensor holds
+            }
+            *(u32x4_t*)(dx + img + (size_t)c * HW) = o;
+            part[(blk * NR + 0) * C + c] = pg[k];
+            part[(blk * NR + 1) * C + c] = pb[k];
+            if constexpr (DB) part[(blk * NR + 2) * C + c] = pd;
+        }
+    }
+}
+
 // dgamma/dbeta (=|+=) column sums of part[nblk][2][C]: 64 columns x 16 row lanes per workgroup, coalesced rows
 // (nr = 3: third row block = the producing convolution's bias gradient -> dprev, with its own accumulate flag)
 __global__ __launch_bounds__(1024) void cn_param_colsum_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
@@ -505,6 +695,17 @@ int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, 
     CnCfg cfg;
     if (cn_pick(N, C, HW, cfg)) {
         dim3 rgrid(cdiv(HW, cfg.pxb), N);
+        // narrowest pixel runs (C > 512 on small planes): the 16-byte-per-lane kernel (cn_fwd_v8_kernel)
+        static const int v8 = getenv("HIFIC_CN_FWD_V8") ? atoi(getenv("HIFIC_CN_FWD_V8")) : 1;
+        if (v8 && dtype == HIFIC_BF16 && cfg.pxb == 16 && HW % 8 == 0 && C <= 1024 &&
+            (((size_t)x | (size_t)y | (size_t)mean | (size_t)rstd) & 15) == 0) {
+            dim3 vgrid(HW / 8, N);
+            if (C <= 768) hipLaunchKernelGGL((cn_fwd_v8_kernel<3>), vgrid, dim3(256), 0, st, (const bf16_t*)x, gamma, beta,
+                                             (bf16_t*)y, mean, rstd, C, HW, eps, relu, cn_remap_flag(1));
+            else hipLaunchKernelGGL((cn_fwd_v8_kernel<4>), vgrid, dim3(256), 0, st, (const bf16_t*)x, gamma, beta,
+                                    (bf16_t*)y, mean, rstd, C, HW, eps, relu, cn_remap_flag(1));
+            return hific_launch_status();
+        }
 #define CN_FWD_R(TT, PXB, NWV, CPT) hipLaunchKernelGGL((cn_fwd_reg_kernel<TT, PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, \
                                            (const TT*)x, gamma, beta, (TT*)y, mean, rstd, C, HW, eps, relu, cn_remap_flag(1))
 #define CN_FWD_C(TT, CPT)                                                                     \
@@ -589,6 +790,24 @@ int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, con
         const int nr = dprev_bias ? 3 : 2;
         if (nblk * nr * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
         float* rpart = (float*)ws;
+        // 8-pixel runs (C > 512 on small planes): the 16-byte-per-lane kernel, same partial layout (cn_bwd_v8_kernel)
+        static const int v8 = getenv("HIFIC_CN_BWD_V8") ? atoi(getenv("HIFIC_CN_BWD_V8")) : 1;
+        if (v8 && dtype == HIFIC_BF16 && cfg.pxb == 8 && pit == 1 && HW % 8 == 0 && C <= 1024 &&
+            (((size_t)x | (size_t)dy | (size_t)dx | (size_t)mean | (size_t)rstd) & 15) == 0) {
+            dim3 vgrid(HW / 8, N);
+#define CN_BWD_V8(CPT)                                                                                                  \
+            do {                                                                                                        \
+                if (dprev_bias) hipLaunchKernelGGL((cn_bwd_v8_kernel<CPT, true>), vgrid, dim3(256), 0, st, (const bf16_t*)x,  \
+                    (const bf16_t*)dy, gamma, beta, mean, rstd, (bf16_t*)dx, rpart, C, HW, relu, cn_remap_flag(2));    \
+                else hipLaunchKernelGGL((cn_bwd_v8_kernel<CPT, false>), vgrid, dim3(256), 0, st, (const bf16_t*)x,      \
+                    (const bf16_t*)dy, gamma, beta, mean, rstd, (bf16_t*)dx, rpart, C, HW, relu, cn_remap_flag(2));    \
+            } while (0)
+            if (C <= 768) CN_BWD_V8(3); else CN_BWD_V8(4);
+#undef CN_BWD_V8
+            hipLaunchKernelGGL(cn_param_colsum_kernel, dim3(cdiv(nr * C, 64)), dim3(1024), 0, st, rpart, dgamma, dbeta, C,
+                               (int)nblk, accumulate, nr, dprev_bias, accumulate_prev);
+            return hific_launch_status();
+        }
 #define CN_BWD_R(TT, PXB, NWV, CPT)                                                                                    \
         do {                                                                                                           \
             if (dprev_bias) hipLaunchKernelGGL((cn_bwd_reg_kernel<TT, PXB, NWV, CPT, true>), rgrid, dim3(NWV * 64), 0, st, \

@@ -22,7 +22,9 @@ def _relerr(a, b):
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape,relu", [((2, 60, 24, 24), True), ((2, 960, 16, 16), False), ((3, 220, 5, 7), True),
-                                        ((4, 8, 250, 256), True), ((1, 1100, 3, 5), False)])
+                                        ((4, 8, 250, 256), True), ((1, 1100, 3, 5), False),
+                                        # many channels on narrow planes (residual blocks; 640: three channels per thread)
+                                        ((3, 960, 16, 16), True), ((2, 640, 8, 8), True)])
 def test_channelnorm(hific, dev, shape, relu, dt, tol):
     from hific_amd import ops
     x = _rnd(shape, 1, -2, 2)
@@ -48,6 +50,31 @@ def test_channelnorm(hific, dev, shape, relu, dt, tol):
     assert _relerr(xd.grad.float().cpu(), xr.grad) < tol * 3
     assert _relerr(gd.grad.cpu(), gr.grad) < tol * 3
     assert _relerr(bd.grad.cpu(), br.grad) < tol * 3
+
+
+@pytest.mark.parametrize("shape", [(3, 960, 16, 16), (2, 640, 8, 8), (2, 60, 24, 24)])
+def test_channelnorm_backward_returns_producer_bias_gradient(hific, dev, shape):
+    """ChannelNorm backward with `prev_bias` (normalisation.channel.fuse_bias_grad): the third output is sum_{n,h,w} dx as
+    the tensor holds it (bf16-rounded), i.e. the bias gradient of the convolution whose output the norm consumes."""
+    from hific_amd import ops
+    dt = torch.bfloat16
+    N, C, H, W = shape
+    x = _rnd(shape, 11, -2, 2).to(dev).to(dt).requires_grad_(True)
+    gamma = _rnd((1, C, 1, 1), 12, 0.5, 1.5).to(dev).requires_grad_(True)
+    beta = _rnd((1, C, 1, 1), 13, -0.3, 0.3).to(dev).requires_grad_(True)
+    pbias = torch.zeros(C, device=dev, requires_grad=True)
+    gy = _rnd(shape, 14).to(dev).to(dt)
+    y = ops.channel_norm(x, gamma, beta, 1e-3, relu=True, prev_bias=pbias)
+    y.backward(gy)
+    x2 = x.detach().clone().requires_grad_(True)
+    g2, b2 = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    y2 = ops.channel_norm(x2, g2, b2, 1e-3, relu=True)
+    y2.backward(gy)
+    torch.cuda.synchronize()
+    assert torch.equal(x.grad, x2.grad) and torch.equal(gamma.grad, g2.grad) and torch.equal(beta.grad, b2.grad)
+    want = x.grad.float().sum(dim=(0, 2, 3))
+    scale = float(x.grad.float().abs().sum(dim=(0, 2, 3)).max())
+    assert float((pbias.grad - want).abs().max()) <= 1e-5 * scale
 
 
 def test_factorized_likelihood(hific, dev):

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${OUTTAG:-r03_final}; mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-timeout 1200 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
+timeout 1200 python bench.py --steps 20 --warmup 5 --cpu-timeout 150 > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
 HIFIC_FORCE_DIST=1 timeout 200 python bench.py --steps 3 --warmup 2 --no-extras > $O/rccl_1rank.log 2>&1; tail -1 $O/rccl_1rank.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
 export HIFIC_SIDE_WGRAD=0 HIFIC_BRANCH_STREAMS=0
