@@ -22,26 +22,6 @@
 #ifndef SP9_ABL
 #define SP9_ABL 0           // timing ablations of gconv_sp9_kernel's A-from-global loop (WRONG RESULTS; tools/micro_sp9.py only):
 #endif                      // 1 = no patch loads / LDS writes, 2 = no A loads, 4 = no B fragment reads, 8 = no chunk barrier
-// Prefetch distances of gconv_sp9_kernel's A-from-global loop, in steps (one step = one tap of a 64-channel chunk).  Vector
-// loads return in order, so a wait for one load also waits for every older one: what a load can hide is the distance to the
-// FIRST wait that covers it.  A operands: SP9_AD steps ahead (register ring of AD+1 sets; 3 needs the chunk loop unrolled x4
-// so that the ring slot of a (chunk, tap) stays a compile-time constant).  Patch rows: requested in steps 0..3, written to LDS
-// SP9_PD steps later (min(PD+1, 4) register sets).  SP9_PFIRST: patch requests before the A requests of the same step.
-#ifndef SP9_AD
-#define SP9_AD 2
-#endif
-#ifndef SP9_PD
-#define SP9_PD 2
-#endif
-#ifndef SP9_PFIRST
-#define SP9_PFIRST 0
-#endif
-#ifndef SP9_W4_PD
-#define SP9_W4_PD 1         // four-quarter form with 64x128 slabs: 128 accumulator registers leave room for two patch sets
-#endif
-#ifndef SP9_W4_PFIRST
-#define SP9_W4_PFIRST 0
-#endif
 #ifndef SP9_TOFF_ARG
 #define SP9_TOFF_ARG 1      // gconv_sp9_kernel: tap offsets from the kernel arguments instead of the LDS table (-1..2 %)
 #endif
@@ -768,40 +748,27 @@ __host__ __device__ constexpr int sp9_tap_in_phase(int phs, int t) {
 // are no longer in lockstep, so the CU scheduler has something to arbitrate); 3 = + the B fragments of the next tap are read
 // from LDS before the current tap's MFMAs are issued (register double buffer; taps of one chunk share the patch buffer);
 // 4 = level 3 without the priority hints.
-// KSP = 4 (with AG): four reduction quarters - a wave owns one 16-deep slice of every 64-channel chunk and a slab that spans
-// all 128 PIXELS of the tile (WN = 4, one wave column), so no two waves load the same A operand (the 64x64 wave tiles of
-// KSP = 2 stream every A operand through the vector-memory path twice, once per wave column: 32 KB per step and CU = the whole
-// 64 B/clk of that path at the MFMA rate).
-//   WM = 2: 8 waves, 2 row positions x 4 quarters, 64-row x 128-pixel slabs: 2 A + 4 B operands per 8 MFMAs.
-//   WM = 4: 4 waves (one per SIMD, 512 registers each, accumulators in AGPRs), every wave the whole 128x128 tile of its
-//           quarter: 4 A + 4 B operands per 16 MFMAs - half the operand bytes per MFMA on both sides; no second wave hides
-//           latency, so it runs the register double buffer for B (AG = 4).
-// The four partial accumulators meet in a two-stage tree through LDS (each stage halves the pixel fragments a wave keeps) and
-// every wave writes one pixel fragment of its row blocks.
-__host__ __device__ constexpr int sp9_threads(int wm, int ksp) { return ksp == 4 ? (wm == 4 ? 256 : 512) : 256 * ksp; }
-// WP (wide patch staging; plan: tile rows = whole image rows, W % 8 == 0, 16-byte aligned input, one pixel of padding):
-// the next chunk's halo patch comes in as 16-byte loads - 8 consecutive pixels of one channel, lane = (channel pair, aligned
-// group) as in stage_W, at most two (patch row, group pair) items per wave and chunk - instead of one 2-byte load per
-// (pixel, channel): 20 instead of 192 vector-memory instructions per chunk and workgroup on the 16x16 residual blocks, and
-// the LDS writes become the conflict-free 32-consecutive-dwords form (the pixel-per-lane writes are 4-way conflicted at the
-// 144-byte pitch).  The two padding columns of a row are written from the registers that already hold their mirror pixels.
-template <int WM, int KSP, bool RFX, int PHS, bool DS = false, int AG = 0, bool WP = false>
-__global__ __launch_bounds__(sp9_threads(WM, KSP))
-__attribute__((amdgpu_waves_per_eu((PHS || WM == 4) ? 1 : 2, (PHS || WM == 4) ? 1 : 2)))
+// KSP = 4 (with AG): four reduction quarters - 8 waves as 2 row positions x 4 quarters; a wave owns one 16-deep slice of every
+// 64-channel chunk and a 64-row slab that spans all 128 PIXELS of the tile (WN = 4, one wave column): 2 A + 4 B operands per
+// 8 MFMAs, and no two waves load the same A operand (the 64x64 wave tiles of KSP = 2 stream every A operand through the
+// vector-memory path twice, once per wave column).  The four partial accumulators meet in a two-stage tree through LDS (each
+// stage halves the pixel fragments a wave keeps) and every wave writes one pixel fragment of its two row blocks.
+// (Also measured: 128x128 slabs on four waves, one per SIMD with 512 registers and the B register double buffer - half the
+//  operand bytes per MFMA on both sides, but nothing hides a wave's own waits: 89 vs 66 us on 960->960 @16x16x16.)
+__host__ __device__ constexpr int sp9_threads(int ksp) { return ksp == 4 ? 512 : 256 * ksp; }
+template <int WM, int KSP, bool RFX, int PHS, bool DS = false, int AG = 0>
+__global__ __launch_bounds__(sp9_threads(KSP)) __attribute__((amdgpu_waves_per_eu(PHS ? 1 : 2, PHS ? 1 : 2)))
 void gconv_sp9_kernel(const GcParams p) {
     typedef bf16_t T;
     static_assert(!(PHS && (RFX || KSP != 1)), "phase-merged mode: 4 waves, no reflect gather");
     static_assert(!(DS && (RFX || PHS)), "shifted fragments: plain 3x3 stride-1 forward type only");
-    static_assert(AG == 0 || (((WM == 2 && KSP == 2) || KSP == 4) && PHS == 0 && !DS), "A-from-global: 128-row K-split tiles");
-    static_assert(KSP != 4 || (AG != 0 && (WM == 2 || WM == 4)), "four reduction quarters: A-from-global form only");
-    static_assert(WM != 4 || KSP == 4, "128-row wave slabs: four-quarter form only");
-    static_assert(!WP || (AG == 1 && !RFX), "wide patch staging: A-from-global forward form");
+    static_assert(AG == 0 || (WM == 2 && (KSP == 2 || KSP == 4) && PHS == 0 && !DS), "A-from-global: 128-row K-split tiles");
+    static_assert(KSP != 4 || AG == 1, "four reduction quarters: A-from-global form only");
     constexpr bool W4 = KSP == 4;
     constexpr int NPH = PHS ? 4 : 1;
     constexpr int BC = 64, KS = 16, PITCH = 144, PPR = 8, WGN = W4 ? 1 : 2, WN = W4 ? 4 : 2, NT = 9, QJ = 3;
-    constexpr int WGM = WM == 4 ? 1 : 2;       // row positions of the wave grid
-    constexpr int BM = WGM * WM * 32;
-    constexpr int NPOS = WGM * WGN;            // wave positions inside the tile
+    constexpr int BM = 2 * WM * 32;
+    constexpr int NPOS = 2 * WGN;              // wave positions inside the tile (2 row positions x WGN pixel positions)
     constexpr int NWAVES = NPOS * KSP;
     constexpr int NTHR = 64 * NWAVES;
     constexpr int WBYTES = BM * PITCH, NWP = BM * PPR / NTHR;
@@ -894,34 +861,6 @@ void gconv_sp9_kernel(const GcParams p) {
         rfx_c[ni][2] = !RFX ? 0 : (j == W - 2 ? 3 * PITCH : (j == 0 ? RFX_ZERO : 0));
     }
 
-    // WP: this wave's (at most two) staging items - item = (patch row, pair of aligned 8-pixel groups), lane = (channel pair,
-    // group of the pair); everything but the channel offset is the same for every chunk
-    const int cpW = lane & 31;
-    unsigned woff[2] = {0u, 0u};
-    int wA0[2] = {0, 0};
-    bool wok[2] = {false, false}, wval[2] = {false, false}, wleft[2] = {false, false}, wright[2] = {false, false};
-    if constexpr (WP) {
-        const int G = p.IW >> 3, NG2 = (G + 1) >> 1, nitems = p.NI * PH * NG2;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int it = wave + NWAVES * s2;
-            const int row = it / NG2;
-            const int g = (it - row * NG2) * 2 + (lane >> 5);
-            const int img = row / PH, py = row - img * PH;
-            int iy = iy0 + py;
-            if (p.bmode == PAD_REFLECT) iy = reflect_idx(iy, p.IH);
-            const int n = n0 + img;
-            wval[s2] = it < nitems && g < G;
-            wok[s2] = wval[s2] && n < p.N && (unsigned)iy < (unsigned)p.IH;
-            woff[s2] = wok[s2] ? ((unsigned)n * (unsigned)p.C * (unsigned)(p.IH * p.IW) + (unsigned)iy * (unsigned)p.IW + (unsigned)(g * 8)) : 0u;
-            wA0[s2] = (row * PW + 1 + g * 8) * PITCH + cpW * 4;
-            wleft[s2] = wval[s2] && g == 0;
-            wright[s2] = wval[s2] && g == G - 1;
-        }
-    }
-    u32x4_t wva[2], wvb[2];
-    unsigned woffa = 0u, woffb = 0u, wcmask = 0u;
-
     f32x16_t acc[NPH][WM][WN];
 #pragma unroll
     for (int f = 0; f < NPH; ++f)
@@ -964,17 +903,17 @@ void gconv_sp9_kernel(const GcParams p) {
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi)
         abase[mi] = (const unsigned char*)p.wp + ((size_t)((m0 >> 5) + wm * WM + mi) * NT * nchunks_all) * 4096 + lane * 16;
-    constexpr bool W4S = W4 && WM == 2;                         // the register-bound form
-    constexpr int AD = (AG == 1 && !W4S) ? SP9_AD : 2, ARING = AD + 1;
-    constexpr int PDS = AG != 1 ? 2 : (W4S ? SP9_W4_PD : SP9_PD), PSETS = PDS + 1 < 4 ? PDS + 1 : 4;
-    constexpr bool PFIRST = AG == 1 && (W4S ? SP9_W4_PFIRST : SP9_PFIRST);
-    static_assert(AD == 2 || AD == 3, "A ring: 3 sets, or 4 with the chunk loop unrolled x4");
-    static_assert(PDS >= 1 && PDS <= 5, "patch rows must be in LDS before the next chunk's barrier");
-    u32x4_t aS[ARING][WM][BC / KS / KSP];
+    // A operands are requested two steps ahead (ring of three register sets); patch rows are written to LDS PDS steps after
+    // their request - one step in the 64x128-slab form, whose 128 accumulator registers leave room for two patch sets only.
+    // (Measured, round 3: patch distances 3 and 4, patch requests ahead of the A requests, and A operands by LDS-DMA into a
+    //  wave-private ring all ran within +-1.5 % of this schedule; a ring of four A sets needs the chunk loop unrolled x4 and
+    //  spills.  Vector loads return in order, so a wait for one load is a wait for every older one.)
+    constexpr int PDS = (AG == 1 && W4) ? 1 : 2, PSETS = PDS + 1;
+    u32x4_t aS[3][WM][BC / KS / KSP];
     u32x4_t bS[2][WN][BC / KS / KSP];                           // AG >= 3: B fragments of the current / next tap
     constexpr int PD = 8 / NWAVES;                              // patch dword columns issued per step (steps 0..3)
     u32x4_t wS[3][NWP];
-    unsigned short rlo[PSETS < 3 ? 3 : PSETS][PD * QJ], rhi[PSETS < 3 ? 3 : PSETS][PD * QJ];
+    unsigned short rlo[3][PD * QJ], rhi[3][PD * QJ];
     u32x4_t bsh[WN][BC / KS / KSP];                             // DS: B fragments carried from tap to tap of a kernel row
     const bool edge_lane = (l31 & 15) == 15;                    // last pixel of a 16-pixel tile row
 
@@ -1022,37 +961,6 @@ void gconv_sp9_kernel(const GcParams p) {
                 const unsigned hi_ = (qok[j] && c1ok) ? (unsigned)rhi[SET][d * QJ + j] : 0u;                \
                 *(unsigned*)(pnext + pdst[j] + (PD * (tt) + d) * 4 * NWAVES) = lo_ | (hi_ << 16);           \
             }                                                                                               \
-        }                                                                                                   \
-    } while (0)
-    // WP: channel offsets of the NEXT chunk for this lane's pair (once per chunk), item S2 requested / written to LDS
-#define SP_WPCHUNK()                                                                                        \
-    do {                                                                                                    \
-        const int ca_ = c0n + 2 * cpW;                                                                      \
-        const bool oka_ = ca_ < p.C, okb_ = ca_ + 1 < p.C;                                                  \
-        woffa = (oka_ ? (unsigned)ca_ : 0u) * plane; woffb = (okb_ ? (unsigned)(ca_ + 1) : 0u) * plane;     \
-        wcmask = (oka_ ? 0xffffu : 0u) | (okb_ ? 0xffff0000u : 0u);                                         \
-    } while (0)
-#define SP_WPISSUE(S2)                                                                                      \
-    do {                                                                                                    \
-        wva[S2] = *(const u32x4_t*)(inb + woff[S2] + woffa);                                                \
-        wvb[S2] = *(const u32x4_t*)(inb + woff[S2] + woffb);                                                \
-    } while (0)
-#define SP_WPRETIRE(S2)                                                                                     \
-    do {                                                                                                    \
-        if (wval[S2]) {                                                                                     \
-            const unsigned vm_ = wok[S2] ? wcmask : 0u;                                                     \
-            unsigned char* d_ = pnext + wA0[S2];                                                            \
-            unsigned v1_ = 0u, v6_ = 0u;                                                                    \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
-                const unsigned v_ = __builtin_amdgcn_perm(wvb[S2][e >> 1], wva[S2][e >> 1],                 \
-                                                          (e & 1) ? 0x07060302u : 0x05040100u) & vm_;      \
-                *(unsigned*)(d_ + e * PITCH) = v_;                                                          \
-                if (e == 1) v1_ = v_;                                                                       \
-                if (e == 6) v6_ = v_;                                                                       \
-            }                                                                                               \
-            const bool refl_ = p.bmode == PAD_REFLECT;                                                      \
-            if (wleft[S2]) *(unsigned*)(d_ - PITCH) = refl_ ? v1_ : 0u;                                     \
-            if (wright[S2]) *(unsigned*)(d_ + 8 * PITCH) = refl_ ? v6_ : 0u;                                \
         }                                                                                                   \
     } while (0)
 #define SP_COMPUTE(SLOT, tt)                                                                                    \
@@ -1128,30 +1036,25 @@ void gconv_sp9_kernel(const GcParams p) {
     // AG: operands of step tt sit in register set tt%3 (requested two steps earlier); the patch double buffer is the only
     // shared state - next chunk's rows are written in steps 2..5 and first read after the barrier of the next chunk's step 0,
     // which also orders the last reads of the buffer that becomes `pnext` there before its first overwrite (step 2)
-    // AG == 1: the general form.  CP = chunk index modulo the unroll period; tile sequence number g = CP * NT + tt.
-#define SP_STEP1(tt, CP)                                                                    \
+    // AG == 1: operands of step tt sit in register set tt % 3 (requested two steps earlier)
+#define SP_STEP1(tt)                                                                        \
     do {                                                                                    \
-        constexpr int g_ = (CP) * NT + (tt);                                                \
         if constexpr (!(SP9_ABL & 8)) { if ((tt) == 0) __syncthreads(); }                   \
-        if constexpr (WP) { if ((tt) == 0) SP_WPCHUNK(); }                                  \
-        if constexpr (PFIRST && !WP && !(SP9_ABL & 1)) { if ((tt) < 4) SP_PISSUE((tt) % PSETS, tt); }  \
         if constexpr (!(SP9_ABL & 2)) {                                                     \
-            if ((tt) + AD < NT) SP_AISSUE((g_ + AD) % ARING, chunk, (tt) + AD);             \
-            else SP_AISSUE((g_ + AD) % ARING, chunk + 1, (tt) + AD - NT);                   \
+            if ((tt) + 2 < NT) SP_AISSUE(((tt) + 2) % 3, chunk, (tt) + 2);                  \
+            else SP_AISSUE(((tt) + 2) % 3, chunk + 1, (tt) + 2 - NT);                       \
         }                                                                                   \
-        if constexpr (WP) { if ((tt) < 2) SP_WPISSUE((tt) & 1); }                           \
-        else if constexpr (!PFIRST && !(SP9_ABL & 1)) { if ((tt) < 4) SP_PISSUE((tt) % PSETS, tt); } \
+        if constexpr (!(SP9_ABL & 1)) { if ((tt) < 4) SP_PISSUE((tt) % PSETS, tt); }        \
         /* keep the requests HERE: the scheduler otherwise sinks each load to just above its MFMA two steps later */ \
         __builtin_amdgcn_sched_barrier(0);                                                  \
-        SP_COMPUTE(g_ % ARING, tt);                                                         \
-        if constexpr (WP) { if ((tt) == 2 || (tt) == 3) SP_WPRETIRE((tt) & 1); }             \
-        else if constexpr (!(SP9_ABL & 1)) {                                                \
+        SP_COMPUTE((tt) % 3, tt);                                                           \
+        if constexpr (!(SP9_ABL & 1)) {                                                     \
             if ((tt) >= PDS && (tt) < 4 + PDS) SP_PRETIRE(((tt) - PDS) % PSETS, (tt) - PDS); \
         }                                                                                   \
     } while (0)
 #define SP_STEP(tt)                                                                         \
     do {                                                                                    \
-        if constexpr (AG == 1) { SP_STEP1(tt, 0); }                                         \
+        if constexpr (AG == 1) { SP_STEP1(tt); }                                            \
         else if constexpr (AG != 0) {                                                       \
             if constexpr (!(SP9_ABL & 8)) { if ((tt) == 0) __syncthreads(); }               \
             if constexpr (!(SP9_ABL & 2)) {                                                 \
@@ -1190,46 +1093,22 @@ void gconv_sp9_kernel(const GcParams p) {
     if constexpr (AG != 0) {
         SP_AISSUE(0, chunk_lo, 0);
         SP_AISSUE(1, chunk_lo, 1);
-        if constexpr (AD == 3) SP_AISSUE(2, chunk_lo, 2);
     } else {
         SP_WISSUE(0, chunk_lo, 0);
         SP_WRETIRE(0, 0);
         SP_WISSUE(1, chunk_lo, 1);
         SP_WISSUE(2, chunk_lo, 2);
     }
-#define SP_CHUNK1(CP)                                                                                           \
-    do {                                                                                                            \
-        const unsigned char* pcur = pbuf + ((chunk - chunk_lo) & 1) * patch_bytes;                                  \
-        unsigned char* pnext = pbuf + ((chunk - chunk_lo + 1) & 1) * patch_bytes;                                   \
-        const int c0n = (chunk + 1 < nchunks ? chunk + 1 : chunk) * BC;                                             \
-        SP_STEP1(0, CP); SP_STEP1(1, CP); SP_STEP1(2, CP); SP_STEP1(3, CP); SP_STEP1(4, CP); SP_STEP1(5, CP);       \
-        SP_STEP1(6, CP); SP_STEP1(7, CP); SP_STEP1(8, CP);                                                          \
-    } while (0)
-    if constexpr (AG == 1 && AD == 3) {
-        // ring of 4: slot of (chunk, tap) = (chunk - chunk_lo + tap) % 4 - four copies of the chunk body
-        int chunk = chunk_lo;
-        while (chunk < chunk_hi) {
-            SP_CHUNK1(0); if (++chunk >= chunk_hi) break;
-            SP_CHUNK1(1); if (++chunk >= chunk_hi) break;
-            SP_CHUNK1(2); if (++chunk >= chunk_hi) break;
-            SP_CHUNK1(3); ++chunk;
-        }
-    } else {
     for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
         const unsigned char* pcur = pbuf + ((chunk - chunk_lo) & 1) * patch_bytes;
         unsigned char* pnext = pbuf + ((chunk - chunk_lo + 1) & 1) * patch_bytes;
         const int c0n = (chunk + 1 < nchunks ? chunk + 1 : chunk) * BC;     // last chunk: harmless re-load
         SP_STEP(0); SP_STEP(1); SP_STEP(2); SP_STEP(3); SP_STEP(4); SP_STEP(5); SP_STEP(6); SP_STEP(7); SP_STEP(8);
     }
-    }
-#undef SP_CHUNK1
 #undef SP_STEP1
 #undef SP_STEP
 #undef SP_COMPUTE
 #undef SP_PRETIRE
-#undef SP_WPRETIRE
-#undef SP_WPISSUE
-#undef SP_WPCHUNK
 #undef SP_PISSUE
 #undef SP_WRETIRE
 #undef SP_MFMA_REG
@@ -2916,24 +2795,13 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
              p.K, p.C, p.N, p.IH, p.IW, p.OHf, p.OWf, p.nphase, maxtaps, p.ist, p.ost, p.NI, p.TH, p.TW, bm, tps,
              max_tiles * (p.Kpad / bm) * p.nphase * p.ksplit);
     char kname[PROF_NAMELEN];
-    // four-quarter forms (gconv_sp9_kernel KSP = 4).  Measured (round 3, 960->960 @16x16x16, in the training cycle): 64x128
-    // slabs (1) 68.7 -> 66.4 us forward, 76.1 -> 74.3 us gather-form data gradient; 128x128 slabs on one wave per SIMD (2) 89 us
-    const int sp9_w4 = (use_sp9 && p.afrag) ? env_int("HIFIC_SP9_W4", 1) : 0;
-    // wide patch staging (gconv_sp9_kernel WP): tile rows are whole, 16-byte aligned image rows with one pixel of padding.
-    // Opt-in: bit-identical LDS image, 20 instead of 192 vector-memory instructions per chunk and workgroup, and no measurable
-    // gain (960->960 @16x16x16: 85.0 vs 84.9 us stand-alone, cycle 27.7 ms either way) - the loop is not VMEM-issue bound.
-    bool sp9_wp = false;
-    if (sp9_w4 == 1 && !p.rfx && env_int("HIFIC_SP9_WP", 0)) {
-        const GcPhase& ph0 = p.ph[0];
-        const int nitems = p.NI * ph0.PH * ((p.IW / 8 + 1) / 2);
-        sp9_wp = p.ist == 1 && !p.in_f32 && p.IW >= 8 && p.IW % 8 == 0 && p.TW == p.IW && ph0.tiles_x == 1 && ph0.dx_min == -1 &&
-                 ph0.PW == p.TW + 2 && (((size_t)p.in) & 15) == 0 && nitems <= 16 &&
-                 (p.bmode == PAD_ZERO || p.bmode == PAD_REFLECT);
-    }
-    if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d%s>", sp9_w4 == 2 ? 4 : bm / 64,
+    // four-quarter form (gconv_sp9_kernel KSP = 4).  Measured (round 3, 960->960 @16x16x16, in the training cycle):
+    // 68.7 -> 66.4 us forward, 76.1 -> 74.3 us gather-form data gradient against the two-half form (HIFIC_SP9_W4=0)
+    const int sp9_w4 = (use_sp9 && p.afrag) ? (env_int("HIFIC_SP9_W4", 1) != 0) : 0;
+    if (use_sp9) snprintf(kname, sizeof(kname), "gconv_sp9_kernel<%d,%d%s>", bm / 64,
                           sp9_w4 ? 4 : phs ? 1 : p.rfx ? (bm == 128 ? 2 : 1)
                                 : ((env_int("HIFIC_SP9_KSPLIT", 2) == 2 && (bm == 128 || env_int("HIFIC_SP9_KSPLIT64", 0))) ? 2 : 1),
-                          phs ? (phs == 1 ? ",phs1" : ",phs2") : (p.rfx ? ",rfx" : (sp9_wp ? ",wp" : "")));
+                          phs ? (phs == 1 ? ",phs1" : ",phs2") : (p.rfx ? ",rfx" : ""));
     else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
                   bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
     const int pslot = prof_open(kname, aflops, st, ptag);
@@ -2982,7 +2850,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                     // no weight ring; the K-split exchange (64 KB) is the larger LDS use for the usual 180-pixel patch
                     size_t lds_ag = 64 + 2 * (((size_t)(npatch + 2) * PITCH + 15) & ~(size_t)15);
                     // four reduction quarters on 64x128 wave slabs (gconv_sp9_kernel KSP = 4): half the A operand loads per MFMA
-                    const int w4 = sp9_w4;                             // 1: 8 waves, 64x128 slabs; 2: 4 waves, 128x128 slabs
+                    const int w4 = sp9_w4;
                     if (lds_ag < (w4 ? 131072u : 65536u)) lds_ag = w4 ? 131072 : 65536;
                     const int agl = env_int("HIFIC_SP9_AG", 1);
 #define SP9_AG_LAUNCH(RFX_, L_)                                                                                         \
@@ -2993,14 +2861,9 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
 #define SP9_W4_LAUNCH(WM_, RFX_, L_)                                                                                    \
     do {                                                                                                                \
         gc_set_max_lds((const void*)gconv_sp9_kernel<WM_, 4, RFX_, 0, false, L_>, (int)lds_ag);                         \
-        hipLaunchKernelGGL((gconv_sp9_kernel<WM_, 4, RFX_, 0, false, L_>), grid, dim3(sp9_threads(WM_, 4)), lds_ag, st, p); \
+        hipLaunchKernelGGL((gconv_sp9_kernel<WM_, 4, RFX_, 0, false, L_>), grid, dim3(sp9_threads(4)), lds_ag, st, p);      \
     } while (0)
-                    if (w4 == 2) { if (p.rfx) SP9_W4_LAUNCH(4, true, 4); else SP9_W4_LAUNCH(4, false, 4); }
-                    else if (w4 == 1 && sp9_wp) {
-                        gc_set_max_lds((const void*)gconv_sp9_kernel<2, 4, false, 0, false, 1, true>, (int)lds_ag);
-                        hipLaunchKernelGGL((gconv_sp9_kernel<2, 4, false, 0, false, 1, true>), grid, dim3(512), lds_ag, st, p);
-                    }
-                    else if (w4 == 1) { if (p.rfx) SP9_W4_LAUNCH(2, true, 1); else SP9_W4_LAUNCH(2, false, 1); }
+                    if (w4) { if (p.rfx) SP9_W4_LAUNCH(2, true, 1); else SP9_W4_LAUNCH(2, false, 1); }
                     else if (p.rfx) { if (agl >= 4) SP9_AG_LAUNCH(true, 4); else if (agl == 3) SP9_AG_LAUNCH(true, 3); else if (agl == 2) SP9_AG_LAUNCH(true, 2); else SP9_AG_LAUNCH(true, 1); }
                     else { if (agl >= 4) SP9_AG_LAUNCH(false, 4); else if (agl == 3) SP9_AG_LAUNCH(false, 3); else if (agl == 2) SP9_AG_LAUNCH(false, 2); else SP9_AG_LAUNCH(false, 1); }
 #undef SP9_AG_LAUNCH

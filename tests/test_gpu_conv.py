@@ -34,9 +34,9 @@ CONV_CASES = {
     "RFX_17x9":             (2, 64, 17, 9, 64, 3, 1, (1, 1, 1, 1), "reflect"),
     "RFX_4x4_min":          (5, 64, 4, 4, 96, 3, 1, (1, 1, 1, 1), "reflect"),
     "odd_s2":               (3, 9, 11, 10, 33, 3, 2, (1, 1, 1, 1), "zeros"),
-    # whole-row tiles of the 128-row software-pipelined kernel (wide patch staging): zero padding, and a one-group row
-    "WP_zero_16":           (2, 128, 16, 16, 256, 3, 1, (1, 1, 1, 1), "zeros"),
-    "WP_12x8":              (2, 64, 12, 8, 128, 3, 1, (1, 1, 1, 1), "reflect"),
+    # the 128-row software-pipelined kernel (four reduction quarters) with zero padding, and on a narrow 12x8 plane
+    "SP128_zero_16":        (2, 128, 16, 16, 256, 3, 1, (1, 1, 1, 1), "zeros"),
+    "SP128_12x8":           (2, 64, 12, 8, 128, 3, 1, (1, 1, 1, 1), "reflect"),
 }
 # name: (N, Ci, H, W, Co, R, stride, pad, outpad)
 CONVT_CASES = {
