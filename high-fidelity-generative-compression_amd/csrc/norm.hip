@@ -269,94 +269,6 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict
     }
 }
 
-// Forward twin of cn_bwd_v8_kernel (below): a lane owns 8 consecutive pixels of a channel (16-byte load / store), 256 threads
-// own all channels of one 8-pixel group; the per-pixel mean and variance cross lanes (butterfly + one LDS hop).
-template <int CPT>
-__global__ __launch_bounds__(256) void cn_fwd_v8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                        int C, int HW, float eps, int relu, int remap) {
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    __shared__ float red[2][4][8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bx, n;
-    cn_block_remap(bx, n, remap);
-    const int hw0 = bx * 8;
-    const size_t img = (size_t)n * C * HW + hw0;
-    u32x4_t xr[CPT];
-    float gm[CPT], bt[CPT];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int c = tid + 256 * k; const int ci = c < C ? c : C - 1;
-        xr[k] = *(const u32x4_t*)(x + img + (size_t)ci * HW);
-        gm[k] = gamma[ci]; bt[k] = beta[ci];
-    }
-    float v[CPT][8], s[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = 0.f;
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const bool okc = tid + 256 * k < C;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned xw = xr[k][j >> 1];
-            v[k][j] = __uint_as_float((j & 1) ? (xw & 0xffff0000u) : (xw << 16));
-            s[j] += okc ? v[k][j] : 0.f;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s[j] += __shfl_xor(s[j], m);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[0][wave][j] = s[j];
-    }
-    __syncthreads();
-    float mu[8], q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        mu[j] = ((red[0][0][j] + red[0][1][j]) + (red[0][2][j] + red[0][3][j])) / (float)C;
-        q[j] = 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const bool okc = tid + 256 * k < C;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mu[j]; v[k][j] = d; q[j] += okc ? d * d : 0.f; }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) q[j] += __shfl_xor(q[j], m);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[1][wave][j] = q[j];
-    }
-    __syncthreads();
-    float r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        r[j] = rsqrtf(((red[1][0][j] + red[1][1][j]) + (red[1][2][j] + red[1][3][j])) / (float)(C - 1) + eps);
-    if (tid < 8) { mean_out[(size_t)n * HW + hw0 + tid] = mu[tid]; rstd_out[(size_t)n * HW + hw0 + tid] = r[tid]; }
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int c = tid + 256 * k;
-        if (c < C) {
-            u32x4_t o;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                float a = gm[k] * (v[k][j] * r[j]) + bt[k], b = gm[k] * (v[k][j + 1] * r[j + 1]) + bt[k];
-                if (relu) { a = a > 0.f ? a : 0.f; b = b > 0.f ? b : 0.f; }
-                o[j >> 1] = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
-            }
-            *(u32x4_t*)(y + img + (size_t)c * HW) = o;
-        }
-    }
-}
-
 // Exact-index chain: the norm between two split-bf16 convolutions.  Input = the float32 output z of
 // the exact convolution; from the float32 result y = relu?(gamma * (z - mu) * rstd + beta) it writes
 //   y   bf16 [N,C,HW]   - the NOMINAL activation: what the (plain bf16) backward pass of the next layer reads,
@@ -522,6 +434,8 @@ __global__ __launch_bounds__(NW * 64) void cn_bwd_reg_kernel(const T* __restrict
 // group: the per-channel sums (dgamma, dbeta, producer bias) stay in the thread, only the 2 x 8 per-pixel sums over the
 // channels cross lanes (DPP/permute butterfly + one LDS hop between the four waves).  bf16, HW % 8 == 0.
 // part[] layout as cn_bwd_reg_kernel with PXB = 8, pit = 1 (same workspace size, same column-sum pass).
+// Measured (round 3, 16 x 960 x 16x16): 25.2 -> 15.4 us.  (The same lane mapping for the FORWARD kernel - two block-wide
+// reductions of 8 values instead of one pass per pixel column - ran 10.5 us against cn_fwd_reg_kernel's 7.5 and was dropped.)
 template <int CPT, bool DB>
 __global__ __launch_bounds__(256) void cn_bwd_v8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -695,17 +609,6 @@ int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, 
     CnCfg cfg;
     if (cn_pick(N, C, HW, cfg)) {
         dim3 rgrid(cdiv(HW, cfg.pxb), N);
-        // narrowest pixel runs (C > 512 on small planes): the 16-byte-per-lane kernel (cn_fwd_v8_kernel)
-        static const int v8 = getenv("HIFIC_CN_FWD_V8") ? atoi(getenv("HIFIC_CN_FWD_V8")) : 1;
-        if (v8 && dtype == HIFIC_BF16 && cfg.pxb == 16 && HW % 8 == 0 && C <= 1024 &&
-            (((size_t)x | (size_t)y | (size_t)mean | (size_t)rstd) & 15) == 0) {
-            dim3 vgrid(HW / 8, N);
-            if (C <= 768) hipLaunchKernelGGL((cn_fwd_v8_kernel<3>), vgrid, dim3(256), 0, st, (const bf16_t*)x, gamma, beta,
-                                             (bf16_t*)y, mean, rstd, C, HW, eps, relu, cn_remap_flag(1));
-            else hipLaunchKernelGGL((cn_fwd_v8_kernel<4>), vgrid, dim3(256), 0, st, (const bf16_t*)x, gamma, beta,
-                                    (bf16_t*)y, mean, rstd, C, HW, eps, relu, cn_remap_flag(1));
-            return hific_launch_status();
-        }
 #define CN_FWD_R(TT, PXB, NWV, CPT) hipLaunchKernelGGL((cn_fwd_reg_kernel<TT, PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, \
                                            (const TT*)x, gamma, beta, (TT*)y, mean, rstd, C, HW, eps, relu, cn_remap_flag(1))
 #define CN_FWD_C(TT, CPT)                                                                     \
