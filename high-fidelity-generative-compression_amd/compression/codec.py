@@ -39,6 +39,17 @@ def _tab(t):
     return f(t.CDF).astype(np.uint32), f(t.CDF_length).astype(np.int32), f(t.CDF_offset).astype(np.int32)
 
 
+def _decoded(encoded, idx, cdf, cl, co, coding_shape, precision, vectorize, block, device):
+    """rANS-decode to a tensor on `device`.  The vectorised coder hands back its [steps][lanes] array and the layout change
+    to (N,C,H,W) is done where the tensor is going to live (rans.ans_decompress `device`)."""
+    if vectorize:
+        return rans.ans_decompress(encoded, idx, cdf, cl, co, coding_shape, precision, vectorize=True, block_decode=block,
+                                   device=device)
+    idx = idx.detach().cpu().numpy() if isinstance(idx, torch.Tensor) else np.asarray(idx)
+    sym = rans.ans_decompress(encoded, idx, cdf, cl, co, coding_shape, precision, vectorize=False, block_decode=block)
+    return torch.from_numpy(np.asarray(sym)).to(device)
+
+
 def compress_forward(latents, spatial_shape, nets, hyper_tables, prior_tables, scale_table, symbol_fns,
                      vectorize=True, block_encode=True, precision=PRECISION, scale_lower_bound=SCALE_LOWER_BOUND,
                      bits_fn=None):
@@ -55,9 +66,8 @@ def compress_forward(latents, spatial_shape, nets, hyper_tables, prior_tables, s
     hyp_enc, hyper_coding_shape = rans.ans_compress(sym, idx, cdf, cl, co, tuple(sym.shape[1:]), precision,
                                                     vectorize=vectorize, block_encode=block_encode)
     # the encoder continues from what the decoder will see (hyperprior.py:211-215)
-    hyp_sym = rans.ans_decompress(hyp_enc, idx, cdf, cl, co, hyper_coding_shape, precision, vectorize=vectorize,
-                                  block_decode=block_encode)
-    hyperlatents_decoded = torch.from_numpy(np.asarray(hyp_sym)).to(latents.dtype).to(latents.device)
+    hyperlatents_decoded = _decoded(hyp_enc, idx, cdf, cl, co, hyper_coding_shape, precision, vectorize, block_encode,
+                                    latents.device).to(latents.dtype)
     means = nets.synthesis_mu(hyperlatents_decoded)
     scales = torch.clamp(nets.synthesis_std(hyperlatents_decoded), min=scale_lower_bound)    # LowerBoundToward fwd
     sym, idx = symbol_fns.prior(latents, means, scales, scale_table)
@@ -89,15 +99,12 @@ def decompress_forward(compression_output, nets, hyper_tables, prior_tables, sca
     idx = np.ascontiguousarray(np.broadcast_to(np.arange(n_hyper_channels, dtype=np.int32).reshape(1, -1, 1, 1),
                                                (B, n_hyper_channels, Hh, Wh)))                # hyperprior_model.py:135-139
     cdf, cl, co = _tab(hyper_tables)
-    hyp_sym = rans.ans_decompress(co_.hyperlatents_encoded, idx, cdf, cl, co, tuple(co_.hyper_coding_shape), precision,
-                                  vectorize=vectorize, block_decode=block_decode)
-    hyperlatents_decoded = torch.from_numpy(np.asarray(hyp_sym)).to(dtype).to(device)
+    hyperlatents_decoded = _decoded(co_.hyperlatents_encoded, idx, cdf, cl, co, tuple(co_.hyper_coding_shape), precision,
+                                    vectorize, block_decode, device).to(dtype)
     means = nets.synthesis_mu(hyperlatents_decoded)
     scales = torch.clamp(nets.synthesis_std(hyperlatents_decoded), min=scale_lower_bound)
     idx = symbol_fns.prior_indices(scales, scale_table)
-    idx = idx.detach().cpu().numpy() if isinstance(idx, torch.Tensor) else np.asarray(idx)
     cdf, cl, co = _tab(prior_tables)
-    lat_sym = rans.ans_decompress(co_.latents_encoded, idx, cdf, cl, co, tuple(co_.latent_coding_shape), precision,
-                                  vectorize=vectorize, block_decode=block_decode)
-    symbols = torch.from_numpy(np.asarray(lat_sym)).to(means.dtype).to(means.device)
+    symbols = _decoded(co_.latents_encoded, idx, cdf, cl, co, tuple(co_.latent_coding_shape), precision, vectorize,
+                       block_decode, means.device).to(means.dtype)
     return symbols + means                                                                     # dequantize, :246

@@ -66,11 +66,28 @@ def _check(rc, what):
 
 def _steps_layout(x):
     """The reference's vectorisation: batch 1 -> one step per (h, w) patch with the C channels as lanes
-    (`compression_utils.decompose`, PATCH_SIZE (1,1)); batch > 1 -> one step per batch element, C*H*W lanes."""
+    (`compression_utils.decompose`, PATCH_SIZE (1,1)); batch > 1 -> one step per batch element, C*H*W lanes.
+    -> (int32 [steps][lanes] ndarray, steps, lanes).  A tensor that lives on the GPU (what the device symbol kernels
+    hand over) is laid out there, before the copy to the host: the (C, H*W) -> (H*W, C) transpose of a megapixel
+    image's 900k symbols costs the host 1.2 ms per tensor and the device nothing."""
     B, C, H, W = x.shape
-    if B == 1:
-        return np.ascontiguousarray(x[0].reshape(C, H * W).T), H * W, C
-    return np.ascontiguousarray(x.reshape(B, -1)), B, C * H * W
+    if isinstance(x, torch.Tensor):
+        x = x.detach().to(torch.int32)
+        y = x[0].reshape(C, H * W).t().contiguous() if B == 1 else x.reshape(B, -1).contiguous()
+        y = y.cpu().numpy()
+    elif B == 1:
+        y = np.ascontiguousarray(x[0].reshape(C, H * W).T)
+    else:
+        y = np.ascontiguousarray(x.reshape(B, -1))
+    return (y, H * W, C) if B == 1 else (y, B, C * H * W)
+
+
+def _sym_idx(symbols, indices):
+    """Shape checks without forcing device tensors through the host twice."""
+    if tuple(symbols.shape) != tuple(indices.shape) or len(symbols.shape) != 4:
+        raise RansError("symbols and indices must be equally shaped (N,C,H,W) tensors")
+    f = lambda a: a if isinstance(a, torch.Tensor) and a.is_cuda else _np(a, np.int32)
+    return f(symbols), f(indices)
 
 
 def _encode_scalar(sym, idx, cdf, cl, co, precision):
@@ -79,20 +96,19 @@ def _encode_scalar(sym, idx, cdf, cl, co, precision):
     need = ctypes.c_longlong(0)
     args = (sym.ctypes.data, idx.ctypes.data, sym.size, cdf.ctypes.data, cdf.shape[0], cdf.shape[1], cl.ctypes.data,
             co.ctypes.data, int(precision))
-    rc = lib.hific_rans_encode(*args, None, 0, ctypes.byref(need))
-    if rc != -7:
-        _check(rc, "hific_rans_encode")
-    out = np.empty(need.value, dtype=np.uint32)
-    _check(lib.hific_rans_encode(*args, out.ctypes.data, out.size, ctypes.byref(need)), "hific_rans_encode")
-    return out
+    out = np.empty(2 + (sym.size * int(precision) + 31) // 32 + sym.size // 8 + 1024, dtype=np.uint32)   # see ans_compress
+    rc = lib.hific_rans_encode(*args, out.ctypes.data, out.size, ctypes.byref(need))
+    if rc == -7:
+        out = np.empty(need.value, dtype=np.uint32)
+        rc = lib.hific_rans_encode(*args, out.ctypes.data, out.size, ctypes.byref(need))
+    _check(rc, "hific_rans_encode")
+    return out[:need.value].copy()
 
 
 def ans_compress(symbols, indices, cdf, cdf_length, cdf_offset, coding_shape, precision, vectorize=False,
                  block_encode=True):
-    sym, idx = _np(symbols, np.int32), _np(indices, np.int32)
+    sym, idx = _sym_idx(symbols, indices)
     cdf, cl, co = _tables_np(cdf, cdf_length, cdf_offset)
-    if sym.shape != idx.shape or sym.ndim != 4:
-        raise RansError("symbols and indices must be equally shaped (N,C,H,W) tensors")
     if vectorize:
         lib = _lib()
         s, T, L = _steps_layout(sym)
@@ -100,32 +116,44 @@ def ans_compress(symbols, indices, cdf, cdf_length, cdf_offset, coding_shape, pr
         need = ctypes.c_longlong(0)
         args = (s.ctypes.data, i.ctypes.data, T, L, cdf.ctypes.data, cdf.shape[0], cdf.shape[1], cl.ctypes.data,
                 co.ctypes.data, int(precision))
-        rc = lib.hific_rans_encode_vec(*args, None, 0, ctypes.byref(need))
-        if rc != -7:
-            _check(rc, "hific_rans_encode_vec")
-        out = np.empty(need.value, dtype=np.uint32)
-        _check(lib.hific_rans_encode_vec(*args, out.ctypes.data, out.size, ctypes.byref(need)), "hific_rans_encode_vec")
-        shape = (sym.shape[1],) + PATCH_SIZE if sym.shape[0] == 1 else tuple(coding_shape)
+        # one pass in the usual case: a symbol costs at most `precision` bits of 32-bit words, overflow nibbles are rare;
+        # the coder reports the exact size when the guess is too small (-7) and is then called again
+        out = np.empty(2 * L + (T * L * int(precision) + 31) // 32 + T * L // 8 + 1024, dtype=np.uint32)
+        rc = lib.hific_rans_encode_vec(*args, out.ctypes.data, out.size, ctypes.byref(need))
+        if rc == -7:
+            out = np.empty(need.value, dtype=np.uint32)
+            rc = lib.hific_rans_encode_vec(*args, out.ctypes.data, out.size, ctypes.byref(need))
+        _check(rc, "hific_rans_encode_vec")
+        out = out[:need.value].copy()
+        shape = (int(sym.shape[1]),) + PATCH_SIZE if sym.shape[0] == 1 else tuple(coding_shape)
         return out, shape
+    sym, idx = _np(sym, np.int32), _np(idx, np.int32)
     if block_encode:
         return _encode_scalar(sym, idx, cdf, cl, co, precision), tuple(sym.shape[1:])
     return [(_encode_scalar(sym[b], idx[b], cdf, cl, co, precision), tuple(sym.shape[2:])) for b in range(sym.shape[0])]
 
 
 def ans_decompress(encoded, indices, cdf, cdf_length, cdf_offset, coding_shape, precision, vectorize=False,
-                   block_decode=True):
-    idx = _np(indices, np.int32)
+                   block_decode=True, device=None):
+    """`device` (extension, vectorised path): return the symbols as an int32 torch tensor on that device instead of a
+    numpy array - the [steps][lanes] -> (N,C,H,W) transpose then happens after the upload."""
     cdf, cl, co = _tables_np(cdf, cdf_length, cdf_offset)
     lib = _lib()
     if vectorize:
         enc = _np(encoded, np.uint32)
-        i, T, L = _steps_layout(idx)
+        if len(indices.shape) != 4:
+            raise RansError("indices must be an (N,C,H,W) tensor")
+        B, C, H, W = (int(d) for d in indices.shape)
+        i, T, L = _steps_layout(indices if isinstance(indices, torch.Tensor) and indices.is_cuda else _np(indices, np.int32))
         out = np.empty(T * L, dtype=np.int32)
         _check(lib.hific_rans_decode_vec(enc.ctypes.data, enc.size, i.ctypes.data, T, L, cdf.ctypes.data, cdf.shape[0],
                                          cdf.shape[1], cl.ctypes.data, co.ctypes.data, int(precision),
                                          out.ctypes.data), "hific_rans_decode_vec")
-        B, C, H, W = idx.shape
-        return out.reshape(H * W, C).T.reshape(1, C, H, W).copy() if B == 1 else out.reshape(idx.shape)
+        if device is not None:
+            t = torch.from_numpy(out).to(device)
+            return t.reshape(H * W, C).t().reshape(1, C, H, W).contiguous() if B == 1 else t.reshape(B, C, H, W)
+        return out.reshape(H * W, C).T.reshape(1, C, H, W).copy() if B == 1 else out.reshape(B, C, H, W)
+    idx = _np(indices, np.int32)
 
     def scalar(enc, ind):
         enc = _np(enc, np.uint32)

@@ -1,6 +1,7 @@
 """GPU parity of the HBM-bound kernels (norm / entropy model / LPIPS taps / pooling / losses / Adam / spectral norm)
 against torch CPU float32 restatements of the reference ops (oracle/hific_oracle.py primitives)."""
 import math
+import os
 
 import pytest
 import torch
@@ -421,3 +422,24 @@ def test_compress_symbols_and_indices_bit_exact(hific, dev):
     torch.cuda.synchronize()
     s_o, i_o = O.hyper_symbols_and_indices(z)
     assert torch.equal(sym.cpu(), s_o) and torch.equal(idx.cpu(), i_o)
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 6, 5), (3, 8, 4, 4)])
+def test_vectorised_coder_takes_device_tensors(hific, dev, shape):
+    """compression.rans lays device tensors out on the device ((N,C,H,W) -> [steps][lanes]) and, with `device=...`, undoes it
+    after the upload: bitstream and decoded symbols equal the all-host path's, for the batch-1 (steps = pixels) and the
+    batch > 1 (steps = images) layouts."""
+    import numpy as np
+    from hific_amd.compression import rans
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tables_golden.npz"))
+    cdf, cl, co = g["prior_CDF"].astype(np.uint32), g["prior_CDF_length"].astype(np.int32), g["prior_CDF_offset"].astype(np.int32)
+    gen = torch.Generator().manual_seed(3)
+    idx = torch.randint(0, cdf.shape[0], shape, generator=gen, dtype=torch.int32)
+    sym = torch.round(torch.randn(shape, generator=gen) * 2).to(torch.int32)
+    enc_h, cs_h = rans.ans_compress(sym.numpy(), idx.numpy(), cdf, cl, co, shape[1:], 16, vectorize=True)
+    enc_d, cs_d = rans.ans_compress(sym.to(dev), idx.to(dev), cdf, cl, co, shape[1:], 16, vectorize=True)
+    assert tuple(cs_h) == tuple(cs_d) and np.array_equal(enc_h, enc_d)
+    dec_h = rans.ans_decompress(enc_h, idx.numpy(), cdf, cl, co, cs_h, 16, vectorize=True)
+    dec_d = rans.ans_decompress(enc_d, idx.to(dev), cdf, cl, co, cs_d, 16, vectorize=True, device=dev)
+    assert isinstance(dec_d, torch.Tensor) and dec_d.is_cuda and dec_d.dtype == torch.int32
+    assert tuple(dec_d.shape) == shape and np.array_equal(dec_d.cpu().numpy(), dec_h)

@@ -146,3 +146,25 @@ def test_hfc_container_bytes_equal_reference(tmp_path):
     assert open(ours, "rb").read() == open(theirs, "rb").read()
     back = cu.load_compressed_format(ours)                      # the reference reads what we write
     assert np.array_equal(back.latents_encoded, co.latents_encoded) and back.latent_coding_shape == (220, 1, 1)
+
+
+def test_vectorised_coder_accepts_torch_tensors_and_returns_on_device(rans, tabs):
+    """The vectorised coder takes torch tensors (the device symbol kernels' outputs) and, with `device=...`, returns a tensor:
+    same bitstream and symbols as the numpy path, for both step layouts (batch 1: steps = pixels; batch > 1: steps = images).
+    (The CUDA flavour of the same check is tests/test_gpu_elementwise.py::test_vectorised_coder_takes_device_tensors.)"""
+    import torch
+    cdf, cl, co = tabs["prior"]
+    for shape in ((1, 24, 6, 5), (3, 8, 4, 4)):
+        gen = torch.Generator().manual_seed(3)
+        idx = torch.randint(0, cdf.shape[0], shape, generator=gen, dtype=torch.int32)
+        sym = torch.round(torch.randn(shape, generator=gen) * 2).to(torch.int32)
+        enc_n, cs_n = rans.ans_compress(sym.numpy(), idx.numpy(), cdf, cl, co, shape[1:], 16, vectorize=True)
+        enc_t, cs_t = rans.ans_compress(sym, idx, cdf, cl, co, shape[1:], 16, vectorize=True)
+        assert tuple(cs_n) == tuple(cs_t) and np.array_equal(enc_n, enc_t)
+        a, _, _ = rans._steps_layout(sym)
+        b, _, _ = rans._steps_layout(sym.numpy())
+        assert np.array_equal(a, b)
+        dec_n = rans.ans_decompress(enc_n, idx.numpy(), cdf, cl, co, cs_n, 16, vectorize=True)
+        dec_t = rans.ans_decompress(enc_n, idx, cdf, cl, co, cs_n, 16, vectorize=True, device="cpu")
+        assert isinstance(dec_t, torch.Tensor) and tuple(dec_t.shape) == shape
+        assert np.array_equal(dec_t.numpy(), dec_n) and np.array_equal(dec_n, sym.numpy())
