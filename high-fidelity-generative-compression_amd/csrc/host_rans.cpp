@@ -21,30 +21,29 @@ inline bool check_tables(const int32_t* indices, long long n, int rows, int stri
     for (long long i = 0; i < n; ++i) if (indices[i] < 0 || indices[i] >= rows) return false;
     return true;
 }
-// Exact h / f for the coder's operands (h < 2^63, 1 <= f <= 2^24) without a divide instruction: with m = floor(2^64 / f) + 1
+// Exact h / f for the coder's operands (h < 2^63, 2 <= f <= 2^16) without a divide instruction: with m = floor(2^64 / f) + 1
 // the estimate q' = floor(h * m / 2^64) satisfies q <= q' <= q + 1 (the error term h * (m - 2^64/f) / 2^64 is below 1/2), so
-// one multiply-high, one multiply and a compare give the quotient and the remainder.  f = 1 has no 64-bit m and is handled
-// by the caller.  The table covers every frequency a `precision`-bit cdf can hold and is built once per process.
+// one multiply-high, one multiply and a compare give the quotient and the remainder.  The table covers every frequency a
+// 16-bit cdf (the reference's PRECISION_P) can hold and is built once per process; wider cdfs use the divide instruction.
 struct Recip {
     std::vector<uint64_t> m;
-    explicit Recip(size_t n) : m(n + 1, 0) {
-        for (size_t f = 2; f <= n; ++f) m[f] = (uint64_t)((((unsigned __int128)1) << 64) / f) + 1;
+    Recip() : m(((size_t)1 << 16) + 1, 0) {
+        for (size_t f = 2; f < m.size(); ++f) m[f] = (uint64_t)((((unsigned __int128)1) << 64) / f) + 1;
     }
 };
 inline const uint64_t* recip_table(int precision) {
-    static const Recip r16((size_t)1 << 16);
-    if (precision <= 16) return r16.m.data();
-    static const Recip r24((size_t)1 << 24);
-    return r24.m.data();
+    if (precision > 16) return nullptr;
+    static const Recip r;
+    return r.m.data();
 }
 inline void divmod(uint64_t h, uint64_t f, const uint64_t* rcp, uint64_t& q, uint64_t& r) {
     if (f == 1) { q = h; r = 0; return; }
+    if (!rcp) { q = h / f; r = h % f; return; }
     uint64_t qq = (uint64_t)(((unsigned __int128)h * rcp[f]) >> 64);
     uint64_t p = qq * f;
     if (p > h) { --qq; p -= f; }
     q = qq; r = h - p;
 }
-
 // Symbol search of the decoders: hint[row][cf >> (precision - 8)] = searchsorted(c[:len], bucket start, 'right') - 1,
 // clamped to >= 0 - a position that is never past the answer, so a short walk from it ends at the same symbol as the
 // reference's binary search (ans.py:80).

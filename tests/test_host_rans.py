@@ -168,3 +168,30 @@ def test_vectorised_coder_accepts_torch_tensors_and_returns_on_device(rans, tabs
         dec_t = rans.ans_decompress(enc_n, idx, cdf, cl, co, cs_n, 16, vectorize=True, device="cpu")
         assert isinstance(dec_t, torch.Tensor) and tuple(dec_t.shape) == shape
         assert np.array_equal(dec_t.numpy(), dec_n) and np.array_equal(dec_n, sym.numpy())
+
+
+@pytest.mark.parametrize("precision", [8, 12, 16, 20, 24])
+def test_synthetic_tables_all_precisions_and_both_symbol_searches(rans, precision):
+    """Random cdf tables at every supported precision: the scalar coder is lossless for any int32 symbol, the vectorised one
+    for in-range symbols; a long message (table-guided symbol search in the decoders) and a short one (binary search) decode
+    to the same symbols; > 16 bits of precision takes the divide instruction instead of the reciprocal table."""
+    rng = np.random.default_rng(precision)
+    rows, maxlen = 12, min(90, (1 << precision) // 4)
+    stride = maxlen + 2
+    cdf = np.zeros((rows, stride), np.uint32); cl = np.zeros(rows, np.int32)
+    co = rng.integers(-9, 3, rows).astype(np.int32)
+    for r in range(rows):
+        n = int(rng.integers(3, maxlen + 1))
+        w = rng.integers(1, 40, n).astype(np.float64)
+        f = np.maximum(1, np.floor(w / w.sum() * (1 << precision))).astype(np.int64)
+        f[np.argmax(f)] += (1 << precision) - f.sum()
+        cdf[r, :n + 1] = np.concatenate([[0], np.cumsum(f)]); cl[r] = n + 1
+    for shape in ((1, 7, 3, 4), (1, 40, 12, 12), (2, 9, 5, 5)):       # 84 / 5760 / 450 symbols
+        idx = rng.integers(0, rows, shape).astype(np.int32)
+        wild = np.round(rng.normal(0, 300, shape)).astype(np.int32)               # mostly out of range: overflow codes
+        enc, cs = rans.ans_compress(wild, idx, cdf, cl, co, shape[1:], precision, vectorize=False)
+        assert np.array_equal(rans.ans_decompress(enc, idx, cdf, cl, co, cs, precision, vectorize=False), wild)
+        inr = (co[idx] + rng.integers(0, 1 << 30, shape) % np.maximum(cl[idx] - 2, 1)).astype(np.int32)   # inside the table
+        for vec in (False, True):
+            enc, cs = rans.ans_compress(inr, idx, cdf, cl, co, shape[1:], precision, vectorize=vec)
+            assert np.array_equal(rans.ans_decompress(enc, idx, cdf, cl, co, cs, precision, vectorize=vec), inr), (shape, vec)
