@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=1)
-    ap.add_argument("--cpu-timeout", type=int, default=270)
+    ap.add_argument("--cpu-timeout", type=int, default=120)
     ap.add_argument("--regime", default="low", choices=["low", "med", "high"])
     ap.add_argument("--no-parity", action="store_true", help="skip the in-process oracle comparison")
     ap.add_argument("--seed", type=int, default=0)
@@ -143,15 +143,21 @@ def make_step(args, model, opts, reducers, dev, config):
     return step
 
 
-def graphed(args, step, world, force=False):
-    """The step as one hipGraph replay (hific_amd.graph.GraphedStep).  Measured (round 3, ROCm 7.2): the capture is
-    bit-identical to eager execution, but hipGraphLaunch of the ~1000-node cycle costs the host 21.6 ms per replay against
-    24.4 ms of eager enqueue, and the cycle is GPU-bound either way (29.8 vs 29.5 ms): eager stays the default for the
-    headline, HIFIC_BENCH_GRAPH=1 switches it, and the `graph` extras leg reports the replayed cycle next to it."""
-    flag = os.environ.get("HIFIC_BENCH_GRAPH", "")
-    if flag != "1" and not force:
+def graphed(args, step, world, force=False, single_stream=True):
+    """The step as one hipGraph replay (hific_amd.graph.GraphedStep).  Round 4 (tools/host_floor_probe.py,
+    profiles/r04_host_floor.md): hipGraphLaunch takes ROCm's packet-replay path only for a graph captured on ONE stream -
+    0.3 ms of host time per cycle; with the side / branch streams in the capture it walks the ~1000 nodes at 19 us each
+    (18.8 ms, what round 3 measured).  So the step is captured single-stream (same kernels, same order: bit-identical,
+    tests/test_gpu_zz_graph.py) and choose_launch() below times it against eager multi-stream launching."""
+    flag = os.environ.get("HIFIC_BENCH_GRAPH", "auto")
+    if flag == "0" and not force:
         return step, False
+    from hific_amd import ops
     from hific_amd.graph import GraphedStep
+    side_was, branch_was = ops._SIDE_ON, ops.branch_streams_on()
+    if single_stream:
+        ops.set_side_stream(False)
+        ops.set_branch_streams(False)
     try:
         return GraphedStep(step, warmup=max(2, args.warmup), generators=step.generators), True
     except Exception as e:                    # a capture failure must not cost the measurement
@@ -161,8 +167,37 @@ def graphed(args, step, world, force=False):
         if world > 1:
             raise
         os.environ["HIFIC_BENCH_GRAPH"] = "0"
-        os.environ["HIFIC_BENCH_NO_GRAPH_LEG"] = "1"
         os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    finally:
+        ops.set_side_stream(side_was)
+        ops.set_branch_streams(branch_was)
+
+
+def choose_launch(args, step, world, fence, ncal=4):
+    """How the timed cycles are launched: eager (one launch per kernel from Python, weight gradients / loss branch on side
+    streams) or one single-stream hipGraph replay per cycle.  Both run the same kernels on the same data and leave the same
+    state; which is faster depends on whether the host (eager: ~22 ms of enqueueing per cycle) or the serialised kernel
+    sum (graph) binds.  `auto` (default at one rank) times `ncal` untimed cycles of each and takes the faster one; the
+    calibration is reported in the line.  HIFIC_BENCH_GRAPH=0 / 1 forces eager / graph.  Multi-rank runs launch eagerly:
+    the bucketed all-reduce lives on its own stream."""
+    flag = os.environ.get("HIFIC_BENCH_GRAPH", "auto")
+    if world > 1 or flag == "0":
+        return step, False, None
+    gstep, ok = graphed(args, step, world, force=True)
+    if not ok:
+        return step, False, None
+    cal = {}
+    for name, fn in (("eager_multi_stream", step), ("graph_single_stream", gstep)):
+        fn(); fence(); t0 = time.perf_counter()
+        for _ in range(ncal):
+            fn()
+        th = time.perf_counter() - t0
+        fence(); te = time.perf_counter() - t0
+        cal[name] = {"ms_per_step": round(te / ncal * 1e3, 3), "host_ms_per_step": round(th / ncal * 1e3, 3)}
+    use_graph = flag == "1" or cal["graph_single_stream"]["ms_per_step"] <= cal["eager_multi_stream"]["ms_per_step"]
+    cal["chosen"] = "graph_single_stream" if use_graph else "eager_multi_stream"
+    cal["how"] = f"{ncal} untimed cycles of each launch mode after the warm-up, same model state; faster one runs the timed region"
+    return (gstep if use_graph else step), use_graph, cal
 
 
 def timed(step, steps, warmup, fence):
@@ -371,6 +406,7 @@ def _cpu_reference_worker(size, B, steps, thread_counts, gan, fwd_batch):
         res["best_threads"], res["images_per_s"] = int(best), res["per_threads"][best]
         print(json.dumps(res), flush=True)
 
+    samples = {}
     for i, th in enumerate(thread_counts):
         torch.set_num_threads(th)
         if i == 0:
@@ -378,6 +414,7 @@ def _cpu_reference_worker(size, B, steps, thread_counts, gan, fwd_batch):
         ts = []
         for _ in range(steps):
             t0 = time.time(); cycle(); ts.append(time.time() - t0)
+        samples[th] = ts
         t = sorted(ts)[len(ts) // 2]
         res["per_threads"][str(th)] = round(B * (2 if gan else 1) / t, 4)
         emit()
@@ -387,6 +424,19 @@ def _cpu_reference_worker(size, B, steps, thread_counts, gan, fwd_batch):
                 model(x)
                 t0 = time.time(); model(x); res["fwd_s"], res["fwd_threads"] = round(time.time() - t0, 3), th
             emit()
+    # at least three timed samples at the best thread count; the value is their median
+    # (the leader can change as its median settles: keep sampling whichever count leads until the leader has three)
+    while True:
+        best = int(max(res["per_threads"], key=lambda k: res["per_threads"][k]))
+        ts = samples[best]
+        if len(ts) >= 3:
+            break
+        torch.set_num_threads(best)
+        t0 = time.time(); cycle(); ts.append(time.time() - t0)
+        t = sorted(ts)[len(ts) // 2] if len(ts) % 2 else 0.5 * (sorted(ts)[len(ts) // 2 - 1] + sorted(ts)[len(ts) // 2])
+        res["per_threads"][str(best)] = round(B * (2 if gan else 1) / t, 4)
+    res["samples_at_best"] = [round(B * (2 if gan else 1) / v, 4) for v in samples[best]]
+    emit()
     shutil.rmtree(root, ignore_errors=True)
 
 
@@ -394,7 +444,7 @@ def cpu_baseline(args):
     """the reference modules on this box's host cores - in a child process with a hard time limit so
     the GPU line can never be lost to it.  kind "reference" (the reference's own src.model.Model, from oracle/_ref) or, when
     that archive did not travel, "port" (the oracle restatement).  Bounded sample: batch 4 (BASELINE configs[0]), one
-    warm-up + `--cpu-steps` timed G-D cycles per thread count (all logical cores, half of them, 32)."""
+    warm-up + `--cpu-steps` timed G-D cycles at 32 / 64 / physical-core threads, then 3 samples at the best count (median)."""
     ncores = os.cpu_count() or 1
     gan = args.config == "gan"
     what = "compression_gan G-turn + D-turn cycle" if gan else "compression training step"
@@ -404,14 +454,21 @@ def cpu_baseline(args):
         # the usual optimum (32) first, then half and ALL logical cores (SURVEY section 8d asks for the latter; on the 256-thread
         # EPYC box 128 threads are 3x SLOWER than 32 and one 256-thread cycle does not finish in 3 minutes - torch's CPU
         # kernels oversubscribe - so whatever the time limit cuts off is reported as absent)
-        ths = [min(ncores, 32)] + [t for t in (max(1, ncores // 2), ncores) if t > 32]
+        # 32 (the usual optimum), 64, and one thread per PHYSICAL core.  All logical cores (256 on the EPYC 9575F box) never
+        # finished one cycle inside the time limit in rounds 2-3 (torch's CPU kernels oversubscribe) and is not attempted.
+        try:
+            import psutil
+            phys = psutil.cpu_count(logical=False) or max(1, ncores // 2)
+        except Exception:
+            phys = max(1, ncores // 2)
+        ths = sorted({min(ncores, 32), min(ncores, 64), min(ncores, phys)})
         cmd = [sys.executable, "-c",
                f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
                f"bench._cpu_reference_worker({args.size}, {args.cpu_batch}, {args.cpu_steps}, {ths}, {gan}, 10)"]
         sample = (f"reference modules (src.model.Model from oracle/_ref, torch CPU float32) {what} as train.py:119-141 runs "
                   f"it (fwd + bwd + 3x torch.optim.Adam), batch {args.cpu_batch} per turn (BASELINE configs[0] batch), "
-                  f"{args.size}x{args.size}, 1 warm-up, then {args.cpu_steps} timed (median) at each of {ths} threads of "
-                  f"{ncores} logical cores; value = best")
+                  f"{args.size}x{args.size}, 1 warm-up, then {args.cpu_steps} timed at each of {ths} threads ({phys} physical / "
+                  f"{ncores} logical cores), then the best count re-timed to 3 samples; value = their median")
         try:
             try:
                 stdout = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_timeout).stdout
@@ -421,7 +478,8 @@ def cpu_baseline(args):
             r = json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
             out = {"value": r["images_per_s"], "unit": "images/s", "cores": r["best_threads"], "kind": "reference",
                    "sample": sample, "images_per_s_by_threads": r["per_threads"],
-                   "all_core_images_per_s": r["per_threads"].get(str(ncores))}
+                   "samples_at_best_images_per_s": r.get("samples_at_best"),
+                   "physical_core_images_per_s": r["per_threads"].get(str(min(ncores, phys)))}
             if "fwd_s" in r:
                 out["src_model_forward_b10_s"] = r["fwd_s"]
                 out["src_model_forward_b10_threads"] = r.get("fwd_threads")
@@ -617,7 +675,9 @@ def main():
     if use_dist:
         for r in reducers.values():
             r.measure_exposed(True)              # two event records per finish(): read after the timed region
-    run_step, is_graph = graphed(args, step, world)
+    for _ in range(args.warmup):                 # (choose_launch needs a settled model: packs, arenas, workspaces)
+        step()
+    run_step, is_graph, launch_cal = choose_launch(args, step, world, fence)
     elapsed = timed(run_step, args.steps, args.warmup, fence)
     rccl = None
     if use_dist:
@@ -658,7 +718,10 @@ def main():
     if args.dtype == "bf16":
         from hific_amd import ops as _ops
         out["config"]["exact_index_chain"] = bool(_ops.exact_index_on())
-    out["config"]["launch"] = "one hipGraph replay per cycle" if is_graph else "eager (one launch per kernel)"
+    out["config"]["launch"] = ("one single-stream hipGraph replay per cycle" if is_graph else
+                               "eager (one launch per kernel, side / branch streams)")
+    if launch_cal is not None:
+        out["launch_modes"] = launch_cal
     if rccl is not None:
         out["rccl"] = rccl
     extras = world == 1 and not args.no_extras
@@ -681,23 +744,6 @@ def main():
         if os.environ.get("HIFIC_BENCH_ROOFLINE_ONLY") == "1":      # kernel experiments: headline + per-kernel table, nothing else
             print(json.dumps(out), flush=True)
             return
-        # ---- the same cycle as ONE hipGraph replay (hific_amd.graph.GraphedStep; bit-identical: tests/test_gpu_zz_graph.py)
-        if not is_graph and os.environ.get("HIFIC_BENCH_NO_GRAPH_LEG") != "1":
-            gstep, ok = graphed(args, step, world, force=True)
-            if ok:
-                ng = max(3, min(args.steps, 10))
-                fence(); t0 = time.perf_counter()
-                for _ in range(ng):
-                    gstep()
-                t_host = time.perf_counter() - t0
-                fence(); eg = time.perf_counter() - t0
-                out["graph"] = {"value": round(world * imgs_per_step * ng / eg, 3), "unit": "images/s",
-                                "ms_per_step": round(eg / ng * 1e3, 3), "host_ms_per_replay": round(t_host / ng * 1e3, 3),
-                                "workload": "the headline cycle captured once into a hipGraph (side / branch streams and the "
-                                            "autograd backward included) and replayed; eager launch stays the headline "
-                                            "because hipGraphLaunch of ~1000 nodes costs the host about as much as enqueueing "
-                                            "them"}
-            del gstep
         del model, opts, reducers, step, run_step
         hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
         torch.cuda.empty_cache()
@@ -705,9 +751,12 @@ def main():
         if cfg == "gan":
             m2, o2, r2 = build(args, dev, "compression")
             s2 = make_step(args, m2, o2, r2, dev, "compression")
-            s2, _ = graphed(args, s2, world)
+            for _ in range(args.warmup):
+                s2()
+            s2, g2, _ = choose_launch(args, s2, world, fence)
             e2 = timed(s2, args.steps, args.warmup, fence)
             out["compression"] = {"value": round(args.batch * args.steps / e2, 3), "unit": "images/s",
+                                  "launch": "graph" if g2 else "eager",
                                   "ms_per_step": round(e2 / args.steps * 1e3, 3),
                                   "workload": "BASELINE configs[1]: compression (no GAN) training step, same batch/dtype",
                                   "whole_step_tflops": round(GFLOP_PER_IMAGE["compression"] * args.batch *
@@ -729,17 +778,25 @@ def main():
         def fwd():
             with torch.no_grad():
                 return ev(xe)
-        ef = timed(fwd, max(args.steps, 10), args.warmup, fence)
+        fwd.generators = ()
+        for _ in range(3):
+            fwd()
+        fwd_run, gf, _ = choose_launch(args, fwd, world, fence)
+        ef = timed(fwd_run, max(args.steps, 10), args.warmup, fence)
         per_img = ef / max(args.steps, 10) / args.batch * 1e3
         out["fwd_ms_per_image"] = round(per_img, 4)
         out["fwd"] = {"workload": f"EVALUATION-mode Model.forward (Encoder -> Hyperprior -> Generator, clamp; returns "
                                   f"reconstruction + q_bpp), no-grad, batch {args.batch}, {args.dtype}",
+                      "launch": "graph" if gf else "eager",
                       "ms_per_batch": round(per_img * args.batch, 3), "images_per_s": round(1e3 / per_img, 1),
                       "tflops": round(GFLOP_PER_IMAGE["forward"] * (args.size / 256.0) ** 2 / 1e3 / (per_img * 1e-3), 1)}
         if args.dtype == "bf16" and hific_ops.exact_index_on():
             hific_ops.set_exact_index(False)                     # for comparison: the plain bf16 chain (0.39 % index flips)
             try:
-                ef2 = timed(fwd, max(args.steps, 10), 2, fence)
+                fwd(); fwd()
+                fwd2, _, _ = choose_launch(args, fwd, world, fence)
+                ef2 = timed(fwd2, max(args.steps, 10), 2, fence)
+                del fwd2
             finally:
                 hific_ops.set_exact_index(True)
             out["fwd"]["plain_bf16_chain_ms_per_image"] = round(ef2 / max(args.steps, 10) / args.batch * 1e3, 4)
@@ -752,10 +809,12 @@ def main():
             a32 = argparse.Namespace(**vars(args)); a32.dtype = "f32"
             m3, o3, r3 = build(a32, dev, cfg)
             s3 = make_step(a32, m3, o3, r3, dev, cfg)
-            s3, _ = graphed(a32, s3, world)
+            s3(); s3()
+            s3, g3, _ = choose_launch(a32, s3, world, fence, ncal=2)
             n3 = max(2, min(args.steps, 4))
             e3 = timed(s3, n3, 1, fence)
             out["f32"] = {"value": round(imgs_per_step * n3 / e3, 3), "unit": "images/s", "ms_per_step": round(e3 / n3 * 1e3, 3),
+                          "launch": "graph" if g3 else "eager",
                           "workload": "the headline cycle in float32 parity mode (v_mfma_f32_32x32x2_f32, f32 activations): "
                                       "every output within 1e-3 of the oracle (tests/test_gpu_golden.py, "
                                       "tests/test_gpu_fullsize_backward.py)",
@@ -769,11 +828,12 @@ def main():
             a5 = argparse.Namespace(**vars(args)); a5.size, a5.batch, a5.regime = 1024, 1, "high"
             m5, o5, r5 = build(a5, dev, "gan")
             s5 = make_step(a5, m5, o5, r5, dev, "gan")
-            s5, _ = graphed(a5, s5, world)
+            s5(); s5()
+            s5, g5, _ = choose_launch(a5, s5, world, fence)
             n5 = max(3, min(args.steps, 10))
             e5 = timed(s5, n5, 2, fence)
             out["config5_1gpu"] = {"value": round(2 * n5 / e5, 3), "unit": "images/s (1024x1024)",
-                                   "ms_per_step": round(e5 / n5 * 1e3, 3),
+                                   "ms_per_step": round(e5 / n5 * 1e3, 3), "launch": "graph" if g5 else "eager",
                                    "workload": f"BASELINE configs[4] on one GPU: compression_gan regime high, G-turn + D-turn "
                                                f"cycle, 1 x 1024x1024 crop per turn, {args.dtype}, fwd+bwd+Adam",
                                    "megapixels_per_s": round(2 * n5 * 1.048576 / e5, 2),

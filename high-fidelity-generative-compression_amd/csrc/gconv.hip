@@ -32,10 +32,13 @@
 #include <mutex>
 #include <unordered_map>
 static void gc_set_max_lds(const void* fn, int bytes) {
+    // the attribute belongs to the CURRENT device's function object: one record per (device, function)
     static std::mutex mu;
-    static std::unordered_map<const void*, int> cur;
+    static std::unordered_map<unsigned long long, int> cur;
+    int dev = 0;
+    hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
-    int& c = cur[fn];
+    int& c = cur[(unsigned long long)(uintptr_t)fn * 64u + (unsigned)dev];
     if (bytes > c) {
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         c = bytes;

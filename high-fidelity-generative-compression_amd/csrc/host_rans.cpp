@@ -98,7 +98,9 @@ extern "C" int hific_rans_encode(const int32_t* symbols, const int32_t* indices,
         if (value < 0) { overflow = (uint64_t)(-2 * value - 1); value = max_value; }
         else if (value >= max_value) { overflow = (uint64_t)(2 * (value - max_value)); value = max_value; }
         const uint64_t start = c[value], freq = c[value + 1] - c[value];
-        if (freq == 0) return HIFIC_HOST_ERR_RANGE;                 // zero-width interval: table not codable
+        // zero-width interval, or a non-monotone / over-range row (freq wraps as unsigned): table not codable, and the
+        // reciprocal table of divmod() only covers f <= 2^precision
+        if (freq == 0 || freq > (1ull << precision)) return HIFIC_HOST_ERR_RANGE;
         if (value == max_value) {                                   // overflow symbol + nibble code (:213-238)
             int nn = 0;
             uint32_t widths = 0;
@@ -241,7 +243,7 @@ extern "C" int hific_rans_encode_vec(const int32_t* symbols, const int32_t* indi
             if (v < 0) { of = (uint64_t)(-2 * v - 1); v = max_value; }
             else if (v >= max_value) { of = (uint64_t)(2 * (v - max_value)); v = max_value; }
             start[l] = c[v]; freq[l] = c[v + 1] - c[v];
-            if (freq[l] == 0) return HIFIC_HOST_ERR_RANGE;       // zero-width interval: table not codable
+            if (freq[l] == 0 || freq[l] > (1ull << precision)) return HIFIC_HOST_ERR_RANGE;   // not codable (see scalar coder)
             overflow[l] = of;
             of_mask[l] = (v == max_value);
             any_of |= of_mask[l] != 0;

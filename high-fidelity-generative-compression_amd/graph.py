@@ -18,7 +18,7 @@ What makes the step capturable (each was a host-side decision baked into kernel 
     the default one must be passed in `generators=` to be registered with the graph.
 What is frozen at capture: learning rate, the schedule values of lambda / target rate (src/helpers/utils.py:64-72 change at
 step 50 000: re-capture then), log_interval bookkeeping (capture with writeout=False).  The captured function must not
-synchronise with the host.  Results are bit-identical to eager execution (tests/test_gpu_graph.py)."""
+synchronise with the host.  Results are bit-identical to eager execution (tests/test_gpu_zz_graph.py)."""
 import torch
 
 
@@ -47,9 +47,16 @@ class GraphedStep:
         # thread's launches are not stream operations the capture needs to police
         with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
             self.out = fn()
+        # the graph holds raw pointers into the packed-weight cache: its entries must outlive it (replays never touch the
+        # cache's LRU bookkeeping)
+        self._pins = ops.pack_cache.pin_all()
         self.replays = 0
 
     def __call__(self):
+        from . import ops
+        if ops.pack_cache.pins_broken != self._pins:
+            raise RuntimeError("GraphedStep: a packed-weight buffer this graph reads was dropped (a parameter was moved, "
+                               "re-created, or the cache was cleared) - capture the step again")
         self.graph.replay()
         self.replays += 1
         return self.out

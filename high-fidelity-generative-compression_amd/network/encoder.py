@@ -2,10 +2,15 @@
 indices (so `Encoder.conv_block{1-5}.1.{weight,bias}`, `.2.{gamma,beta}`, `conv_block_out.1.*` state_dict keys are
 identical), forward on the gfx950 kernels.  Reflection pads (encoder.py:46-48) are folded into the conv tile
 loader; ChannelNorm + ReLU (encoder.py:58-60) is one fused kernel."""
+import warnings
+
 import torch.nn as nn
 
 from ..normalisation import channel, instance
 from .layers import HipConv2d, mark_exact_index_chain
+
+
+_warned_big = False
 
 
 class Encoder(nn.Module):
@@ -70,9 +75,36 @@ class Encoder(nn.Module):
     def forward(self, x):
         from .. import ops
         import torch
-        if (ops.exact_index_on() and ops.get_compute_dtype() == torch.bfloat16 and x.is_cuda and self.conv_block1[1].exact_index_chain
-                and isinstance(self.conv_block1[2], channel.ChannelNorm2D) and ops.fused_exact_blocks_on()):
+        exact = ops.exact_index_on() and ops.get_compute_dtype() == torch.bfloat16 and x.is_cuda \
+            and self.conv_block1[1].exact_index_chain
+        if exact and not ops.exact_chain_fits(self._exact_planes(x)):
+            # images beyond ~11.9 MP: the split-bf16 operand images outgrow the kernels' 32-bit element offsets
+            # (HIFIC_ERR_UNSUPPORTED); the plain bf16 chain still runs - 0.4 % of the latent indices may then differ by
+            # one step from a float32 run
+            global _warned_big
+            if not _warned_big:
+                _warned_big = True
+                warnings.warn(f"hific_amd Encoder: input {tuple(x.shape)} is too large for the exact-index (split-bf16) "
+                              f"chain; this forward runs the plain bf16 chain", RuntimeWarning, stacklevel=2)
+            with ops.exact_index_suspended():
+                return self._forward_plain(x)
+        if exact and isinstance(self.conv_block1[2], channel.ChannelNorm2D) and ops.fused_exact_blocks_on():
             return self._forward_exact_chain(x)
+        return self._forward_plain(x)
+
+    def _exact_planes(self, x):
+        """(channels, H, W) of the block inputs / outputs the exact chain holds as (hi, lo, hi) images."""
+        _, C, H, W = x.shape
+        planes = [(C, H, W)]
+        for blk in (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4, self.conv_block5):
+            conv = blk[1]
+            pt, pl, pb, pr = conv.pads
+            H = (H + pt + pb - conv.kernel_size[0]) // conv.stride[0] + 1
+            W = (W + pl + pr - conv.kernel_size[1]) // conv.stride[1] + 1
+            planes.append((conv.out_channels, H, W))
+        return planes
+
+    def _forward_plain(self, x):
         x = self.conv_block1(x)
         x = self.conv_block2(x)
         x = self.conv_block3(x)

@@ -61,7 +61,7 @@ _PACK_CACHE_ON = __import__("os").environ.get("HIFIC_PACK_CACHE", "1") != "0"
 
 class _PackEntry:
     __slots__ = ("weight", "buf", "job", "token", "nblocks", "lds", "dtype", "kind", "event", "pack_sid", "waited",
-                 "last_use")
+                 "last_use", "pinned")
 
 
 class WeightPackCache:
@@ -74,10 +74,21 @@ class WeightPackCache:
         # Keys carry the full geometry, so inference over many image sizes would add a packed copy of every weight per
         # size: least-recently-used entries are dropped beyond this many bytes (one training configuration needs ~0.8 GB)
         self.cap_bytes = int(os.environ.get("HIFIC_PACK_CACHE_MB", "6144")) << 20
+        # entries a captured hipGraph reads by raw pointer (graph.GraphedStep pins everything that exists at capture time:
+        # replays never call lookup(), so their last_use would go stale and the LRU would free them first).  Dropping a
+        # pinned entry (its weight died or moved) bumps pins_broken: every graph captured before that refuses to replay.
+        self.pins_broken = 0
+
+    def pin_all(self):
+        for e in self.entries.values():
+            e.pinned = True
+        return self.pins_broken
 
     def _drop(self, key):
         e = self.entries.pop(key)
         self.bytes -= e.buf.numel()
+        if e.pinned:
+            self.pins_broken += 1
         # kernels on other streams may still read the packed image: the allocator must not recycle it under them
         for st in producer_streams(e.buf.device):
             e.buf.record_stream(st)
@@ -85,10 +96,11 @@ class WeightPackCache:
     def _make_room(self, device):
         if self.bytes <= self.cap_bytes:
             return
-        for key, _ in sorted(self.entries.items(), key=lambda kv: kv[1].last_use):
+        for key, e in sorted(self.entries.items(), key=lambda kv: kv[1].last_use):
             if self.bytes <= self.cap_bytes // 2:
                 break
-            self._drop(key)
+            if not e.pinned:
+                self._drop(key)
         self.prepared.clear()
 
     @staticmethod
@@ -97,6 +109,8 @@ class WeightPackCache:
         return (w._version, sl.arena.epoch if sl is not None else -1)
 
     def clear(self):
+        if any(e.pinned for e in self.entries.values()):
+            self.pins_broken += 1
         self.entries.clear(); self.prepared.clear()
         self.bytes = 0
 
@@ -118,7 +132,8 @@ class WeightPackCache:
         tok = self._token(weight)
         if e is not None and e.weight() is not weight:
             # another tensor object at this address (the old one died, or an alias whose version counter we cannot
-            # relate to the packed image): start over for this key
+            # relate to the packed image): start over for this key (the old buffer leaves the byte count with it)
+            self._drop(key)
             e = None
             self.prepared.clear()
         self.tick += 1
@@ -135,7 +150,7 @@ class WeightPackCache:
             e.weight = weakref.ref(weight)
             call("hific_pack_job_set_ptrs", e.job, e.buf.data_ptr(), weight.data_ptr(), None)
             e.token = None                       # never packed yet
-            e.kind, e.event, e.pack_sid, e.waited = kind, None, None, set()
+            e.kind, e.event, e.pack_sid, e.waited, e.pinned = kind, None, None, set(), False
             self.entries[key] = e
             self.bytes += e.buf.numel()
             self.prepared.clear()
@@ -288,6 +303,32 @@ def set_exact_index(on):
 
 def exact_index_on():
     return _EXACT_INDEX
+
+
+class exact_index_suspended:
+    """`with ops.exact_index_suspended():` - the plain bf16 chain for the calls inside (restores the previous setting)."""
+
+    def __enter__(self):
+        global _EXACT_INDEX
+        self._was = _EXACT_INDEX
+        _EXACT_INDEX = False
+        return self
+
+    def __exit__(self, *exc):
+        global _EXACT_INDEX
+        _EXACT_INDEX = self._was
+        return False
+
+
+# The split images of the exact chain carry 3C channels per image and are addressed with 32-bit element offsets
+# (hific_split3 / hific_channelnorm_fwd_exact return HIFIC_ERR_UNSUPPORTED from 3*C*H*W >= 2^31 on): a 60-channel plane
+# reaches that at ~11.9 megapixels.  The plain bf16 chain addresses C*H*W and keeps working there.
+_EXACT_MAX_ELEMS = 1 << 31
+
+
+def exact_chain_fits(planes):
+    """planes: iterable of (channels, H, W) of every tensor the exact chain would hold a split image of."""
+    return all(3 * c * h * w < _EXACT_MAX_ELEMS for c, h, w in planes)
 
 
 # Encoder blocks of the exact chain as one op each (ExactConvNormFn: bf16 autograd graph, split images handed from norm to

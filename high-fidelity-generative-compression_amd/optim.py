@@ -209,6 +209,7 @@ class FusedAdam:
 
     @property
     def step_count(self):
+        """Blocking device-to-host read: not for use inside a captured step (graph.GraphedStep) or per parameter."""
         return int(self._step_dev.item())
 
     @step_count.setter
@@ -230,10 +231,11 @@ class FusedAdam:
         wrote a Python int - both load here)."""
         ops.wait_late_params()
         state = {}
-        if self.step_count > 0:
+        step_n = self.step_count               # ONE blocking device read (the count lives in device memory)
+        if step_n > 0:
             for i, p in enumerate(self.arena.params):
                 o, n = self.arena.slice_of(i)
-                state[i] = dict(step=torch.tensor(float(self.step_count)),
+                state[i] = dict(step=torch.tensor(float(step_n)),
                                 exp_avg=self.exp_avg[o:o + n].view(p.shape).clone(),
                                 exp_avg_sq=self.exp_avg_sq[o:o + n].view(p.shape).clone())
         g = self.param_groups[0]

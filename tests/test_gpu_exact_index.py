@@ -218,3 +218,35 @@ def test_hyperprior_bf16_indices_equal_the_oracle(hific, dev, training):
         tie = torch.minimum(frac, 1 - frac)
         assert n <= max(2, 1e-4 * flips.numel()) and float(tie[flips].max()) < 1e-4, (n, float(tie[flips].max()))
         assert int(((idx_h - idx_o).abs() > 1).sum()) == 0
+
+
+def test_encoder_falls_back_to_plain_bf16_beyond_the_split_image_limit(hific, dev, monkeypatch):
+    """hific_channelnorm_fwd_exact / hific_split3 return HIFIC_ERR_UNSUPPORTED from 3*C*H*W >= 2^31 on
+    (~11.9 MP for the 60-channel block).  The Encoder must then run the plain bf16 chain (with a warning) instead of
+    raising; checked with the limit lowered so a 64x64 image trips it: the result equals the HIFIC_EXACT_INDEX=0 forward
+    bit for bit, and the real limit itself is what the C-ABI reports."""
+    import warnings
+    from hific_amd import ops, lib
+    from hific_amd.network import encoder
+    torch.manual_seed(3)
+    enc = encoder.Encoder((3, 64, 64), 2, C=220).to(dev)
+    x = torch.rand(2, 3, 64, 64, device=dev)
+    with torch.no_grad():
+        y_exact = enc(x)
+        ops.set_exact_index(False)
+        y_plain = enc(x)
+        ops.set_exact_index(True)
+        monkeypatch.setattr(ops, "_EXACT_MAX_ELEMS", 3 * 60 * 64 * 64)          # block 1's output plane no longer fits
+        monkeypatch.setattr(encoder, "_warned_big", False)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            y_fall = enc(x)
+        assert any("plain bf16 chain" in str(i.message) for i in w)
+        assert ops.exact_index_on()                                             # the suspension is scoped to the call
+    assert torch.equal(y_fall, y_plain) and not torch.equal(y_fall, y_exact)
+    # the limit the predicate mirrors: the C-ABI refuses 3*C*HW >= 2^31 without touching memory
+    rc = lib.raw("hific_channelnorm_fwd_exact")(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                                x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 60, (1 << 31) // 180 + 1,
+                                                1e-3, 1, lib.stream())
+    assert rc == -4
+    assert not ops.exact_chain_fits([(60, 3456, 3456)]) and ops.exact_chain_fits([(60, 3000, 3000)])

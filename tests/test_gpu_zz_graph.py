@@ -104,3 +104,48 @@ def test_captured_cycle_with_device_rng(hific, dev):
     assert int(graph["amort.step"]) == WARM + REPLAYS
     assert abs(float(eager["loss_G"]) - float(graph["loss_G"])) < 2e-2 * abs(float(eager["loss_G"]))
     assert all(torch.isfinite(v.float()).all() for v in graph.values())
+
+
+def test_captured_single_stream_cycle_and_pinned_pack_cache(hific, dev):
+    """(i) The cycle captured with everything on ONE stream (no side / branch streams: the only form whose hipGraphLaunch
+    takes ROCm's packet-replay path, 0.3 ms of host time per cycle instead of 19 ms) leaves the eager multi-stream state bit
+    for bit.  (ii) ADVICE round 3: a captured graph reads the packed-weight cache by raw pointer and never touches its LRU
+    bookkeeping - entries that exist at capture are pinned: eager work that floods the cache afterwards must not evict
+    them, replacing an entry must keep the byte count exact, and dropping a pinned entry makes the graph refuse to replay."""
+    from hific_amd import ops
+    from hific_amd.graph import GraphedStep
+    eager = _run(dev, False, False)
+    side_was, branch_was = ops._SIDE_ON, ops.branch_streams_on()
+    ops.set_side_stream(False); ops.set_branch_streams(False)
+    try:
+        torch.manual_seed(1234)
+        model, opts, step, gen = _setup(dev, False)
+        gs = GraphedStep(step, warmup=WARM, generators=(gen,))
+        out = gs()
+        pc = ops.pack_cache
+        assert pc.entries and all(e.pinned for e in pc.entries.values())
+        pinned = set(pc.entries)
+        # flood: a tiny cap and new geometry keys (another batch size through one layer) - the LRU may only take the new ones
+        cap_was = pc.cap_bytes
+        pc.cap_bytes = 1
+        try:
+            conv = model.Generator.resblock_0.conv1
+            for n in (1, 2, 3):
+                with torch.no_grad():
+                    conv(torch.zeros(n, 960, 8, 8, device=dev, dtype=torch.bfloat16))
+        finally:
+            pc.cap_bytes = cap_was
+        assert pinned <= set(pc.entries)
+        assert pc.bytes == sum(e.buf.numel() for e in pc.entries.values())
+        for _ in range(REPLAYS - 1):
+            out = gs()
+        graph = _state(model, opts, out)
+        bad = [k for k in eager if not torch.equal(eager[k], graph[k])]
+        assert not bad, bad
+        # a pinned entry goes away -> the graph must not replay over freed memory
+        pc._drop(next(iter(pinned)))
+        with pytest.raises(RuntimeError, match="capture the step again"):
+            gs()
+    finally:
+        ops.set_side_stream(side_was); ops.set_branch_streams(branch_was)
+        ops.pack_cache.clear(); ops.split_weights.clear()
