@@ -39,7 +39,9 @@ static bool geomT_ok(const ConvTGeom& g) {
 
 // y = act(conv2d(pad(x), w*w_scale) + bias [+ resid]);  x [N,C,H,W], w f32 [K,C,R,S], y [N,K,OH,OW]
 // flags: bit0 = x is f32 although dtype is bf16, bit1 = y (and resid) are f32 although dtype is bf16, bit2 = C is the
-// 3x split-bf16 reduction of a C/3-channel layer (hific_split3; only the profiler's FLOP count changes)
+// 3x split-bf16 reduction of a C/3-channel layer (hific_split3; only the profiler's FLOP count changes), bit3 = x and w
+// are in the PAIR layout (hific_split3 which = 2, C = 2 * C16): the native split kernel forms hi*hi + hi*lo + lo*hi; bits
+// 8.. = the layer's real channel count (profiler FLOPs)
 int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const float* bias, const void* resid, void* y,
                      int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb, int pr,
                      int pad_mode, int act, int dtype, int flags, void* ws, size_t ws_bytes, void* wcache,
@@ -48,7 +50,9 @@ int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const 
     if (!geom_ok(g) || !x || !w || !y) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
     a.wcache = wcache; a.wcache_bytes = wcache_bytes; a.wcache_state = wcache_state;
-    g.red_split = (flags >> 2) & 1;
+    g.red_split = (flags & 8) ? 2 : ((flags >> 2) & 1);
+    g.red_C = flags >> 8;
+    if ((flags & 8) && (dtype != HIFIC_BF16 || (flags & 1) || C % 32 != 0 || w_scale)) return HIFIC_ERR_ARG;
     return gc_conv_fwd(g, x, w, w_scale, bias, y, resid, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 
@@ -83,7 +87,9 @@ int hific_conv_transpose2d_fwd(const void* x, const float* w, const float* bias,
     if (!geomT_ok(g) || !x || !w || !y) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
     a.wcache = wcache; a.wcache_bytes = wcache_bytes; a.wcache_state = wcache_state;
-    g.red_split = (flags >> 2) & 1;
+    g.red_split = (flags & 8) ? 2 : ((flags >> 2) & 1);
+    g.red_C = flags >> 8;
+    if ((flags & 8) && (dtype != HIFIC_BF16 || (flags & 1) || Ci % 32 != 0)) return HIFIC_ERR_ARG;
     return gc_convT_fwd(g, x, w, bias, y, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 int hific_conv_transpose2d_bwd_data(const void* dy, const float* w, void* dx, int N, int Ci, int H, int W, int Co,
@@ -116,6 +122,7 @@ int hific_conv2d_pack_plan(int kind, int N, int C, int H, int W, int K, int R, i
     WsAlloc a{(char*)0x100000, (size_t)1 << 60, 0};            // plan-only: nothing is dereferenced or launched
     a.plan_out = (PackJob*)job;
     const float* fake_w = (const float*)job;       // never dereferenced in a plan-only call
+    g.red_split = (flags & 8) ? 2 : 0;                          // (the plan - and so the pack layout - depends on it)
     if (kind == 0) return gc_conv_fwd(g, job, fake_w, nullptr, nullptr, job, nullptr, ACT_NONE, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
     return gc_conv_bwd_data(g, job, fake_w, nullptr, job, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
 }
@@ -126,6 +133,7 @@ int hific_conv_transpose2d_pack_plan(int kind, int N, int Ci, int H, int W, int 
     WsAlloc a{(char*)0x100000, (size_t)1 << 60, 0};            // plan-only: nothing is dereferenced or launched
     a.plan_out = (PackJob*)job;
     const float* fake_w = (const float*)job;
+    g.red_split = (flags & 8) ? 2 : 0;
     if (kind == 0) return gc_convT_fwd(g, job, fake_w, nullptr, job, ACT_NONE, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
     return gc_convT_bwd_data(g, job, fake_w, job, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
 }

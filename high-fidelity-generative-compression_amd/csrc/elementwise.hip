@@ -525,6 +525,24 @@ __global__ void split3_bf16x4_kernel(const float4* __restrict__ src, uint2* __re
         d[2ull * ci] = WHICH == 0 ? H : L;
     }
 }
+// Pair layout of the native split-bf16 kernels (gconv_kernel SPLIT): channel c = 16 g + j of the source becomes channels
+// 32 g + j (hi) and 32 g + 16 + j (lo) of dst [outer][2 * C16][inner], C16 = C rounded up to 16; the padding channels of the
+// last group are written as zeros.  The same layout serves activations and weights: the kernel forms the cross terms.
+template <typename TO>
+__global__ void split_pair_kernel(const float* __restrict__ src, TO* __restrict__ dst, long long total, unsigned C,
+                                  unsigned C16, unsigned inner) {
+    const unsigned ci16 = C16 * inner;
+    EW_LOOP(i, total) {
+        const unsigned long long o = (unsigned long long)i / ci16;
+        const unsigned r = (unsigned)((unsigned long long)i - o * ci16);
+        const unsigned c = r / inner, q = r - c * inner;
+        float h = 0.f, l = 0.f;
+        if (c < C) split_hl(src[(o * C + c) * inner + q], h, l);
+        TO* d = dst + (o * 2ull * C16 + 32u * (c >> 4) + (c & 15u)) * inner + q;
+        DT<TO>::st(d, h);
+        DT<TO>::st(d + 16ull * inner, l);
+    }
+}
 
 extern "C" {
 
@@ -587,12 +605,24 @@ int hific_cast(const void* a, int src_dtype, void* o, int dst_dtype, long long n
     return hific_launch_status();
 }
 
-// which 0: activation layout (hi, lo, hi); 1: weight layout (hi, hi, lo).  dst_dtype bf16 (activations) or f32 (a
+// which 0: activation layout (hi, lo, hi); 1: weight layout (hi, hi, lo); 2: pair layout [outer][2 * C16][inner] of the
+// native split kernels (split_pair_kernel; activations and weights alike).  dst_dtype bf16 (activations) or f32 (a
 // derived weight tensor whose values are exactly bf16-representable, fed to the ordinary weight-pack path).
 int hific_split3(const float* src, void* dst, long long outer, int C, long long inner, int which, int dst_dtype,
                  hipStream_t st) {
-    if (!src || !dst || outer <= 0 || C <= 0 || inner <= 0 || (which != 0 && which != 1)) return HIFIC_ERR_ARG;
+    if (!src || !dst || outer <= 0 || C <= 0 || inner <= 0 || which < 0 || which > 2) return HIFIC_ERR_ARG;
     if ((long long)C * inner >= (1ll << 31)) return HIFIC_ERR_UNSUPPORTED;
+    if (which == 2) {       // pair layout: dst [outer][2 * C16][inner]
+        const long long C16 = ((long long)C + 15) / 16 * 16;
+        if (2 * C16 * inner >= (1ll << 31)) return HIFIC_ERR_UNSUPPORTED;
+        const long long tot = outer * C16 * inner;
+        if (dst_dtype == HIFIC_BF16)
+            hipLaunchKernelGGL(split_pair_kernel<bf16_t>, EW_GRID(tot), dim3(256), 0, st, src, (bf16_t*)dst, tot, (unsigned)C, (unsigned)C16, (unsigned)inner);
+        else if (dst_dtype == HIFIC_F32)
+            hipLaunchKernelGGL(split_pair_kernel<float>, EW_GRID(tot), dim3(256), 0, st, src, (float*)dst, tot, (unsigned)C, (unsigned)C16, (unsigned)inner);
+        else return HIFIC_ERR_ARG;
+        return hific_launch_status();
+    }
     const long long total = outer * C * inner;
     if (dst_dtype == HIFIC_BF16 && inner % 4 == 0 && (((size_t)src & 15) | ((size_t)dst & 7)) == 0) {
         if (which == 0) hipLaunchKernelGGL(split3_bf16x4_kernel<0>, EW_GRID(total / 4), dim3(256), 0, st, (const float4*)src, (uint2*)dst, total / 4, (unsigned)C, (unsigned)(inner / 4));

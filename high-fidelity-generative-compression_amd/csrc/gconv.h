@@ -51,6 +51,9 @@ struct GcParams {
     int ksplit, kchunks;
     float* kpart;
     long long kpart_stride;
+    int split;           // native split-bf16 reduction (gconv_kernel SPLIT): both operands in the pair layout of
+                         // hific_split3 which = 2 - every 32 reduction channels are (hi 16 | lo 16) of 16 real channels and
+                         // a step issues hi*hi + hi*lo + lo*hi
     int afrag;           // packed weights in MFMA A-fragment order (gc_wp_index): gconv_sp9_kernel AG streams them
                          // global -> registers, bypassing LDS
     // reflect-padded data gradient: `out` is the f32 padded plane buffer (only its rim is written); pixels inside
@@ -85,14 +88,16 @@ struct WgParams {
 // geometry of a conv layer as the reference constructs it (nn.Conv2d semantics)
 struct ConvGeom {
     int N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode;
-    int red_split = 0;   // C is 3x the layer's channels (split-bf16 operands, hific_split3): count 1/3 of the FLOPs
+    int red_split = 0;   // 1: C is 3x the layer's channels (split-bf16 operands, hific_split3): count 1/3 of the FLOPs
+                         // 2: C is the pair layout (2 * C16) of the native split kernels; red_C = the layer's real channels
+    int red_C = 0;
     int OH() const { return (H + pt + pb - R) / stride + 1; }
     int OW() const { return (W + pl + pr - S) / stride + 1; }
 };
 // nn.ConvTranspose2d semantics: x[N,Ci,H,W], w[Ci,Co,R,S]
 struct ConvTGeom {
     int N, Ci, H, W, Co, R, S, stride, pad, outpad;
-    int red_split = 0;
+    int red_split = 0, red_C = 0;
     int OH() const { return (H - 1) * stride - 2 * pad + R + outpad; }
     int OW() const { return (W - 1) * stride - 2 * pad + S + outpad; }
 };

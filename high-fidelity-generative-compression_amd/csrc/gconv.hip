@@ -459,10 +459,16 @@ __device__ __forceinline__ void gc_epilogue_wide(const GcParams& p, const GcPhas
 // QBW = patch pixels per lane per staging batch (stage_T QB); -1 = the wide-load staging variant (stage_W).  A separate
 // instantiation on purpose: with both loaders behind a runtime flag the 64-row kernel went from 3 to 2 waves per SIMD
 // (189 VGPRs) and every stride-1 layer on it lost 15-35 %.
-template <typename T, int BC, int WGM, int WGN, int WM, int WN, int QBW, int TPS>
+// SPLIT (bf16, BC >= 32): native split-bf16 reduction of the exact-index chain.  Both operands arrive in the pair layout
+// (hific_split3 which = 2): K-slices (2j, 2j+1) of a chunk are the hi and lo halves of the same 16 real channels, and a
+// step issues hi*hi + hi*lo + lo*hi per slice pair - 3 MFMAs on 2 + 2 staged fragments, where the (hi, lo, hi) x (hi, hi, lo)
+// form over 3C channels of the plain kernel stages 3 + 3 (a third more patch staging, weight tiles, LDS reads and barrier
+// steps for the same MFMAs).
+template <typename T, int BC, int WGM, int WGN, int WM, int WN, int QBW, int TPS, bool SPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QBW > 1 ? 1 : 2, QBW > 1 ? 1 : 8)))
 void gconv_kernel(const GcParams p) {
     constexpr bool WIDE = QBW < 0;
+    static_assert(!SPLIT || (std::is_same<T, bf16_t>::value && BC >= 32), "split reduction: bf16, slice pairs");
     constexpr int QB = QBW < 0 ? 1 : QBW;
     static_assert(!WIDE || (std::is_same<T, bf16_t>::value && BC >= 32), "wide staging: bf16, 32/64-channel chunks");
     using Cfg = GcCfg<T>;
@@ -619,6 +625,23 @@ void gconv_kernel(const GcParams p) {
                 _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                               \
                     _Pragma("unroll") for (int ni = 0; ni < WN; ++ni)                                           \
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0); \
+            } else if constexpr (SPLIT) {                                                                       \
+                if (kk & 1) continue;                                                                           \
+                bf16x8_t a[WM], al[WM], b[WN], bl[WN];                                                          \
+                _Pragma("unroll") for (int mi = 0; mi < WM; ++mi) {                                             \
+                    a[mi] = *(const bf16x8_t*)(arow + mi * 32 * PITCH + kk * 32 + lhi * 16);                    \
+                    al[mi] = *(const bf16x8_t*)(arow + mi * 32 * PITCH + (kk + 1) * 32 + lhi * 16);             \
+                }                                                                                               \
+                _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                             \
+                    b[ni] = *(const bf16x8_t*)(patch + (size_t)(qb[ni] + toff) * PITCH + kk * 32 + lhi * 16);   \
+                    bl[ni] = *(const bf16x8_t*)(patch + (size_t)(qb[ni] + toff) * PITCH + (kk + 1) * 32 + lhi * 16); \
+                }                                                                                               \
+                _Pragma("unroll") for (int mi = 0; mi < WM; ++mi)                                               \
+                    _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                         \
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], b[ni], acc[mi][ni], 0, 0, 0); \
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bl[ni], acc[mi][ni], 0, 0, 0); \
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);  \
+                    }                                                                                           \
             } else {                                                                                            \
                 bf16x8_t a[WM], b[WN];                                                                          \
                 if (!(p.dbg & 8)) {                                                                             \
@@ -2494,7 +2517,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         // >= 4 channel chunks: the software pipeline needs chunks to overlap; single-chunk large-plane layers are
         // HBM/epilogue-bound and did better with two co-resident generic workgroups (K60 C120 @128x128: 205 -> 230 us,
         // K480 C960 @16x16: 134 -> 89 us)
-        if (p.nphase == 4 && p.ist == 1 && !p.in_f32 && p.K > 32 && p.C >= 256 && !p.rfx && !env_int("HIFIC_NO_PHS", 0)) {
+        if (p.nphase == 4 && p.ist == 1 && !p.in_f32 && p.K > 32 && p.C >= 256 && !p.rfx && !p.split && !env_int("HIFIC_NO_PHS", 0)) {
             const int n0_ = p.ph[0].ntaps, n1_ = p.ph[1].ntaps, n2_ = p.ph[2].ntaps, n3_ = p.ph[3].ntaps;
             if (n0_ == 1 && n1_ == 2 && n2_ == 2 && n3_ == 4) phs = 1;
             else if (n0_ == 4 && n1_ == 2 && n2_ == 2 && n3_ == 1) phs = 2;
@@ -2667,7 +2690,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, bf16 input, halo patch <= 192 pixels
     bool use_sp9 = false;
     if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
-        use_sp9 = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 &&
+        use_sp9 = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 && !p.split &&
                   p.NI * p.ph[0].PH * p.ph[0].PW <= 192 && !env_int("HIFIC_NO_SP", 0) &&
                   64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(p.NI * p.ph[0].PH * p.ph[0].PW + 2) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
     }
@@ -2825,6 +2848,16 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             if constexpr (nwp_ * 4 <= 8) { if (tps == 4) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 4>; } \
             if constexpr (nwp_ * 7 <= 8) { if (tps == 7) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 7>; } \
         }                                                                                                \
+        if constexpr (std::is_same<T, bf16_t>::value && BC >= 32) {                                      \
+            if (p.split) {                                                                               \
+                constexpr int nwp_ = (WGM * WM * 32 * (BC * (int)sizeof(T) / 16) + 255) / 256;           \
+                kfn = p.wstage ? gconv_kernel<T, BC, WGM, WGN, WM, WN, -1, 1, true>                      \
+                               : gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 1, true>;                      \
+                if constexpr (nwp_ * 4 <= 8) { if (tps == 4) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 4, true>; } \
+                if (tps == 7) kfn = nullptr;                                                             \
+            }                                                                                            \
+        }                                                                                                \
+        if (!kfn) { prof_close(pslot, st); return HIFIC_ERR_UNSUPPORTED; }                               \
         if (lds > 48 * 1024)                                                                             \
             gc_set_max_lds((const void*)kfn, (int)lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);                                            \
@@ -3121,7 +3154,9 @@ int gc_conv_fwd(const ConvGeom& g, const void* x, const float* w, const float* w
     ph.ntaps = nt; ph.tap0 = 0; ph.ooy = 0; ph.oox = 0; ph.OHt = p.OHf; ph.OWt = p.OWf;
     finish_phase(ph, p);
     const long long RS = (long long)g.R * g.S;
-    p.aflops = 2.0 * g.K * g.C * (double)RS * g.N * g.OH() * g.OW() / (g.red_split ? 3.0 : 1.0);
+    p.split = g.red_split == 2;
+    const double cred = g.red_split == 2 ? (g.red_C > 0 ? g.red_C : g.C / 2) : (g.red_split ? g.C / 3.0 : g.C);
+    p.aflops = 2.0 * g.K * cred * (double)RS * g.N * g.OH() * g.OW();
     return launch_gconv(p, dtype, w, w_scale, (long long)g.C * RS, RS, g.S, 1, ws, st);
 }
 
@@ -3263,7 +3298,9 @@ int gc_convT_fwd(const ConvTGeom& g, const void* x, const float* w, const float*
     }
     p.nphase = np;
     const long long RS = (long long)g.R * g.S;
-    p.aflops = 2.0 * g.Ci * g.Co * (double)RS * g.N * g.H * g.W / (g.red_split ? 3.0 : 1.0);   // every (input pixel, tap) pair once
+    p.split = g.red_split == 2;
+    const double cred = g.red_split == 2 ? (g.red_C > 0 ? g.red_C : g.Ci / 2) : (g.red_split ? g.Ci / 3.0 : g.Ci);
+    p.aflops = 2.0 * cred * g.Co * (double)RS * g.N * g.H * g.W;   // every (input pixel, tap) pair once
     // w[ci][co][r][s]: m = co (stride RS), reduction channel ci (stride Co*RS)
     return launch_gconv(p, dtype, w, nullptr, RS, (long long)g.Co * RS, g.S, 1, ws, st);
 }

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_exact_kernel(const float* __re
                                                                const float* __restrict__ beta, bf16_t* __restrict__ zb,
                                                                bf16_t* __restrict__ y, bf16_t* __restrict__ x3,
                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                               int C, int HW, float eps, int relu, int remap) {
+                                                               int C, int HW, float eps, int relu, int remap, int pair) {
     constexpr int SUBS = 64 / PXB, G = NW * SUBS;
     __shared__ float red[2][NW][PXB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -294,7 +294,8 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_exact_kernel(const float* __re
     const float* xb = z + (size_t)n * C * HW;
     bf16_t* zbb = zb + (size_t)n * C * HW;
     bf16_t* yb = y + (size_t)n * C * HW;
-    bf16_t* x3b = x3 + (size_t)n * 3 * C * HW;
+    const int C16 = (C + 15) & ~15;
+    bf16_t* x3b = x3 + (size_t)n * (pair ? 2 * C16 : 3 * C) * HW;
     float v[CPT], gm[CPT], bt[CPT];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
@@ -335,7 +336,15 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_exact_kernel(const float* __re
             const bf16_t l = f2bf(o - bf2f(h));
             zbb[off] = f2bf(v[k]);
             yb[off] = h;
-            x3b[off] = h; x3b[off + chw] = l; x3b[off + 2u * chw] = h;
+            if (!pair) { x3b[off] = h; x3b[off + chw] = l; x3b[off + 2u * chw] = h; }
+            else {
+                // pair layout of the native split kernels (hific_split3 which = 2): [32 g + j] = hi, [32 g + 16 + j] = lo
+                const unsigned o2 = (unsigned)(32 * (c >> 4) + (c & 15)) * (unsigned)HW + (unsigned)hw;
+                x3b[o2] = h; x3b[o2 + 16u * (unsigned)HW] = l;
+            }
+        } else if (pair && ok && c < C16) {        // zero padding channels of the last 16-group
+            const unsigned o2 = (unsigned)(32 * (c >> 4) + (c & 15)) * (unsigned)HW + (unsigned)hw;
+            x3b[o2] = 0; x3b[o2 + 16u * (unsigned)HW] = 0;
         }
     }
 }
@@ -637,17 +646,21 @@ int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, 
 }
 
 // Exact-index chain norm (cn_fwd_exact_kernel): z f32 [N,C,HW] -> zb, y bf16 [N,C,HW], x3 bf16 [N,3C,HW], mean/rstd f32.
+// split_layout 0: x3 = (hi, lo, hi) over 3C channels; 2: the pair layout [N, 2 * C16, HW] of the native split kernels.
 // HIFIC_ERR_UNSUPPORTED when the shape has no register-resident configuration (the caller then runs the float32 norm and
 // hific_split3 instead).
 int hific_channelnorm_fwd_exact(const float* z, const float* gamma, const float* beta, void* zb, void* y, void* x3,
-                                float* mean, float* rstd, int N, int C, int HW, float eps, int relu, hipStream_t st) {
-    if (C < 2 || N <= 0 || HW <= 0 || !z || !zb || !y || !x3) return HIFIC_ERR_ARG;
+                                float* mean, float* rstd, int N, int C, int HW, float eps, int relu, int split_layout,
+                                hipStream_t st) {
+    if (C < 2 || N <= 0 || HW <= 0 || !z || !zb || !y || !x3 || (split_layout != 0 && split_layout != 2)) return HIFIC_ERR_ARG;
     if ((long long)3 * C * HW >= (1ll << 31)) return HIFIC_ERR_UNSUPPORTED;
+    const int pair = split_layout == 2;
+    if (pair && (long long)2 * ((C + 15) / 16 * 16) * HW >= (1ll << 31)) return HIFIC_ERR_UNSUPPORTED;
     CnCfg cfg;
     if (!cn_pick(N, C, HW, cfg)) return HIFIC_ERR_UNSUPPORTED;
     dim3 rgrid(cdiv(HW, cfg.pxb), N);
 #define CN_FWD_X(PXB, NWV, CPT) hipLaunchKernelGGL((cn_fwd_exact_kernel<PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, z, gamma, \
-                                       beta, (bf16_t*)zb, (bf16_t*)y, (bf16_t*)x3, mean, rstd, C, HW, eps, relu, cn_remap_flag(1))
+                                       beta, (bf16_t*)zb, (bf16_t*)y, (bf16_t*)x3, mean, rstd, C, HW, eps, relu, cn_remap_flag(1), pair)
 #define CN_FWD_XC(CPT)                                                                    \
     do {                                                                                  \
         if (cfg.pxb == 64 && cfg.nw == 4) CN_FWD_X(64, 4, CPT);                           \

@@ -62,13 +62,21 @@ class Encoder(nn.Module):
         reads the split-bf16 image of its input and emits the nominal bf16 activation plus the next block's split image, so
         the forward values are float32-accurate while the stored activations and the whole backward pass are plain bf16."""
         from .. import ops
-        x3 = ops.split3_act(x)
+
+        def layout(conv):
+            # the stride-2 blocks run on the generic strided kernel, which has the native split form (pair layout: 2C staged
+            # channels for the three MFMAs); the 7x7 three-channel layer and the stride-1 960 -> 220 layer (software-pipelined
+            # kernel) keep the (hi, lo, hi) x (hi, hi, lo) form over 3C channels
+            return ops.SPLIT_PAIR if (ops.exact_pair_on() and conv.stride[0] == 2 and conv.in_channels >= 32) else ops.SPLIT_3C
+        blocks = (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4, self.conv_block5)
+        out = self.conv_block_out[1]
+        lays = [layout(blk[1]) for blk in blocks] + [layout(out)]
+        x3 = ops.split3_act(x, lays[0])
         h = x
-        for blk in (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4, self.conv_block5):
+        for i, blk in enumerate(blocks):
             conv, norm = blk[1], blk[2]
             h, x3 = ops.exact_conv_norm(h, x3, conv.weight, conv.bias, conv.stride[0], conv.pads, conv.hip_pad_mode,
-                                        norm.gamma, norm.beta, norm.eps, norm.fuse_relu)
-        out = self.conv_block_out[1]
+                                        norm.gamma, norm.beta, norm.eps, norm.fuse_relu, lays[i], lays[i + 1])
         return ops.conv2d(h, out.weight, out.bias, stride=out.stride[0], pads=out.pads, pad_mode=out.hip_pad_mode,
                           out_f32=True, exact=True, x3=x3)
 

@@ -1,5 +1,7 @@
 """Parameter holders that initialise exactly like torch.nn.Conv2d / ConvTranspose2d (same RNG consumption, same
 state_dict keys) but whose forward runs the gfx950 implicit-GEMM kernels (csrc/gconv.hip)."""
+import os
+
 import torch.nn as nn
 
 from .. import ops, lib
@@ -22,8 +24,7 @@ class HipConv2d(nn.Conv2d):
     def forward(self, x):
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], pads=self.pads,
                           pad_mode=self.hip_pad_mode, act=self.act, out_f32=self.out_f32,
-                          exact=self.exact_index_chain and ops.exact_index_on(),
-                          bias_grad=not self.bias_grad_in_norm)
+                          exact=_exact_mode(self), bias_grad=not self.bias_grad_in_norm)
 
     def extra_repr(self):
         return super().extra_repr() + f", pads(t,l,b,r)={self.pads}, hip_act={self.act}"
@@ -44,8 +45,19 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x):
         return ops.conv_transpose2d(x, self.weight, self.bias, self.stride[0], self.padding[0],
                                     self.output_padding[0], act=self.act, out_f32=self.out_f32,
-                                    exact=self.exact_index_chain and ops.exact_index_on(),
-                                    bias_grad=not self.bias_grad_in_norm)
+                                    exact=_exact_mode(self), bias_grad=not self.bias_grad_in_norm)
+
+
+# hyper nets: the 5x5 stride-2 layers (generic kernel) in the pair layout of the native split kernel (ops.SPLIT_PAIR)
+_PAIR_HYPER = os.environ.get("HIFIC_EXACT_PAIR_HYPER", "1") not in ("0", "")
+
+
+def _exact_mode(m):
+    """False (plain bf16), True (split operands over 3C channels) or "pair" (native split kernel) for layer m's forward."""
+    if not (m.exact_index_chain and ops.exact_index_on()):
+        return False
+    pair = _PAIR_HYPER and ops.exact_pair_on() and m.stride[0] == 2 and m.in_channels >= 32
+    return "pair" if pair else True
 
 
 def mark_exact_index_chain(module, on=True):

@@ -341,7 +341,28 @@ def fused_exact_blocks_on():
 
 
 class _SplitEntry:
-    __slots__ = ("weight", "w3", "token", "addr", "transposed")
+    __slots__ = ("weight", "w3", "token", "addr", "transposed", "layout")
+
+
+# Operand layouts of the exact chain.  SPLIT_3C: (hi, lo, hi) x (hi, hi, lo) over 3C reduction channels of the ordinary bf16
+# kernels (round 3).  SPLIT_PAIR: both operands as (hi 16 | lo 16) groups over 2 * C16 channels, cross terms formed by the
+# native split kernel (gconv_kernel SPLIT; hific_split3 which = 2): a third less staging, LDS traffic and barrier steps for
+# the same three MFMAs.  HIFIC_EXACT_PAIR=0 keeps every layer on the 3C form.
+SPLIT_3C, SPLIT_PAIR = 0, 2
+_EXACT_PAIR = os.environ.get("HIFIC_EXACT_PAIR", "1") not in ("0", "")
+
+
+def exact_pair_on():
+    return _EXACT_PAIR
+
+
+def set_exact_pair(on):
+    global _EXACT_PAIR
+    _EXACT_PAIR = bool(on)
+
+
+def pair_channels(C):
+    return 2 * ((C + 15) // 16 * 16)
 
 
 class SplitWeightCache:
@@ -356,14 +377,16 @@ class SplitWeightCache:
     def clear(self):
         self.entries.clear()
 
-    def get(self, weight, transposed):
-        e = self.entries.get(id(weight))
+    def get(self, weight, transposed, layout=SPLIT_3C):
+        key = (id(weight), layout)
+        e = self.entries.get(key)
         if e is not None and e.weight() is not weight:
             e = None
         if e is None:
             e = _SplitEntry()
             e.weight, e.transposed, e.token, e.addr, e.w3 = weakref.ref(weight), transposed, None, None, None
-            self.entries[id(weight)] = e
+            e.layout = layout
+            self.entries[key] = e
         if e.token != WeightPackCache._token(weight) or e.addr != weight.data_ptr():
             self.refresh()
         return e.w3
@@ -383,17 +406,17 @@ class SplitWeightCache:
             if not waited and _is_late(w):
                 wait_late_params(); waited = True
             shape = list(w.shape)
+            cdim = 0 if e.transposed else 1
             if e.transposed:
                 outer, C, inner = 1, shape[0], w.numel() // shape[0]
-                shape[0] *= 3
             else:
                 outer, C, inner = shape[0], shape[1], shape[2] * shape[3]
-                shape[1] *= 3
+            shape[cdim] = pair_channels(C) if e.layout == SPLIT_PAIR else 3 * C
             if e.w3 is None or e.w3.device != w.device or list(e.w3.shape) != shape:
                 e.w3 = torch.empty(shape, dtype=torch.float32, device=w.device)
             with torch.cuda.device(w.device):
-                call("hific_split3", w.data_ptr(), e.w3.data_ptr(), outer, C, inner, 1, HIFIC_F32,
-                     torch.cuda.current_stream(w.device).cuda_stream)
+                call("hific_split3", w.data_ptr(), e.w3.data_ptr(), outer, C, inner, 2 if e.layout == SPLIT_PAIR else 1,
+                     HIFIC_F32, torch.cuda.current_stream(w.device).cuda_stream)
             torch.autograd.graph.increment_version(e.w3)        # the pack cache keys on it
             e.token, e.addr = tok, w.data_ptr()
 
@@ -401,14 +424,20 @@ class SplitWeightCache:
 split_weights = SplitWeightCache()
 
 
-def _split3_act(x):
-    """float32 [N, C, H, W] -> bf16 [N, 3C, H, W] = (hi, lo, hi)."""
+def _split3_act(x, layout=SPLIT_3C):
+    """float32 [N, C, H, W] -> bf16 [N, 3C, H, W] = (hi, lo, hi), or the pair layout [N, 2 * C16, H, W]."""
     if x.dtype != torch.float32:
         raise lib.HificError("exact-index convolutions take float32 activations")
     N, C, H, W = x.shape
-    x3 = torch.empty((N, 3 * C, H, W), dtype=torch.bfloat16, device=x.device)
-    call("hific_split3", ptr(x), ptr(x3), N, C, H * W, 0, HIFIC_BF16, stream())
+    Cx = pair_channels(C) if layout == SPLIT_PAIR else 3 * C
+    x3 = torch.empty((N, Cx, H, W), dtype=torch.bfloat16, device=x.device)
+    call("hific_split3", ptr(x), ptr(x3), N, C, H * W, 2 if layout == SPLIT_PAIR else 0, HIFIC_BF16, stream())
     return x3
+
+
+def _exact_flags(layout, C):
+    """conv forward flags of an exact layer: float32 output, + 3C marker (profiler) or pair layout + real channel count."""
+    return (1 << 1) | ((1 << 3) | (C << 8) if layout == SPLIT_PAIR else (1 << 2))
 
 
 def _wcache(weight, kind, geom, cd, flags, w_scale=None, transposed=False):
@@ -624,6 +653,7 @@ class Conv2dFn(Function):
         assert Cw == C, "channel mismatch"
         OH = (H + pt + pb - R) // stride + 1
         OW = (W + pl + pr - S) // stride + 1
+        lay = SPLIT_PAIR if (exact == "pair" and C >= 16) else SPLIT_3C
         exact = bool(exact) and cd == HIFIC_BF16 and w_scale is None
         ydt = torch.float32 if (cd == HIFIC_F32 or out_f32 or exact) else torch.bfloat16
         if cd == HIFIC_F32 and x.dtype != torch.float32:
@@ -631,14 +661,16 @@ class Conv2dFn(Function):
         y = torch.empty((N, K, OH, OW), dtype=ydt, device=x.device)
         wsp, wsb = _ws(x)
         if exact:
-            # split-bf16 forward: 3C reduction channels of (hi, lo, hi) x (hi, hi, lo); flags bit2 = count C (not 3C) FLOPs
+            # split-bf16 forward: 3C reduction channels of (hi, lo, hi) x (hi, hi, lo) (flags bit2 = count C, not 3C, FLOPs), or
+            # exact="pair": both operands in the pair layout, cross terms formed by the native split kernel (flags bit3)
             # x3 given (ExactConvNormFn chain): x is the nominal bf16 activation, only saved for the weight gradient
-            x3 = x3 if x3 is not None else _split3_act(x)
-            w3 = split_weights.get(weight, transposed=False)
-            flags = (1 << 1) | (1 << 2)
-            wc = _wcache(w3, 0, (N, 3 * C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None)
+            x3 = x3 if x3 is not None else _split3_act(x, lay)
+            Cx = x3.shape[1]
+            w3 = split_weights.get(weight, transposed=False, layout=lay)
+            flags = _exact_flags(lay, C)
+            wc = _wcache(w3, 0, (N, Cx, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags & 0xff, None)
             call("hific_conv2d_fwd", ptr(x3), ptr(w3), None, ptr(bias), None, ptr(y),
-                 N, 3 * C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
+                 N, Cx, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
         else:
             flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | ((1 if ydt == torch.float32 else 0) << 1 if cd == HIFIC_BF16 else 0)
             wc = _wcache(weight, 0, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, w_scale)
@@ -725,6 +757,7 @@ class ConvTranspose2dFn(Function):
         assert Ciw == Ci
         OH = (H - 1) * stride - 2 * pad + R + outpad
         OW = (W - 1) * stride - 2 * pad + S + outpad
+        lay = SPLIT_PAIR if (exact == "pair" and Ci >= 16) else SPLIT_3C
         exact = bool(exact) and cd == HIFIC_BF16
         ydt = torch.float32 if (cd == HIFIC_F32 or out_f32 or exact) else torch.bfloat16
         if cd == HIFIC_F32 and x.dtype != torch.float32:
@@ -732,10 +765,11 @@ class ConvTranspose2dFn(Function):
         y = torch.empty((N, Co, OH, OW), dtype=ydt, device=x.device)
         wsp, wsb = _ws(x)
         if exact:
-            x3, w3 = _split3_act(x), split_weights.get(weight, transposed=True)
-            flags = (1 << 1) | (1 << 2)
-            wc = _wcache(w3, 0, (N, 3 * Ci, H, W, Co, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
-            call("hific_conv_transpose2d_fwd", ptr(x3), ptr(w3), ptr(bias), ptr(y), N, 3 * Ci, H, W, Co, R, S, stride, pad,
+            x3, w3 = _split3_act(x, lay), split_weights.get(weight, transposed=True, layout=lay)
+            Cx = x3.shape[1]
+            flags = _exact_flags(lay, Ci)
+            wc = _wcache(w3, 0, (N, Cx, H, W, Co, R, S, stride, pad, outpad), cd, flags & 0xff, None, transposed=True)
+            call("hific_conv_transpose2d_fwd", ptr(x3), ptr(w3), ptr(bias), ptr(y), N, Cx, H, W, Co, R, S, stride, pad,
                  outpad, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
         else:
             flags = 0
@@ -855,36 +889,43 @@ class ExactConvNormFn(Function):
     side stream): no float32 activation is stored, re-read or back-propagated."""
 
     @staticmethod
-    def forward(ctx, x, x3, weight, bias, geom, gamma, beta, eps, relu):
+    def forward(ctx, x, x3, weight, bias, geom, gamma, beta, eps, relu, lay_in=SPLIT_3C, lay_out=SPLIT_3C):
         require_gpu(x, x3, weight, bias, gamma, beta)
         stride, pt, pl, pb, pr, pad_mode = geom
         N, C, H, W = x.shape
         K, Cw, R, S = weight.shape
-        assert Cw == C and tuple(x3.shape) == (N, 3 * C, H, W) and x3.dtype == torch.bfloat16
+        Cx = pair_channels(C) if lay_in == SPLIT_PAIR else 3 * C
+        assert Cw == C and tuple(x3.shape) == (N, Cx, H, W) and x3.dtype == torch.bfloat16
         OH = (H + pt + pb - R) // stride + 1
         OW = (W + pl + pr - S) // stride + 1
         z = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
-        w3 = split_weights.get(weight, transposed=False)
-        flags = (1 << 1) | (1 << 2)
+        w3 = split_weights.get(weight, transposed=False, layout=lay_in)
+        flags = _exact_flags(lay_in, C)
         wsp, wsb = _ws(x)
-        wc = _wcache(w3, 0, (N, 3 * C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), HIFIC_BF16, flags, None)
-        call("hific_conv2d_fwd", ptr(x3), ptr(w3), None, ptr(bias), None, ptr(z), N, 3 * C, H, W, K, R, S, stride, pt, pl, pb,
+        wc = _wcache(w3, 0, (N, Cx, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), HIFIC_BF16, flags & 0xff, None)
+        call("hific_conv2d_fwd", ptr(x3), ptr(w3), None, ptr(bias), None, ptr(z), N, Cx, H, W, K, R, S, stride, pt, pl, pb,
              pr, pad_mode, lib.ACT_NONE, HIFIC_BF16, flags, wsp, wsb, *wc, stream())
         zb = torch.empty((N, K, OH, OW), dtype=torch.bfloat16, device=x.device)
         y = torch.empty_like(zb)
-        x3n = torch.empty((N, 3 * K, OH, OW), dtype=torch.bfloat16, device=x.device)
+        Kx = pair_channels(K) if lay_out == SPLIT_PAIR else 3 * K
+        x3n = torch.empty((N, Kx, OH, OW), dtype=torch.bfloat16, device=x.device)
         mean = torch.empty((N, OH * OW), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         call("hific_channelnorm_fwd_exact", ptr(z), ptr(gamma), ptr(beta), ptr(zb), ptr(y), ptr(x3n), ptr(mean), ptr(rstd),
-             N, K, OH * OW, float(eps), int(relu), stream())
+             N, K, OH * OW, float(eps), int(relu), lay_out, stream())
         ctx.geom, ctx.relu, ctx.has_bias = geom, int(relu), bias is not None
         ctx.w_slot, ctx.b_slot, ctx.g_slot, ctx.be_slot = _slot(weight), _slot(bias), _slot(gamma), _slot(beta)
         ctx.save_for_backward(x, weight, zb, gamma, beta, mean, rstd)
         ctx.mark_non_differentiable(x3n)
+        # x3n never receives a gradient: without this the engine would MATERIALISE a zero gradient for it in every backward
+        # (five fills of 23-377 MB per G-turn at batch 16 x 256^2: 0.1 ms and 0.73 GB of HBM writes for nothing)
+        ctx.set_materialize_grads(False)
         return y, x3n
 
     @staticmethod
     def backward(ctx, dy, _unused):
+        if dy is None:
+            return (None,) * 11
         x, weight, zb, gamma, beta, mean, rstd = ctx.saved_tensors
         stride, pt, pl, pb, pr, pad_mode = ctx.geom
         N, C, H, W = x.shape
@@ -932,19 +973,20 @@ class ExactConvNormFn(Function):
             else:
                 wgrad()
         _written(ctx.w_slot if want_w else None)
-        return dx, None, dw, db, None, dg, dbe, None, None
+        return dx, None, dw, db, None, dg, dbe, None, None, None, None
 
 
-def exact_conv_norm(x, x3, weight, bias, stride, pads, pad_mode, gamma, beta, eps, relu):
+def exact_conv_norm(x, x3, weight, bias, stride, pads, pad_mode, gamma, beta, eps, relu, lay_in=SPLIT_3C, lay_out=SPLIT_3C):
     pt, pl, pb, pr = pads
-    return ExactConvNormFn.apply(x.contiguous(), x3, weight, bias, (stride, pt, pl, pb, pr, pad_mode), gamma, beta, eps, relu)
+    return ExactConvNormFn.apply(x.contiguous(), x3, weight, bias, (stride, pt, pl, pb, pr, pad_mode), gamma, beta, eps, relu,
+                                 lay_in, lay_out)
 
 
-def split3_act(x):
-    """float32 [N,C,H,W] -> bf16 [N,3C,H,W] (hi, lo, hi): the operand image of the first exact convolution."""
+def split3_act(x, layout=SPLIT_3C):
+    """float32 [N,C,H,W] -> bf16 split image (see _split3_act): the operand of the first exact convolution."""
     if x.dtype != torch.float32:
         x = cast(x.contiguous(), torch.float32)
-    return _split3_act(x.contiguous())
+    return _split3_act(x.contiguous(), layout)
 
 
 def channel_norm(x, gamma, beta, eps=1e-3, relu=False, prev_bias=None):

@@ -14,7 +14,9 @@
  *       HIFIC_BF16 (1) bfloat16 storage, v_mfma_f32_32x32x16_bf16 (f32 accumulate)
  *     weights, biases, norm parameters, statistics, losses and all gradients of parameters are float32
  *   - `flags` on conv entry points, meaningful for HIFIC_BF16 only: bit0 = the input activation tensor is float32,
- *     bit1 = the output activation tensor is float32 (entropy-model boundary stays float32)
+ *     bit1 = the output activation tensor is float32 (entropy-model boundary stays float32); forward entry points only:
+ *     bit2 = C is the 3C split-bf16 reduction (hific_split3 which 0/1; profiler FLOP count only), bit3 = both operands are in
+ *     the pair layout (hific_split3 which 2; C = 2 * C16, native split kernel), bits 8.. = the layer's real channel count
  *   - thread-safe for distinct streams as long as the workspaces are distinct
  */
 #ifndef HIFIC_HIP_H
@@ -81,9 +83,12 @@ int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, 
 /* The norm between two split-bf16 convolutions of the exact-index chain (encoder.py:56-93 blocks in bf16 mode): z is the
  * float32 output of the exact convolution; writes zb = bf16(z) (for this norm's backward), y = bf16 of the float32 result
  * (the nominal activation of the bf16 autograd graph) and x3 [N,3C,HW] = (hi, lo, hi) of that result (operand of the next
- * exact convolution, hific_split3 layout).  Returns -4 when the shape has no register-resident configuration. */
+ * exact convolution, hific_split3 layout).  split_layout 0: x3 as above; 2: x3 is [N, 2 * C16, HW] in the pair layout of
+ * the native split kernels (hific_split3 which = 2).  Returns -4 when the shape has no register-resident configuration or
+ * a split image would exceed 2^31 elements per sample (callers then run the plain bf16 chain). */
 int hific_channelnorm_fwd_exact(const float* z, const float* gamma, const float* beta, void* zb, void* y, void* x3,
-                                float* mean, float* rstd, int N, int C, int HW, float eps, int relu, hipStream_t stream);
+                                float* mean, float* rstd, int N, int C, int HW, float eps, int relu, int split_layout,
+                                hipStream_t stream);
 size_t hific_channelnorm_bwd_ws_bytes(int N, int C, int HW);
 /* dprev_bias (nullable, f32 [C]): additionally (=|+= by accumulate_prev) sum_{n,hw} dx, i.e. the bias gradient of the
  * convolution whose output is x when this norm is its only consumer (encoder.py:56-93, generator.py:28-42,115-137): saves
@@ -108,7 +113,11 @@ int hific_cast(const void* a, int src_dtype, void* o, int dst_dtype, long long n
  * into the latent indices (src/hyperprior.py:68-74,108-122; src/network/encoder.py:104-111) runs its forward
  * contractions as x*w ~= xh*wh + xl*wh + xh*wl (hi = bf16(v), lo = bf16(v - hi)), i.e. over 3C reduction channels of the
  * ordinary bf16 kernels.  src f32 [outer][C][inner] -> dst [outer][3C][inner]; which 0 = activation layout (hi, lo, hi),
- * 1 = weight layout (hi, hi, lo); dst_dtype HIFIC_BF16 or HIFIC_F32 (values exactly bf16-representable). */
+ * 1 = weight layout (hi, hi, lo); dst_dtype HIFIC_BF16 or HIFIC_F32 (values exactly bf16-representable).
+ * which 2 = the PAIR layout of the native split kernels (round 4): dst [outer][2 * C16][inner], C16 = C rounded up to 16,
+ * source channel 16 g + j -> channels 32 g + j (hi) and 32 g + 16 + j (lo), padding channels zero; activations and weights
+ * alike.  A convolution whose flags carry bit 3 reads both operands in this layout and issues hi*hi + hi*lo + lo*hi per
+ * 16-channel slice pair itself: 2C instead of 3C staged channels for the same three MFMAs. */
 int hific_split3(const float* src, void* dst, long long outer, int C, long long inner, int which, int dst_dtype,
                  hipStream_t stream);
 int hific_axpby_f32(const float* a, const float* b, float* o, float alpha, float beta, long long n,
