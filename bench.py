@@ -599,6 +599,18 @@ def parity_leg(args, dev):
     sym = torch.round(inter.latents_quantized.float() - model.Hyperprior.debug_latent_means).cpu()
     got = dict(loss=float(losses["compression"]), n_bpp=float(inter.n_bpp), q_bpp=float(inter.q_bpp))
     rec = inter.reconstruction.float().cpu()
+    dec = inter.latents_quantized.detach().float()
+    rec_x = None
+    if args.dtype == "bf16":
+        # the exact-reconstruction option (ops.set_exact_reconstruction): the Generator on the same decoded latents, no-grad,
+        # split-bf16 contractions on float32 activations - what Model.decompress / the EVALUATION forward run under the option
+        hops.set_exact_reconstruction(True)
+        try:
+            with torch.no_grad():
+                rec_x = model.Generator(dec.contiguous()).float().cpu()
+        finally:
+            hops.set_exact_reconstruction(False)
+    dec = dec.cpu()
     del model, losses, inter
     hops.pack_cache.clear(); hops.split_weights.clear()
     torch.cuda.empty_cache()
@@ -624,10 +636,20 @@ def parity_leg(args, dev):
            "flips_by_more_than_one": int(((sym - sym_o).abs() > 1).sum()),
            "loss_rel": rel(got["loss"], float(out["compression"])), "nbpp_rel": rel(got["n_bpp"], float(hi.total_nbpp)),
            "qbpp_rel": rel(got["q_bpp"], float(hi.total_qbpp))}
-    if nflip == 0:
-        ref = out["reconstruction"]
-        res["reconstruction_rms_rel"] = float((rec - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-        res["reconstruction_max_rel"] = float((rec - ref).abs().max() / ref.abs().max())
+    # reconstruction GIVEN EQUAL INDICES (one flipped index moves a decoded latent by 1.0): the oracle Generator on the device's
+    # decoded latents when a rounding tie went the other way
+    ref = out["reconstruction"]
+    if nflip:
+        with torch.no_grad():
+            ref = O.generator_forward(sd, dec, margs.n_residual_blocks)
+    res["recon_rel"] = float((rec - ref).abs().max() / ref.abs().max())
+    res["recon_rms_rel"] = float((rec - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    if rec_x is not None:
+        res["recon_rel_exact_reconstruction_option"] = float((rec_x - ref).abs().max() / ref.abs().max())
+        res["recon_note"] = ("recon_rel: max |rec - rec_oracle| / max |rec_oracle| of the benchmarked mode (bf16 Generator "
+                             "activations); *_exact_reconstruction_option: the same latents through the Generator under "
+                             "hific_amd.set_exact_reconstruction(True) (no-grad forwards only: decompress / EVALUATION), the "
+                             "mode that meets north_star's 1e-3 on the reconstruction; its cost is fwd.exact_reconstruction_*")
     return {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in res.items()}
 
 
@@ -691,6 +713,7 @@ def main():
         rccl = {"backend": "nccl (RCCL)", "rccl_ranks": world,
                 "buckets": {k: len(r.buckets) for k, r in reducers.items()},
                 "bucket_mbytes": float(os.environ.get("HIFIC_BUCKET_MB", 128)),
+                "gradient_payload": next(iter(reducers.values())).payload,
                 "gradient_mbytes_per_step": {k: round(r.arena.numel * 4 / 2 ** 20, 1) for k, r in reducers.items()},
                 "exposed_comm_ms": round(float(t.item()), 3),
                 "exposed_comm_note": "GPU time per step the compute stream waits in BucketedGradReducer.finish() for "
@@ -800,6 +823,15 @@ def main():
             finally:
                 hific_ops.set_exact_index(True)
             out["fwd"]["plain_bf16_chain_ms_per_image"] = round(ef2 / max(args.steps, 10) / args.batch * 1e3, 4)
+            hific_ops.set_exact_reconstruction(True)             # the option that reconstructs within 1e-3 (parity.recon_rel_*)
+            try:
+                fwd(); fwd()
+                fwd3, _, _ = choose_launch(args, fwd, world, fence)
+                ef3 = timed(fwd3, max(args.steps, 10), 2, fence)
+                del fwd3
+            finally:
+                hific_ops.set_exact_reconstruction(False)
+            out["fwd"]["exact_reconstruction_ms_per_image"] = round(ef3 / max(args.steps, 10) / args.batch * 1e3, 4)
         del ev
         hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
         torch.cuda.empty_cache()

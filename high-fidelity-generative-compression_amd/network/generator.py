@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..normalisation import channel, instance
-from .layers import HipConv2d, HipConvTranspose2d
+from .layers import HipConv2d, HipConvTranspose2d, mark_exact_reconstruction
 
 
 def _norm_factory(channel_norm):
@@ -80,6 +80,8 @@ class Generator(nn.Module):
             nn.Identity(),
             HipConv2d(filters[-1], 3, (7, 7), stride=1, pads=(3, 3, 3, 3), pad_mode="reflect"),
         )
+        # EVALUATION option (ops.set_exact_reconstruction): no-grad forwards with split-bf16 operands, float32 activations
+        mark_exact_reconstruction(self)
 
     def _draw_noise(self, shape):
         return torch.randn(shape)

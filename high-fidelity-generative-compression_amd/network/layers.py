@@ -2,6 +2,7 @@
 state_dict keys) but whose forward runs the gfx950 implicit-GEMM kernels (csrc/gconv.hip)."""
 import os
 
+import torch
 import torch.nn as nn
 
 from .. import ops, lib
@@ -19,6 +20,7 @@ class HipConv2d(nn.Conv2d):
         self.act = act
         self.out_f32 = out_f32
         self.exact_index_chain = False     # set by the owner: this layer feeds the floor() of the latent indices
+        self.exact_recon = False           # set by the owner (Generator): split-bf16 forward under ops.set_exact_reconstruction
         self.bias_grad_in_norm = False     # set by normalisation.channel.fuse_bias_grad: the norm behind this layer owns db
 
     def forward(self, x):
@@ -40,6 +42,7 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
         self.act = act
         self.out_f32 = out_f32
         self.exact_index_chain = False
+        self.exact_recon = False
         self.bias_grad_in_norm = False
 
     def forward(self, x):
@@ -54,10 +57,22 @@ _PAIR_HYPER = os.environ.get("HIFIC_EXACT_PAIR_HYPER", "1") not in ("0", "")
 
 def _exact_mode(m):
     """False (plain bf16), True (split operands over 3C channels) or "pair" (native split kernel) for layer m's forward."""
-    if not (m.exact_index_chain and ops.exact_index_on()):
+    chain = m.exact_index_chain and ops.exact_index_on()
+    # exact-reconstruction option: the Generator's layers in no-grad forwards (ops.set_exact_reconstruction)
+    recon = m.exact_recon and ops.exact_reconstruction_on() and not torch.is_grad_enabled()
+    if not (chain or recon):
         return False
     pair = _PAIR_HYPER and ops.exact_pair_on() and m.stride[0] == 2 and m.in_channels >= 32
     return "pair" if pair else True
+
+
+def mark_exact_reconstruction(module, on=True):
+    """Every conv of `module` (the Generator) runs its NO-GRAD forward with split-bf16 operands when
+    ops.set_exact_reconstruction(True) is in effect (bf16 compute mode)."""
+    for m in module.modules():
+        if isinstance(m, (HipConv2d, HipConvTranspose2d)):
+            m.exact_recon = bool(on)
+    return module
 
 
 def mark_exact_index_chain(module, on=True):

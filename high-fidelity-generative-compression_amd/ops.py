@@ -305,6 +305,23 @@ def exact_index_on():
     return _EXACT_INDEX
 
 
+# Exact-reconstruction option: north_star asks for reconstructions within 1e-3 of the reference;
+# with bf16 activations through 24 Generator convolutions + 25 ChannelNorms the reconstruction given equal indices is 1.3e-2
+# off.  With this option every NO-GRAD Generator forward (Model.decompress, the EVALUATION forward: src/model.py:312-344,
+# 357-366) runs its contractions with split-bf16 operands and keeps float32 activations, like the exact-index chain.
+# Off by default (the forward costs ~2x); HIFIC_EXACT_RECON=1 / hific_amd.set_exact_reconstruction(True).
+_EXACT_RECON = os.environ.get("HIFIC_EXACT_RECON", "0") not in ("0", "")
+
+
+def set_exact_reconstruction(on):
+    global _EXACT_RECON
+    _EXACT_RECON = bool(on)
+
+
+def exact_reconstruction_on():
+    return _EXACT_RECON
+
+
 class exact_index_suspended:
     """`with ops.exact_index_suspended():` - the plain bf16 chain for the calls inside (restores the previous setting)."""
 

@@ -24,6 +24,13 @@ arrives after its bucket has been reduced cannot be repaired (the other ranks' c
 it raises instead of training on a silently wrong gradient.  Arenas whose write pattern is not fixed (the
 Discriminator's slots are written by the G-turn and the D-turn of one optimizer step) use eager=False: everything is
 reduced in finish().
+
+Gradient payload (round 4): `payload="bf16"` ($HIFIC_GRAD_PAYLOAD=bf16) halves the bytes on the xGMI ring - a sealed bucket is
+rounded to bfloat16 into a persistent staging buffer (on the reduce stream, hific_cast), the staging slice is all-reduced, and
+finish() converts the sums back into the float32 gradient arena before Adam reads it, so the optimizer state and the
+accumulation over steps stay float32.  Error per element: one rounding of each rank's term (2^-9 |g_r|) plus one rounding per
+addition of the reduction; tests/test_ddp_gloo.py bounds the two-rank result by 2^-7 sum_r |g_r| element-wise.  The default
+stays float32 (bit-identical to the sum of the shards).  DESIGN.md section 6 has the per-bucket time model.
 """
 import os
 
@@ -35,9 +42,15 @@ _NONBLOCK = os.environ.get("HIFIC_REDUCE_NONBLOCK", "1") not in ("0", "")
 
 
 class BucketedGradReducer:
-    def __init__(self, arena, bucket_mbytes=128, process_group=None, eager=True, expected_writes=None):
-        """expected_writes: {parameter or slot index: writes per backward} for slots written more than once."""
+    def __init__(self, arena, bucket_mbytes=128, process_group=None, eager=True, expected_writes=None, payload=None):
+        """expected_writes: {parameter or slot index: writes per backward} for slots written more than once.
+        payload: "f32" (default) or "bf16" (module docstring); $HIFIC_GRAD_PAYLOAD when None."""
         self.arena = arena
+        payload = payload or os.environ.get("HIFIC_GRAD_PAYLOAD", "f32")
+        if payload not in ("f32", "bf16"):
+            raise ValueError("gradient payload must be 'f32' or 'bf16'")
+        self.payload = payload
+        self.stage = None            # bf16 staging image of the gradient arena (allocated on first use)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         bucket_mbytes = float(os.environ.get("HIFIC_BUCKET_MB", bucket_mbytes))
@@ -78,11 +91,32 @@ class BucketedGradReducer:
         self.remaining = [b[2] for b in self.buckets]      # slots of each bucket still short of their write count
         self.launched = [False] * len(self.buckets)
 
+    def _to_stage(self, lo, hi):
+        """float32 gradient slice -> bf16 staging slice (the tensor that goes on the wire); runs on the current stream."""
+        if self.stage is None:
+            self.stage = torch.empty(self.arena.numel, dtype=torch.bfloat16, device=self.arena.flat_grad.device)
+        src, dst = self.arena.flat_grad[lo:hi], self.stage[lo:hi]
+        if src.is_cuda:
+            from . import lib
+            lib.call("hific_cast", src.data_ptr(), lib.HIFIC_F32, dst.data_ptr(), lib.HIFIC_BF16, hi - lo, lib.stream())
+        else:
+            dst.copy_(src)
+        return dst
+
+    def _from_stage(self, lo, hi):
+        src, dst = self.stage[lo:hi], self.arena.flat_grad[lo:hi]
+        if src.is_cuda:
+            from . import lib
+            lib.call("hific_cast", src.data_ptr(), lib.HIFIC_BF16, dst.data_ptr(), lib.HIFIC_F32, hi - lo, lib.stream())
+        else:
+            dst.copy_(src)
+
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self.launched[b] = True
         grad = self.arena.flat_grad[lo:hi]
         from . import ops
+        bf16 = self.payload == "bf16"
         if grad.is_cuda and _NONBLOCK:
             # The bucket's gradients were written by kernels on up to three streams (main, side = weight gradients, branch);
             # all of them are enqueued by now.  A dedicated reduce stream waits for those streams' current positions and the
@@ -93,11 +127,14 @@ class BucketedGradReducer:
             for st in ops.producer_streams(dev):
                 red.wait_stream(st)
             with torch.cuda.stream(red):
-                self.works.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                wire = self._to_stage(lo, hi) if bf16 else grad
+                self.works.append(dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             return
         # the collective is ordered after the CURRENT stream: bring the side / branch streams in
-        ops.join_side_stream()
-        self.works.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        if grad.is_cuda:
+            ops.join_side_stream()
+        wire = self._to_stage(lo, hi) if bf16 else grad
+        self.works.append(dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _on_write(self, slot):
         i = slot.index
@@ -127,6 +164,9 @@ class BucketedGradReducer:
                 e0 = torch.cuda.Event(enable_timing=True); e0.record(cur)
             for w in self.works:
                 w.wait()
+            if self.payload == "bf16":
+                # the sums come home: bf16 staging image -> float32 gradient arena (ONE pass over the arena; Adam reads float32)
+                self._from_stage(0, self.arena.numel)
             if timed:
                 e1 = torch.cuda.Event(enable_timing=True); e1.record(cur)
                 self._ev_pairs.append((e0, e1))

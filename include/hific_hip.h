@@ -18,6 +18,13 @@
  *     bit2 = C is the 3C split-bf16 reduction (hific_split3 which 0/1; profiler FLOP count only), bit3 = both operands are in
  *     the pair layout (hific_split3 which 2; C = 2 * C16, native split kernel), bits 8.. = the layer's real channel count
  *   - thread-safe for distinct streams as long as the workspaces are distinct
+ *   - NO collective entry point (SURVEY section 8b proposed `hific_allreduce_bucket`): the data-parallel exchange is one
+ *     all-reduce per contiguous gradient-arena slice, which is exactly ncclAllReduce(ptr, count, dtype, sum, comm, stream) -
+ *     a C-ABI wrapper would add a second owner of the RCCL communicator next to torch.distributed (the process-group
+ *     plumbing the brief assigns to PyTorch) and nothing else.  What the library contributes to that step is the
+ *     float32 <-> bfloat16 wire conversion of a bucket (hific_cast, hific_amd.parallel payload="bf16") and the 1/world
+ *     scale folded into hific_adam_apply (grad_scale).  A host that does not use torch binds ncclAllReduce directly on the
+ *     same pointers ("data-parallel step").
  */
 #ifndef HIFIC_HIP_H
 #define HIFIC_HIP_H

@@ -120,6 +120,62 @@ def test_multiwrite_slots_and_global_rate_branch_world2(hific):
     assert all(r[1] == "ok" for r in res), res
 
 
+def _worker_bf16_payload(rank, world, port, q):
+    """payload="bf16": the wire carries bfloat16, the arena gets float32 sums back; element-wise
+    |result - sum_r g_r| <= 2^-7 sum_r |g_r| (one rounding per term, one per addition), and exactly-representable gradients
+    (small integers) come back exact."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hific_amd import optim, parallel
+        sizes = (300, 70000, 5, 130000, 64)
+        ps = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+        arena = optim.ParamArena(ps)
+        for eager in (True, False):
+            red = parallel.BucketedGradReducer(arena, bucket_mbytes=0.25, eager=eager, payload="bf16")
+            assert red.payload == "bf16" and len(red.buckets) >= 3
+            for it in range(2):
+                gs = {r: [torch.randn(n, generator=torch.Generator().manual_seed(1000 * it + 10 * r + i)) * 10.0 ** (i - 2)
+                          for i, n in enumerate(sizes)] for r in range(world)}
+                for i in reversed(range(len(ps))):
+                    s = ps[i]._hific_slot
+                    assert s.take() == 0
+                    s.grad.copy_(gs[rank][i] if it == 0 else torch.full((sizes[i],), float(rank + 2 + i)))
+                    s.written()
+                assert red.finish() == 1.0 / world
+                for i, p in enumerate(ps):
+                    assert p.grad.dtype == torch.float32
+                    if it == 0:
+                        exact = sum(gs[r][i].double() for r in range(world))
+                        bound = 2.0 ** -7 * sum(gs[r][i].abs().double() for r in range(world)) + 1e-30
+                        assert bool(((p.grad.double() - exact).abs() <= bound).all()), (eager, i)
+                        assert float((p.grad.double() - exact).abs().max()) > 0.0 or sizes[i] < 10   # it WAS rounded
+                    else:
+                        assert torch.equal(p.grad, torch.full_like(p.grad, float(sum(r + 2 + i for r in range(world)))))
+                arena.zero_grad()
+            arena.on_write = None
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_gradient_payload_world2(hific):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_worker_bf16_payload, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
+
+
 @pytest.mark.parametrize("eager", [True, False])
 def test_bucketed_allreduce_world2(hific, eager):
     ctx = mp.get_context("spawn")

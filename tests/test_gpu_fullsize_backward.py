@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from oracle import hific_oracle as O
-from gradcheck import check_grads
+from gradcheck import check_grads, relu_trace
 
 pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 
@@ -136,7 +136,8 @@ def test_gan_cycle_every_gradient_fullsize_f32(hific, dev):
                    uv={k: v.detach() for k, v in out["new_uv"].items()})
         return res
 
-    o32 = oracle_cycle(torch.float32)
+    with relu_trace(O) as trace:                     # pre-activations of every ReLU / LeakyReLU of the float32 oracle run
+        o32 = oracle_cycle(torch.float32)
     assert abs(loss_G - o32["loss_G"]) < 1e-3 * abs(o32["loss_G"]) and abs(loss_D - o32["loss_D"]) < 1e-3 * abs(o32["loss_D"])
     cache = {}
 
@@ -145,8 +146,9 @@ def test_gan_cycle_every_gradient_fullsize_f32(hific, dev):
             cache.update(oracle_cycle(torch.float64))
         return cache
 
-    worst_G, arb_G = check_grads(dev_G, o32["G"], lambda: o64()["G"], 1e-3, "G-turn, all parameters")
-    worst_D, arb_D = check_grads(dev_D, o32["D"], lambda: o64()["D"], 1e-3, "D-turn, Discriminator (G-turn leftovers + D-turn)")
+    worst_G, arb_G = check_grads(dev_G, o32["G"], lambda: o64()["G"], 1e-3, "G-turn, all parameters", trace=trace)
+    worst_D, arb_D = check_grads(dev_D, o32["D"], lambda: o64()["D"], 1e-3, "D-turn, Discriminator (G-turn leftovers + D-turn)",
+                                 trace=trace)
     for k, v in o32["uv"].items():
         assert torch.allclose(uv_dev[k], v, atol=1e-5), k
     print(f"  full-size f32 gradients vs oracle: worst G-turn {worst_G:.2e}, worst D-turn {worst_D:.2e}; beyond the plain "
@@ -186,14 +188,16 @@ def test_config5_one_1024_crop_regime_high(hific, dev):
         out["compression"].backward()
         return out, {k: sdr[k].grad.detach() for k in r32["grads"]}
 
-    out, g32 = oracle(torch.float32)
+    with relu_trace(O) as trace:
+        out, g32 = oracle(torch.float32)
     for name, a, b in (("compression", r32["loss"], float(out["compression"])), ("disc", r32["disc"], float(out["disc"])),
                        ("n_bpp", r32["n_bpp"], float(out["hyperinfo"].total_nbpp)),
                        ("q_bpp", r32["q_bpp"], float(out["hyperinfo"].total_qbpp))):
         assert abs(a - b) < 1e-3 * abs(b), (name, a, b)
     rec_ref = out["reconstruction"].detach()
     assert float((r32["rec"] - rec_ref).abs().max()) < 1e-3 * float(rec_ref.abs().max())
-    _, arb = check_grads(r32["grads"], g32, lambda: oracle(torch.float64)[1], 1e-3, "config 5, f32, all parameters")
+    _, arb = check_grads(r32["grads"], g32, lambda: oracle(torch.float64)[1], 1e-3, "config 5, f32, all parameters",
+                         trace=trace)
     assert len(arb) <= 8
     # the benchmarked mode at this shape: finite, bit-reproducible, same rate decision, aggregates near the f32 run
     b1, b2 = run(torch.bfloat16), run(torch.bfloat16)
