@@ -132,7 +132,8 @@ __device__ __forceinline__ void px_decode(int q, int npatch, int npp, int PW, fl
 // round trip per 64 pixels (a 645-pixel stride-2 halo patch = 11 serialised round trips per channel chunk: measured
 // 166 of the 198 us of the 60->120 stride-2 layer).  Kernels that run one workgroup per CU anyway (full-LDS tiles)
 // have 512 VGPRs per lane to spend and use QB = 12: up to 768 pixels x 16 loads in flight, one round trip per chunk.
-template <typename T, int DWR, int PITCH, bool SF32, int QB>
+// W8: 512-thread workgroups (gconv_mp_kernel) - waves 4..7 take the odd 64-pixel groups with the dword split of waves 0..3.
+template <typename T, int DWR, int PITCH, bool SF32, int QB, bool W8 = false>
 __device__ __forceinline__ void stage_T_impl(unsigned char* lds, const void* src, int N, int C, int H, int W, int bmode,
                                              int n0, int NI, int y0, int x0, int PH, int PW, int c0, int tid, int PWs) {
     // Thread (lane, wave) handles patch pixels q = lane + 64*j and dwords dw = wave + 4*i: the pixel is decoded once
@@ -144,10 +145,10 @@ __device__ __forceinline__ void stage_T_impl(unsigned char* lds, const void* src
     const int npp = PH * PW;
     const int npatch = NI * npp;
     const unsigned plane = (unsigned)(H * W);
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = W8 ? ((tid >> 6) & 3) : (tid >> 6);
     const float inv_npp = 1.0f / (float)npp, inv_pw = 1.0f / (float)PW;
     const bool full = c0 + BCH <= C;
-    for (int q0 = lane; q0 < npatch; q0 += 64 * QB) {
+    for (int q0 = lane + (W8 ? 64 * QB * (tid >> 8) : 0); q0 < npatch; q0 += 64 * QB * (W8 ? 2 : 1)) {
         unsigned qoff[QB]; bool ok[QB]; int qs[QB];
         unsigned lo[QB][NDW], hi[QB][NDW];
 #pragma unroll
@@ -161,16 +162,16 @@ __device__ __forceinline__ void stage_T_impl(unsigned char* lds, const void* src
                 px_store<T, NDW, SF32>(lds + (size_t)qs[b] * PITCH + wv * 4, lo[b], hi[b], ok[b], C, c0, wv, full);
     }
 }
-template <typename T, int DWR, int PITCH, int QB = 1>
+template <typename T, int DWR, int PITCH, int QB = 1, bool W8 = false>
 __device__ __forceinline__ void stage_T(unsigned char* lds, const void* src, int src_f32,
                                         int N, int C, int H, int W, int bmode,
                                         int n0, int NI, int y0, int x0, int PWs, int PH, int PW,
                                         int c0, int tid, int nthreads) {
     if (PWs < PW) PWs = PW;
     if (std::is_same<T, float>::value || src_f32)
-        stage_T_impl<T, DWR, PITCH, true, QB>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
+        stage_T_impl<T, DWR, PITCH, true, QB, W8>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
     else
-        stage_T_impl<T, DWR, PITCH, false, QB>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
+        stage_T_impl<T, DWR, PITCH, false, QB, W8>(lds, src, N, C, H, W, bmode, n0, NI, y0, x0, PH, PW, c0, tid, PWs);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -724,6 +725,229 @@ void gconv_kernel(const GcParams p) {
     }
     gc_epilogue<std::is_same<T, float>::value, WM, WN, -1>(p, ph, acc[0][0], acc[0][WN - 1], acc[WM - 1][0], acc[WM - 1][WN - 1],
                                                         m0 + wm * WM * 32, lhi, pu, pv, pn, pvalid);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Merged-phase kernel for the stride-2 TRANSPOSED structure (round 4): conv-transpose forward and the data gradient of a
+// stride-2 convolution are four sub-pixel phases (py, px) over the same (u, v) input domain.  gconv_kernel runs them as four
+// workgroups per tile (blockIdx.z): each stages the SAME halo patch, and each writes every other pixel of every other
+// output row - 2-byte stores at a 4-byte stride.  Timing ablation of 60 <- 120 @128 -> 256 (tools/micro_conv.py, HIFIC_DBG):
+// of 273 us, staging 88, epilogue 74, launch + barriers of the 8192 workgroups 54, MFMA + fragment reads 29, weights 12.
+// Here ONE workgroup owns a (u, v) tile for the two column phases of an output row parity: the union halo patch is staged once
+// per channel chunk for both, their taps stream through the same weight ring as one step sequence (accumulator set chosen by a
+// uniform branch per step: the set index must be a compile-time constant or the accumulators go to scratch), and the epilogue
+// writes the two column phases of a pixel as ONE 4-byte (bf16) / 8-byte (f32) store: 32 lanes = 128 contiguous bytes.  64-row
+// tiles, 64-channel chunks, two workgroups per CU, grid.z = 2 (row parity).
+// p.ph[0..3]: the phases (py-major, as the planners emit them); p.ph[4]: union patch / tile grid (host); p.epi_wide == 2:
+// pair stores are legal (no fold / residual, even output width, both column phases of a row have the same domain).
+// SPLIT: operands in the pair layout of the exact-index chain (see gconv_kernel).
+template <bool F32>
+__device__ __forceinline__ void mp_store_pair(const GcParams& p, const GcPhase& phA, const f32x16_t a, const f32x16_t b,
+                                              int mbase, int lhi, int pu_, int pv_, int pn_, bool pvalid_, bool hb,
+                                              const float* bp, float slope) {
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        bv[r] = bp[(hb && m < p.K) ? m : 0];
+    }
+    const int oy = pu_ * 2 + phA.ooy, ox = pv_ * 2 + phA.oox;
+    const bool okp = pvalid_ && pn_ < p.N && pu_ < phA.OHt && pv_ < phA.OWt && (unsigned)oy < (unsigned)p.OHf &&
+                     (unsigned)(ox + 1) < (unsigned)p.OWf;
+    if (!okp) return;
+    const size_t plane = (size_t)p.OHf * p.OWf;
+    const size_t pbase = (size_t)pn_ * p.K * plane + (size_t)oy * p.OWf + ox;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float b_ = (hb && m < p.K) ? bv[r] : 0.f;
+        float x0 = a[r] + b_, x1 = b[r] + b_;
+        x0 = x0 > 0.f ? x0 : x0 * slope;
+        x1 = x1 > 0.f ? x1 : x1 * slope;
+        if (m < p.K) {
+            const size_t idx = pbase + (size_t)m * plane;
+            if constexpr (F32) *(float2*)((float*)p.out + idx) = make_float2(x0, x1);
+            else *(unsigned*)((bf16_t*)p.out + idx) = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+        }
+    }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gconv_mp_kernel(const GcParams p) {
+    // A workgroup owns the two COLUMN phases (py, 0), (py, 1) of its tile (py = blockIdx.z): 4 waves as 2 x 2, two pixel
+    // fragments per wave and phase = 64 accumulator registers.  (All four phases in one workgroup - 128 accumulator registers
+    // on four waves, or 64 on eight waves at four waves per SIMD - spilled an accumulator fragment in every step on this
+    // compiler; the row-pair form stages the patch twice instead of four times and keeps the pair stores.)
+    constexpr int BC = 64, KS = 16, PITCH = 144, DWR = 32, PPR = 8, BM = 64, WN = 2, WGN = 2;
+    constexpr int WBYTES = BM * PITCH;
+    constexpr int NWP = 2;                          // 16-byte weight pieces per thread per step (64 rows x 8 pieces / 256)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const GcPhase& U = p.ph[4];
+    const int py2 = (int)blockIdx.z * 2;
+    const GcPhase& PA = p.ph[py2];
+    const GcPhase& PB = p.ph[py2 + 1];
+    const int ntile = p.tiles_n * U.tiles_y * U.tiles_x;
+    int tile, mtile;
+    {
+        const int nwg = gridDim.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int q = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        mtile = q / p.max_tiles;
+        tile = q - mtile * p.max_tiles;
+    }
+    if (tile >= ntile) return;
+    const int tx = tile % U.tiles_x;
+    const int ty = (tile / U.tiles_x) % U.tiles_y;
+    const int tn = tile / (U.tiles_x * U.tiles_y);
+    const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
+    const int m0 = mtile * BM;
+    const int PH = U.PH, PW = U.PW, PWs = U.PWs;
+    const int npps = PH * PWs;
+    const int iy0 = u0 + U.dy_min, ix0 = v0 + U.dx_min;
+    // the taps of the two phases are contiguous in the tap table: [gt0, gt0 + T), the first t1 of them belong to phase A
+    const int gt0 = PA.tap0, t1 = PA.ntaps, T = PA.ntaps + PB.ntaps;
+
+    int* toffs = (int*)smem;
+    unsigned char* wbuf = smem + 512;
+    unsigned char* patch = wbuf + 2 * WBYTES;
+    if (tid < T) toffs[tid] = ((int)p.tap_dy[gt0 + tid] - U.dy_min) * PWs + ((int)p.tap_dx[gt0 + tid] - U.dx_min);
+
+    int qb[WN], pu[WN], pv[WN], pn[WN];
+    bool pvalid[WN];
+    const int thw = p.TH * p.TW;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int pt = (wn * WN + ni) * 32 + l31;
+        const int img = pt / thw;
+        const int rem = pt - img * thw;
+        const int ty_ = rem / p.TW;
+        const int tx_ = rem - ty_ * p.TW;
+        const bool v = img < p.NI;
+        pvalid[ni] = v;
+        qb[ni] = v ? (img * npps + ty_ * PWs + tx_) : 0;
+        pu[ni] = u0 + ty_; pv[ni] = v0 + tx_; pn[ni] = n0 + img;
+    }
+    f32x16_t acc0[WN], acc1[WN];
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[ni][r] = 0.f; acc1[ni][r] = 0.f; }
+
+    const int nchunks = p.Cpad / BC;
+    const int nsteps = nchunks * T;
+    // per-phase weight images [Kpad][ntaps_ph][Cpad]: base and row pitch in scalars; 32-bit byte offsets (far below 4 GB)
+    const unsigned char* wpb = (const unsigned char*)p.wp;
+    const unsigned b0 = (unsigned)PA.wp_off * 2u, b1 = (unsigned)PB.wp_off * 2u;
+    const unsigned r0 = (unsigned)(PA.ntaps * p.Cpad * 2), r1 = (unsigned)(PB.ntaps * p.Cpad * 2);
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t wA[NWP], wB[NWP];
+    // piece i of a thread: row tid / 8 + 32 i, 16-byte part tid % 8
+    const unsigned wp16 = (unsigned)((tid & 7) * 16);
+    const unsigned wlds0 = (unsigned)((tid >> 3) * PITCH) + wp16;
+    unsigned wmrow[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int wrow = (tid >> 3) + 32 * i;
+        wmrow[i] = (unsigned)(m0 + wrow < p.K ? m0 + wrow : p.K - 1);           // padded rows re-read row K-1 (never stored)
+    }
+#define MP_WLOAD(R, S_)                                                                     \
+    do {                                                                                    \
+        int s_ = (S_) < nsteps ? (S_) : nsteps - 1;                                         \
+        const int c_ = s_ / T;                                                              \
+        const int g_ = s_ - c_ * T;                                                         \
+        const unsigned base_ = g_ < t1 ? b0 : b1;                                           \
+        const unsigned rowb_ = g_ < t1 ? r0 : r1;                                           \
+        const int tl_ = g_ < t1 ? g_ : g_ - t1;                                             \
+        const unsigned off_ = base_ + (unsigned)(tl_ * p.Cpad + c_ * BC) * 2u;              \
+        _Pragma("unroll") for (int i = 0; i < NWP; ++i)                                     \
+            R[i] = *(const u32x4_t*)(wpb + (off_ + wmrow[i] * rowb_ + wp16));               \
+    } while (0)
+#define MP_WSTORE(R, BUF)                                                                   \
+    do {                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NWP; ++i)                                     \
+            *(u32x4_t*)((BUF) + wlds0 + i * 32 * PITCH) = R[i];                             \
+    } while (0)
+#define MP_COMPUTE(ACC, wb, toff)                                                                               \
+    do {                                                                                                        \
+        const unsigned char* arow = (wb) + (wm * 32 + l31) * PITCH;                                             \
+        if constexpr (!SPLIT) {                                                                                 \
+            _Pragma("unroll") for (int kk = 0; kk < BC / KS; ++kk) {                                            \
+                const bf16x8_t a = *(const bf16x8_t*)(arow + kk * 32 + lhi * 16);                               \
+                _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                             \
+                    const bf16x8_t b = *(const bf16x8_t*)(patch + (size_t)(qb[ni] + (toff)) * PITCH + kk * 32 + lhi * 16); \
+                    ACC[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, ACC[ni], 0, 0, 0);                  \
+                }                                                                                               \
+            }                                                                                                   \
+        } else {                                                                                                \
+            _Pragma("unroll") for (int kk = 0; kk < BC / KS; kk += 2) {                                         \
+                const bf16x8_t a = *(const bf16x8_t*)(arow + kk * 32 + lhi * 16);                               \
+                const bf16x8_t al = *(const bf16x8_t*)(arow + (kk + 1) * 32 + lhi * 16);                        \
+                _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) {                                             \
+                    const bf16x8_t b = *(const bf16x8_t*)(patch + (size_t)(qb[ni] + (toff)) * PITCH + kk * 32 + lhi * 16); \
+                    const bf16x8_t bl = *(const bf16x8_t*)(patch + (size_t)(qb[ni] + (toff)) * PITCH + (kk + 1) * 32 + lhi * 16); \
+                    ACC[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, ACC[ni], 0, 0, 0);                 \
+                    ACC[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, ACC[ni], 0, 0, 0);                 \
+                    ACC[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, ACC[ni], 0, 0, 0);                  \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    } while (0)
+#define MP_STEP(s, RL, RS)                                                                  \
+    do {                                                                                    \
+        if (g == 0) {                                                                       \
+            __syncthreads();                                                                \
+            stage_T<bf16_t, DWR, PITCH, 2>(patch, p.in, 0, p.N, p.C, p.IH, p.IW, p.bmode, n0, p.NI, iy0, ix0, PWs, \
+                                           PH, PW, chunk * BC, tid, 256);                   \
+        }                                                                                   \
+        __syncthreads();                                                                    \
+        MP_WLOAD(RL, (s) + 2);                                                              \
+        const int toff = toffs[g];                                                          \
+        const unsigned char* wb_ = wbuf + ((s) & 1) * WBYTES;                               \
+        if (g < t1) MP_COMPUTE(acc0, wb_, toff);                                            \
+        else MP_COMPUTE(acc1, wb_, toff);                                                   \
+        MP_WSTORE(RS, wbuf + (((s) + 1) & 1) * WBYTES);                                     \
+        if (++g == T) { g = 0; ++chunk; }                                                   \
+    } while (0)
+
+    if (nsteps > 0) {
+        MP_WLOAD(wA, 0);
+        MP_WLOAD(wB, 1);
+        MP_WSTORE(wA, wbuf);
+        int chunk = 0, g = 0, s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            MP_STEP(s, wA, wB);
+            MP_STEP(s + 1, wB, wA);
+        }
+        if (s < nsteps) MP_STEP(s, wA, wB);
+    }
+#undef MP_STEP
+#undef MP_COMPUTE
+#undef MP_WSTORE
+#undef MP_WLOAD
+    const int mbase = m0 + wm * 32;
+    if (p.epi_wide == 2) {
+        const bool hb = p.bias != nullptr;
+        const float* bp = hb ? p.bias : (const float*)p.in;
+        const float slope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LEAKY ? 0.2f : 1.f);
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            if (p.out_f32)
+                mp_store_pair<true>(p, PA, acc0[ni], acc1[ni], mbase, lhi, pu[ni], pv[ni], pn[ni], pvalid[ni], hb, bp, slope);
+            else
+                mp_store_pair<false>(p, PA, acc0[ni], acc1[ni], mbase, lhi, pu[ni], pv[ni], pn[ni], pvalid[ni], hb, bp, slope);
+        }
+        return;
+    }
+    gc_epilogue<false, 1, WN, -1>(p, PA, acc0[0], acc0[1], acc0[0], acc0[1], mbase, lhi, pu, pv, pn, pvalid);
+    gc_epilogue<false, 1, WN, -1>(p, PB, acc1[0], acc1[1], acc1[0], acc1[1], mbase, lhi, pu, pv, pn, pvalid);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2532,6 +2756,26 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             }
         }
     }
+    // Merged-phase kernel (gconv_mp_kernel): the four phases of a stride-2 transposed structure in one workgroup per (u, v)
+    // tile.  Where the software-pipelined phase-merged kernel above applies (>= 4 channel chunks, small planes) that one stays.
+    bool mp = false;
+    if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
+        // (K <= 32: a 64-row tile would be mostly padding - the 15-channel data gradient of the Discriminator's first layer ran
+        //  252 -> 291 us on it)
+        if (!phs && p.nphase == 4 && p.ist == 1 && p.ost == 2 && p.K > 32 && !p.rfx && !p.resid && !p.csplit && !p.msplit &&
+            !p.in_f32 && env_int("HIFIC_MP", 1)) {
+            mp = true;
+            int nt_ = 0;
+            for (int i = 0; i < 4; ++i) { if (p.ph[i].tap0 != nt_ || p.ph[i].ntaps < 1) mp = false; nt_ += p.ph[i].ntaps; }
+            if (nt_ > GC_MAXTAPS) mp = false;
+            for (int t = 0; t < nt_ && mp; ++t) {
+                const int dy = p.tap_dy[t], dx = p.tap_dx[t];
+                if (t == 0) { u_dymin = u_dymax = dy; u_dxmin = u_dxmax = dx; }
+                if (dy < u_dymin) u_dymin = dy; if (dy > u_dymax) u_dymax = dy;
+                if (dx < u_dxmin) u_dxmin = dx; if (dx > u_dxmax) u_dxmax = dx;
+            }
+        }
+    }
     // M tile
     int bm;
     {
@@ -2541,7 +2785,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         else bm = 128;
         int e = env_int("HIFIC_BM", 0);
         if ((e == 64 || e == 128) && p.K > 32) bm = e;
-        if (phs) bm = 64;
+        if (phs || mp) bm = 64;
     }
     p.Kpad = cdiv(p.K, bm) * bm;
     p.Cpad = cdiv(p.C, BC) * BC;
@@ -2567,7 +2811,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         est_grid += cdivl((long long)p.N * p.ph[i].OHt * p.ph[i].OWt, GC_NPIX) * cdiv(p.K, 64);
     const bool small_grid = est_grid < 256 && !env_int("HIFIC_NO_TPS_SMALL", 0);
     // ... and with >= 25 taps, 32-row tiles: twice the workgroups, and a 4 KB weight tile per tap lets 7 taps share a step
-    if (small_grid && maxtaps >= 25 && bm == 64 && !phs && std::is_same<T, bf16_t>::value && BC == 64 &&
+    if (small_grid && maxtaps >= 25 && bm == 64 && !phs && !mp && std::is_same<T, bf16_t>::value && BC == 64 &&
         !env_int("HIFIC_NO_TPS", 0) && !env_int("HIFIC_BM", 0)) {
         bm = 32; p.Kpad = cdiv(p.K, bm) * bm;
     }
@@ -2597,7 +2841,25 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             for (int i = 0; i < p.nphase; ++i) { if (p.ph[i].PH > span_y) span_y = p.ph[i].PH; if (p.ph[i].PW > span_x) span_x = p.ph[i].PW; }
         }
     }
-    if (!phs && choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, tile_budget, p.TH, p.TW, p.NI, maxtaps)) {
+    if (mp) {
+        // one union patch, one tap per step, tiles small enough for two co-resident workgroups
+        tps = 1; wbytes = 512 + 2 * bm * PITCH;
+        span_y = u_dymax - u_dymin + 1; span_x = u_dxmax - u_dxmin + 1;
+        int nt_all = 0;
+        for (int i = 0; i < 4; ++i) nt_all += p.ph[i].ntaps;
+        // (launches that cannot give every CU a workgroup - the hyperprior's 4x4 .. 16x16 planes - keep the per-phase grid and its
+        //  split-K: a quarter of the workgroups with four times the serial steps is the wrong trade there)
+        if (choose_tile(p.N, OHt, OWt, 1, span_y, span_x, PITCH, wbytes, 76 * 1024, p.TH, p.TW, p.NI, nt_all) &&
+            2ll * cdiv(OHt, p.TH) * cdiv(OWt, p.TW) * cdiv(p.N, p.NI) * (p.Kpad / bm) >= env_int("HIFIC_MP_MIN_GRID", 512))
+            tiled = true;
+        else {
+            mp = false;
+            tps = pick_tps(bm); wbytes = 512 + 2 * tps * bm * PITCH;
+            span_y = 1; span_x = 1;
+            for (int i = 0; i < p.nphase; ++i) { if (p.ph[i].PH > span_y) span_y = p.ph[i].PH; if (p.ph[i].PW > span_x) span_x = p.ph[i].PW; }
+        }
+    }
+    if (!phs && !mp && choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, tile_budget, p.TH, p.TW, p.NI, maxtaps)) {
         const long long g = (long long)cdiv(OHt, p.TH) * cdiv(OWt, p.TW) * cdiv(p.N, p.NI) * (p.Kpad / bm) * p.nphase;
         tiled = g >= env_int("HIFIC_GC_BIGTILE_MIN_GRID", 256);
     }
@@ -2609,7 +2871,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         // ... when the launch has at least two workgroups per CU to co-reside (a 256-workgroup launch only gets the
         // doubled step count: 960<-480 @16x16 138 -> 191 us)
         const long long g64 = (long long)cdiv(OHt, p.TH) * cdiv(OWt, p.TW) * cdiv(p.N, p.NI) * (p.Kpad / bm) * p.nphase;
-        if (tiled && !phs && g64 >= 512 && env_int("HIFIC_BC32", 1)) {
+        if (tiled && !phs && !mp && g64 >= 512 && env_int("HIFIC_BC32", 1)) {
             size_t need = 0;
             for (int i = 0; i < p.nphase; ++i) {
                 const size_t b = (size_t)wbytes + (size_t)p.NI * ((p.TH - 1) * p.ist + p.ph[i].PH) * ((p.TW - 1) * p.ist + p.ph[i].PW) * PITCH;
@@ -2626,7 +2888,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     if (!tiled && !choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, 72 * 1024, p.TH, p.TW, p.NI, maxtaps))
         return HIFIC_ERR_UNSUPPORTED;
     p.tiles_n = cdiv(p.N, p.NI);
-    if (bm == 128 && !phs && !env_int("HIFIC_NO_BM_TAIL", 0)) {
+    if (bm == 128 && !phs && !mp && !env_int("HIFIC_NO_BM_TAIL", 0)) {
         // 128-row tiles run one workgroup per CU: a grid of e.g. 1.5 x 256 workgroups (18x18 padded-gradient
         // domain of the 16x16x960 layers) leaves half the chip idle in its second wave.  64-row tiles co-reside two
         // per CU, so the same launch quantises at 512 slots.
@@ -2694,6 +2956,30 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                   p.NI * p.ph[0].PH * p.ph[0].PW <= 192 && !env_int("HIFIC_NO_SP", 0) &&
                   64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(p.NI * p.ph[0].PH * p.ph[0].PW + 2) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
     }
+    if (mp) {
+        GcPhase& u = p.ph[4];
+        memset(&u, 0, sizeof(u));
+        u.tap0 = 0; u.dy_min = u_dymin; u.dx_min = u_dxmin;
+        for (int i = 0; i < 4; ++i) u.ntaps += p.ph[i].ntaps;
+        u.PH = (p.TH - 1) + (u_dymax - u_dymin + 1); u.PW = (p.TW - 1) + (u_dxmax - u_dxmin + 1); u.PWs = u.PW;
+        for (int i = 0; i < 4; ++i) {
+            if (p.ph[i].tiles_y > u.tiles_y) u.tiles_y = p.ph[i].tiles_y;
+            if (p.ph[i].tiles_x > u.tiles_x) u.tiles_x = p.ph[i].tiles_x;
+            if (p.ph[i].OHt > u.OHt) u.OHt = p.ph[i].OHt;
+            if (p.ph[i].OWt > u.OWt) u.OWt = p.ph[i].OWt;
+        }
+        max_tiles = p.tiles_n * u.tiles_y * u.tiles_x;
+        lds = (size_t)wbytes + (size_t)p.NI * u.PH * u.PWs * PITCH;
+        use_sp9 = false;
+        p.wstage = 0;
+        // pair stores: the two column phases of an output row as one 4 / 8-byte store per pixel
+        p.epi_wide = 0;
+        if (!p.fold_h && p.OWf % 2 == 0 && p.ph[0].ooy == p.ph[1].ooy && p.ph[2].ooy == p.ph[3].ooy &&
+            p.ph[0].oox == 0 && p.ph[1].oox == 1 && p.ph[2].oox == 0 && p.ph[3].oox == 1 &&
+            p.ph[0].OHt == p.ph[1].OHt && p.ph[0].OWt == p.ph[1].OWt && p.ph[2].OHt == p.ph[3].OHt &&
+            p.ph[2].OWt == p.ph[3].OWt && (((size_t)p.out) & 7) == 0 && !env_int("HIFIC_MP_NO_PAIR", 0))
+            p.epi_wide = 2;
+    }
     if (phs) {
         GcPhase& u = p.ph[4];
         memset(&u, 0, sizeof(u));
@@ -2731,7 +3017,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     // workgroups x 405 steps) 178 -> 108; launches of 128-256 workgroups or < ~60 us of chain got 10-40 % SLOWER.
     p.ksplit = 1; p.kchunks = 0; p.kpart = nullptr; p.kpart_stride = 0;
     if constexpr (std::is_same<T, bf16_t>::value) {
-        const long long g0 = (long long)max_tiles * (p.Kpad / bm) * (phs ? 1 : p.nphase);
+        const long long g0 = mp ? (1ll << 40) : (long long)max_tiles * (p.Kpad / bm) * (phs ? 1 : p.nphase);
         const int nch = p.Cpad / BC;
         const double chain_us = (double)nch * (use_sp9 ? 9 * 0.5 : cdiv(maxtaps, tps) * 1.5);
         // (the generic kernel's step is a barrier + synchronous staging, ~1.5-2 us; the software-pipelined one ~0.5 us)
@@ -2812,7 +3098,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         p.kpart = (float*)ws.take((size_t)p.ksplit * (size_t)p.kpart_stride * sizeof(float));
         if (!p.kpart) { p.ksplit = 1; p.kchunks = 0; }          // no room: one pass (epi_wide stays off: harmless)
     }
-    dim3 grid(max_tiles * (p.Kpad / bm), p.ksplit, phs ? 1 : p.nphase);
+    dim3 grid(max_tiles * (p.Kpad / bm), p.ksplit, phs ? 1 : (mp ? 2 : p.nphase));
     // algorithmic FLOPs of the op (set by the caller on the op's REAL output domain: a reflect-padded data gradient
     // computes on the padded plane, which is extra work, not extra useful FLOPs)
     const double aflops = p.aflops;
@@ -2828,6 +3114,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                           sp9_w4 ? 4 : phs ? 1 : p.rfx ? (bm == 128 ? 2 : 1)
                                 : ((env_int("HIFIC_SP9_KSPLIT", 2) == 2 && (bm == 128 || env_int("HIFIC_SP9_KSPLIT64", 0))) ? 2 : 1),
                           phs ? (phs == 1 ? ",phs1" : ",phs2") : (p.rfx ? ",rfx" : ""));
+    else if (mp) snprintf(kname, sizeof(kname), "gconv_mp_kernel%s", p.split ? "<split>" : "");
     else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
                   bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
     const int pslot = prof_open(kname, aflops, st, ptag);
@@ -2919,7 +3206,20 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             }
         }
     }
-    if (sp_done) { /* launched */ }
+    bool mp_done = false;
+    if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
+        if (mp) {
+            if (p.split) {
+                if (lds > 48 * 1024) gc_set_max_lds((const void*)gconv_mp_kernel<true>, (int)lds);
+                hipLaunchKernelGGL(gconv_mp_kernel<true>, grid, dim3(256), lds, st, p);
+            } else {
+                if (lds > 48 * 1024) gc_set_max_lds((const void*)gconv_mp_kernel<false>, (int)lds);
+                hipLaunchKernelGGL(gconv_mp_kernel<false>, grid, dim3(256), lds, st, p);
+            }
+            mp_done = true;
+        }
+    }
+    if (sp_done || mp_done) { /* launched */ }
     else if (bm == 128) GC_LAUNCH(2, 2, 2, 2);
     else if (bm == 64) GC_LAUNCH(2, 2, 1, 2);
     else GC_LAUNCH(1, 4, 1, 1);
