@@ -950,6 +950,197 @@ void gconv_mp_kernel(const GcParams p) {
     gc_epilogue<false, 1, WN, -1>(p, PB, acc1[0], acc1[1], acc1[0], acc1[1], mbase, lhi, pu, pv, pn, pvalid);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Virtual-column forward kernel for FEW-CHANNEL inputs (round 4): LPIPS/AlexNet conv1 (3 -> 64, 11x11 stride 4), the first
+// Encoder layer in the exact-index chain (9 = 3 x 3 split channels -> 60, 7x7), the Discriminator's first layer (15 -> 64, 4x4
+// stride 2).  An implicit GEMM spends one 16-deep MFMA slice per TAP on C useful channels (3/16 .. 9/16 of the work, 49-121
+// barrier steps): 248 us for the 5.9 GFLOP of AlexNet conv1, 291 us for the first Encoder layer.  Here the reduction index is
+// the dense virtual column j = c * R*S + tap - the weight tensor's own memory order, so the packed operand is just the weight
+// matrix [K][C*R*S] in bf16 (packed by the ordinary 1x1 pack path) - and per 64-column chunk every thread GATHERS its part of
+// the im2col image [128 pixels][64 columns] from an LDS-resident halo patch of the input tile ([img][c][rows][cols], padding
+// rule applied while staging); the MFMAs then run exactly like gconv_kernel's on a one-tap "patch".  ceil(C*R*S / 64) steps of
+// 4 K-slices instead of R*S steps of one mostly-empty slice.
+// p.ph[0]: the phase (PH/PW = halo patch of the tile); p.Cpad = padded C*R*S; taps in (r, s) order; ost = 1.
+template <bool F32SRC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gconv_vc_kernel(const GcParams p) {
+    constexpr int PITCH = 144, BM = 64, WN = 2, WGN = 2, PPR = 8;
+    constexpr int WBYTES = BM * PITCH;
+    constexpr int NWP = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wv = tid >> 6;
+    const GcPhase& ph = p.ph[0];
+    const int ntile = p.tiles_n * ph.tiles_y * ph.tiles_x;
+    int tile, mtile;
+    {
+        const int nwg = gridDim.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int q = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        mtile = q / p.max_tiles;
+        tile = q - mtile * p.max_tiles;
+    }
+    if (tile >= ntile) return;
+    const int tx = tile % ph.tiles_x;
+    const int ty = (tile / ph.tiles_x) % ph.tiles_y;
+    const int tn = tile / (ph.tiles_x * ph.tiles_y);
+    const int u0 = ty * p.TH, v0 = tx * p.TW, n0 = tn * p.NI;
+    const int m0 = mtile * BM;
+    const int PHh = ph.PH, PWw = ph.PW;
+    const int npl = PHh * PWw;
+    const int T = ph.ntaps;
+    const int J = p.C * T;                                     // real virtual columns; p.Cpad = J rounded up to 64
+    const int nch = p.Cpad / 64;
+
+    int* jtab = (int*)smem;                                    // [Cpad] patch offset of column j, -1 for the padding
+    unsigned char* wt = smem + (((size_t)p.Cpad * 4 + 15) & ~(size_t)15);      // 2 x WBYTES
+    unsigned char* bt = wt + 2 * WBYTES;                       // [128][PITCH] im2col chunk
+    unsigned short* pb = (unsigned short*)(bt + (size_t)GC_NPIX * PITCH);
+    for (int j = tid; j < p.Cpad; j += 256) {
+        const int c = j / T, t = j - c * T;
+        jtab[j] = j < J ? (c * npl + ((int)p.tap_dy[t] - ph.dy_min) * PWw + ((int)p.tap_dx[t] - ph.dx_min)) : -1;
+    }
+    // halo patch of the tile, padding rule applied, bf16: rows y0 .., columns x0 ..
+    {
+        const int y0 = u0 * p.ist + ph.dy_min, x0 = v0 * p.ist + ph.dx_min;
+        const int npatch = p.NI * p.C * npl;
+        const float inv_npl = 1.0f / (float)npl, inv_pww = 1.0f / (float)PWw;
+        const unsigned plane = (unsigned)(p.IH * p.IW);
+        // eight loads in flight per thread (one load per loop trip was one memory round trip per 256 elements: 20 serialised
+        // round trips for the 5040-element patch of the first Encoder layer, 300 us of the launch)
+        constexpr int SB = 8;
+        for (int base = tid; base < npatch && !(p.dbg & 64); base += 256 * SB) {
+            unsigned off[SB], v[SB];
+            bool ok[SB];
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                const int idx = base + 256 * b;
+                const int ci = (int)(((float)idx + 0.5f) * inv_npl);           // exact for idx < 2^22
+                const int r = idx - ci * npl;
+                const int yy = (int)(((float)r + 0.5f) * inv_pww);
+                const int xx = r - yy * PWw;
+                const int img = ci / p.C, c = ci - img * p.C;
+                int yb = y0 + yy, xb = x0 + xx;
+                if (p.bmode == PAD_REFLECT) { yb = reflect_idx(yb, p.IH); xb = reflect_idx(xb, p.IW); }
+                const int n = n0 + img;
+                ok[b] = idx < npatch && n < p.N && (unsigned)yb < (unsigned)p.IH && (unsigned)xb < (unsigned)p.IW;
+                off[b] = ok[b] ? ((unsigned)(n * p.C + c) * plane + (unsigned)(yb * p.IW + xb)) : 0u;
+            }
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                if constexpr (F32SRC) v[b] = __float_as_uint(((const float*)p.in)[off[b]]);
+                else v[b] = ((const bf16_t*)p.in)[off[b]];
+            }
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                const int idx = base + 256 * b;
+                unsigned x = v[b];
+                if constexpr (F32SRC) x = f2bf(__uint_as_float(x));
+                if (idx < npatch) pb[idx] = (unsigned short)(ok[b] ? x : 0u);
+            }
+        }
+    }
+    // gather role: pixels q = lane, lane + 64 of the tile; dword columns wv + 4 i of a chunk
+    const int thw = p.TH * p.TW;
+    int pixl[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = lane + 64 * k;
+        const int img = q / thw;
+        const int rem = q - img * thw;
+        const int tyy = rem / p.TW, txx = rem - tyy * p.TW;
+        pixl[k] = img < p.NI ? (img * p.C * npl + tyy * p.ist * PWw + txx * p.ist) : 0;
+    }
+    // MFMA role
+    int pu[WN], pv[WN], pn[WN];
+    bool pvalid[WN];
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int pt = (wn * WN + ni) * 32 + l31;
+        const int img = pt / thw;
+        const int rem = pt - img * thw;
+        const int ty_ = rem / p.TW;
+        const int tx_ = rem - ty_ * p.TW;
+        pvalid[ni] = img < p.NI;
+        pu[ni] = u0 + ty_; pv[ni] = v0 + tx_; pn[ni] = n0 + img;
+    }
+    f32x16_t acc[WN];
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+
+    // weight tile of chunk ch: rows m0 .. m0 + 63, columns 64 ch .. of wp[Kpad][Cpad]; one chunk ahead in registers
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const unsigned char* wpb = (const unsigned char*)p.wp;
+    const unsigned wp16 = (unsigned)((tid & 7) * 16);
+    const unsigned wlds0 = (unsigned)((tid >> 3) * PITCH) + wp16;
+    unsigned wrowoff[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int wrow = (tid >> 3) + 32 * i;
+        wrowoff[i] = (unsigned)(m0 + wrow < p.K ? m0 + wrow : p.K - 1) * (unsigned)(p.Cpad * 2) + wp16;
+    }
+    u32x4_t wr[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) wr[i] = *(const u32x4_t*)(wpb + wrowoff[i]);
+    __syncthreads();                                           // jtab and the patch are in place
+
+    for (int ch = 0; ch < nch; ++ch) {
+        unsigned char* wcur = wt + (ch & 1) * WBYTES;
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) *(u32x4_t*)(wcur + wlds0 + i * 32 * PITCH) = wr[i];
+        {
+            const int chn = ch + 1 < nch ? ch + 1 : ch;
+#pragma unroll
+            for (int i = 0; i < NWP; ++i) wr[i] = *(const u32x4_t*)(wpb + wrowoff[i] + (unsigned)chn * 128u);
+        }
+        // im2col chunk: columns 64 ch + 2 (wv + 4 i) + {0, 1}
+        int jt[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) jt[k] = jtab[ch * 64 + 2 * (wv + 4 * (k >> 1)) + (k & 1)];
+        if (!(p.dbg & 1))
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            unsigned raw[16];
+#pragma unroll
+            for (int c2 = 0; c2 < 16; ++c2) raw[c2] = pb[pixl[k] + (jt[c2] >= 0 ? jt[c2] : 0)];
+            unsigned char* row = bt + (size_t)(lane + 64 * k) * PITCH + wv * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *(unsigned*)(row + i * 16) = (jt[2 * i] >= 0 ? raw[2 * i] : 0u) | ((jt[2 * i + 1] >= 0 ? raw[2 * i + 1] : 0u) << 16);
+        }
+        __syncthreads();
+        if (!(p.dbg & 2)) {
+            const unsigned char* arow = wcur + (wm * 32 + l31) * PITCH;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8_t a = *(const bf16x8_t*)(arow + kk * 32 + lhi * 16);
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    const bf16x8_t b = *(const bf16x8_t*)(bt + (size_t)((wn * WN + ni) * 32 + l31) * PITCH + kk * 32 + lhi * 16);
+                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ni], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                       // every wave is done with bt before the next gather
+    }
+    const int mbase = m0 + wm * 32;
+    if (p.dbg & 32) { if (acc[0][0] == 12345.678f) ((float*)p.out)[0] = acc[1][1]; return; }
+    if (p.epi_wide) {
+        gc_epilogue_wide<1, WN, -1>(p, ph, acc[0], acc[1], acc[0], acc[1], mbase, lane, wn, u0, v0, n0,
+                                    smem + (size_t)wave * 32 * (WN * 64 + 16));
+        return;
+    }
+    gc_epilogue<false, 1, WN, -1>(p, ph, acc[0], acc[1], acc[0], acc[1], mbase, lhi, pu, pv, pn, pvalid);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Software-pipelined kernel for the stride-1 3x3 layers (bf16, 9 taps in one phase, 64-channel chunks, halo patch of
 // <= 192 pixels).  Same tiling as gconv_kernel; the 9 GEMM steps of a channel chunk are ONE straight-line block in
@@ -2322,22 +2513,37 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
         // so the gather below needs no bounds tests); consecutive threads take consecutive columns
         {
             const int y0 = u0 + p.b_y0 + tdy_min, x0 = v0 + p.b_x0 + tdx_min;
-            for (int idx = tid; idx < npatch; idx += 256) {
-                const int ci = (int)(((float)idx + 0.5f) * inv_npl);           // exact for idx < 2^22
-                const int r = idx - ci * npl;
-                const int yy = (int)(((float)r + 0.5f) * inv_pww);
-                const int xx = r - yy * PWw;
-                const int img = ci / p.creal, c = ci - img * p.creal;
-                int yb = y0 + yy, xb = x0 + xx;
-                if (p.bmode == PAD_REFLECT) { yb = reflect_idx(yb, p.BH); xb = reflect_idx(xb, p.BW); }
-                const int n = n0 + img;
-                const bool ok = n < p.N && (unsigned)yb < (unsigned)p.BH && (unsigned)xb < (unsigned)p.BW;
-                const unsigned off = ok ? ((unsigned)(n * p.creal + c) * bplane + (unsigned)(yb * p.BW + xb)) : 0u;
-                unsigned v;
-                if constexpr (BF32) v = __float_as_uint(((const float*)p.b)[off]);
-                else v = ((const bf16_t*)p.b)[off];
-                if constexpr (!std::is_same<T, float>::value && BF32) v = f2bf(__uint_as_float(v));
-                pb[idx] = (PE)(ok ? v : 0u);
+            // (eight loads in flight per thread: one per loop trip was a memory round trip per 256 elements)
+            constexpr int SB = 8;
+            for (int base = tid; base < npatch; base += 256 * SB) {
+                unsigned off[SB], v[SB];
+                bool ok[SB];
+#pragma unroll
+                for (int b = 0; b < SB; ++b) {
+                    const int idx = base + 256 * b;
+                    const int ci = (int)(((float)idx + 0.5f) * inv_npl);       // exact for idx < 2^22
+                    const int r = idx - ci * npl;
+                    const int yy = (int)(((float)r + 0.5f) * inv_pww);
+                    const int xx = r - yy * PWw;
+                    const int img = ci / p.creal, c = ci - img * p.creal;
+                    int yb = y0 + yy, xb = x0 + xx;
+                    if (p.bmode == PAD_REFLECT) { yb = reflect_idx(yb, p.BH); xb = reflect_idx(xb, p.BW); }
+                    const int n = n0 + img;
+                    ok[b] = idx < npatch && n < p.N && (unsigned)yb < (unsigned)p.BH && (unsigned)xb < (unsigned)p.BW;
+                    off[b] = ok[b] ? ((unsigned)(n * p.creal + c) * bplane + (unsigned)(yb * p.BW + xb)) : 0u;
+                }
+#pragma unroll
+                for (int b = 0; b < SB; ++b) {
+                    if constexpr (BF32) v[b] = __float_as_uint(((const float*)p.b)[off[b]]);
+                    else v[b] = ((const bf16_t*)p.b)[off[b]];
+                }
+#pragma unroll
+                for (int b = 0; b < SB; ++b) {
+                    const int idx = base + 256 * b;
+                    unsigned x = v[b];
+                    if constexpr (!std::is_same<T, float>::value && BF32) x = f2bf(__uint_as_float(x));
+                    if (idx < npatch) pb[idx] = (PE)(ok[b] ? x : 0u);
+                }
             }
         }
         __syncthreads();
@@ -3430,9 +3636,90 @@ static int launch_gconv_t_bf16(GcParams& p, const float* w, const float* w_scale
     return launch_gconv_t<bf16_t>(p, w, w_scale, sm, sc, sr, ss, ws, st);
 }
 
+
+// Few-channel forward convolutions on the virtual-column kernel (gconv_vc_kernel).  HIFIC_ERR_UNSUPPORTED: not this layer.
+static int launch_gconv_vc(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
+                           long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
+    GcPhase& ph = p.ph[0];
+    const int T = ph.ntaps;
+    // Measured (round 4, batch 16-32 x 256^2): AlexNet conv1 (C 3, 121 taps, stride 4) 245 -> 50 us.  NOT taken for the 9- and
+    // 15-channel layers on 256 x 256 planes (first exact Encoder layer 288 -> 306 us, Discriminator conv1 121 -> 154 us): with
+    // 4 000-8 000 tiles their time is the per-tile staging of the raw patch (73-93 us), the gather (21-69 us) and the per-tile
+    // base cost, which the saved MFMA slices do not pay for (HIFIC_VC_MAXC widens the rule for experiments).
+    if (p.nphase != 1 || p.ost != 1 || p.C > env_int("HIFIC_VC_MAXC", 4) || p.C > 16 || p.C * T < 96 || p.K <= 4 || p.K > 256 ||
+        p.csplit || p.msplit || p.rfx || p.fold_h || p.resid || p.split || ph.tap0 != 0 || env_int("HIFIC_NO_VC", 0))
+        return HIFIC_ERR_UNSUPPORTED;
+    // the virtual column order c * T + t is the weight tensor's own order: taps must be (r, s)-major and contiguous
+    if (!(ss == 1 && sr > 0 && sc == (long long)T)) return HIFIC_ERR_UNSUPPORTED;
+    for (int t = 0; t < T; ++t) if (p.tap_r[t] * (int)sr + p.tap_s[t] != t) return HIFIC_ERR_UNSUPPORTED;
+    const int J = p.C * T;
+    p.Kpad = cdiv(p.K, 64) * 64;
+    p.Cpad = cdiv(J, 64) * 64;
+    p.dbg = env_int("HIFIC_DBG", 0); p.afrag = 0; p.ksplit = 1; p.kchunks = 0; p.kpart = nullptr; p.wstage = 0;
+    // pixel tile: 2 x 64 on wide planes (whole 128-byte lines of the output), 8 x 16 otherwise
+    p.TW = ph.OWt < 64 ? (ph.OWt < 16 ? ph.OWt : 16) : 64;
+    p.TH = GC_NPIX / p.TW; if (p.TH > ph.OHt) p.TH = ph.OHt;
+    p.NI = 1;
+    const int sy = ph.PH, sx = ph.PW;                          // tap spans (finish_phase)
+    ph.PH = (p.TH - 1) * p.ist + sy; ph.PW = (p.TW - 1) * p.ist + sx; ph.PWs = ph.PW;
+    ph.tiles_y = cdiv(ph.OHt, p.TH); ph.tiles_x = cdiv(ph.OWt, p.TW); p.tiles_n = cdiv(p.N, p.NI);
+    ph.wp_off = 0;
+    p.max_tiles = p.tiles_n * ph.tiles_y * ph.tiles_x;
+    const size_t patch_b = (((size_t)p.NI * p.C * ph.PH * ph.PW * 2) + 15) & ~(size_t)15;
+    size_t lds = (((size_t)p.Cpad * 4 + 15) & ~(size_t)15) + 2 * (size_t)64 * 144 + (size_t)GC_NPIX * 144 + patch_b;
+    if (lds > (size_t)76 * 1024) { ph.PH = sy; ph.PW = sx; return HIFIC_ERR_UNSUPPORTED; }
+    p.epi_wide = 0;
+    if (!p.out_f32 && p.TW % 8 == 0 && p.OWf % 8 == 0 && ph.OWt % 8 == 0 && ph.ooy == 0 && ph.oox == 0 &&
+        !env_int("HIFIC_NO_WIDE_EPI", 0)) {
+        p.epi_wide = 1;
+        const size_t need = (size_t)4 * 32 * (2 * 64 + 16);
+        if (need > lds) lds = need;
+    }
+    // the packed operand = the weight matrix [K][J] in bf16, rows padded to Cpad: the 1x1 pack plan over J "channels"
+    const size_t wp_bytes = (size_t)p.Kpad * p.Cpad * sizeof(bf16_t);
+    PackJob job; memset(&job, 0, sizeof(job));
+    GcParams& q = job.p;
+    q.K = p.K; q.C = J; q.Kpad = p.Kpad; q.Cpad = p.Cpad; q.nphase = 1; q.tap_sw = 1;
+    q.ph[0].ntaps = 1; q.ph[0].tap0 = 0; q.ph[0].wp_off = 0;
+    job.sm = sm; job.sc = 1; job.sr = 1; job.ss = 1; job.RS = 1; job.dtype = HIFIC_BF16; job.wp_bytes = (long long)wp_bytes;
+    job.mode = 0; job.MB = 16; job.gx = p.Cpad / 64; job.gy = cdiv(p.Kpad, job.MB);
+    job.lds_bytes = (int)((size_t)64 * ((job.MB * 1) | 1) * sizeof(float));
+    if (ws.plan_out) { *ws.plan_out = job; return HIFIC_OK; }
+    void* wp;
+    if (ws.wcache_state != 0) {
+        if (!ws.wcache || ws.wcache_bytes < wp_bytes) return HIFIC_ERR_WS;
+        wp = ws.wcache;
+    } else {
+        wp = ws.take(wp_bytes);
+        if (!wp) return HIFIC_ERR_WS;
+    }
+    p.wp = wp;
+    if (ws.wcache_state != 2) {
+        q.wp = wp;
+        hipLaunchKernelGGL((pack_w2_kernel<bf16_t, 0>), dim3(job.gx, job.gy), dim3(256), job.lds_bytes, st, q, w, w_scale, job.sm,
+                           job.sc, job.RS, job.MB);
+    }
+    dim3 grid(p.max_tiles * (p.Kpad / 64), 1, 1);
+    char ptag[112];
+    snprintf(ptag, sizeof(ptag), "gconv_vc K%d C%d N%d in%dx%d out%dx%d taps%d ist%d tile%dx%dx%d J%d grid%d", p.K, p.C, p.N, p.IH,
+             p.IW, p.OHf, p.OWf, T, p.ist, p.NI, p.TH, p.TW, J, (int)grid.x);
+    const int pslot = prof_open("gconv_vc_kernel", p.aflops, st, ptag);
+    if (p.in_f32) {
+        if (lds > 48 * 1024) gc_set_max_lds((const void*)gconv_vc_kernel<true>, (int)lds);
+        hipLaunchKernelGGL(gconv_vc_kernel<true>, grid, dim3(256), lds, st, p);
+    } else {
+        if (lds > 48 * 1024) gc_set_max_lds((const void*)gconv_vc_kernel<false>, (int)lds);
+        hipLaunchKernelGGL(gconv_vc_kernel<false>, grid, dim3(256), lds, st, p);
+    }
+    prof_close(pslot, st);
+    return hific_launch_status();
+}
+
 static int launch_gconv(GcParams& p, int dtype, const float* w, const float* w_scale, long long sm, long long sc,
                         long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
     if (dtype == HIFIC_BF16) {
+        int rcv = launch_gconv_vc(p, w, w_scale, sm, sc, sr, ss, ws, st);
+        if (rcv != HIFIC_ERR_UNSUPPORTED) return rcv;
         int rc = launch_gconv_fewc(p, w, w_scale, sm, sc, sr, ss, ws, st);
         if (rc != HIFIC_ERR_UNSUPPORTED) return rc;
         rc = launch_gconv_fewk(p, w, w_scale, sm, sc, sr, ss, ws, st);
