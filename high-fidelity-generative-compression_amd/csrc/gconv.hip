@@ -3646,8 +3646,8 @@ static int launch_gconv_vc(GcParams& p, const float* w, const float* w_scale, lo
     // 15-channel layers on 256 x 256 planes (first exact Encoder layer 288 -> 306 us, Discriminator conv1 121 -> 154 us): with
     // 4 000-8 000 tiles their time is the per-tile staging of the raw patch (73-93 us), the gather (21-69 us) and the per-tile
     // base cost, which the saved MFMA slices do not pay for (HIFIC_VC_MAXC widens the rule for experiments).
-    if (p.nphase != 1 || p.ost != 1 || p.C > env_int("HIFIC_VC_MAXC", 4) || p.C > 16 || p.C * T < 96 || p.K <= 4 || p.K > 256 ||
-        p.csplit || p.msplit || p.rfx || p.fold_h || p.resid || p.split || ph.tap0 != 0 || env_int("HIFIC_NO_VC", 0))
+    if (p.nphase != 1 || p.ost != 1 || p.C > env_int("HIFIC_VC_MAXC", 4) || p.C > 16 || p.C * T < 96 || T < env_int("HIFIC_VC_MINTAPS", 64) ||
+        p.K <= 4 || p.K > 256 || p.csplit || p.msplit || p.rfx || p.fold_h || p.resid || p.split || ph.tap0 != 0 || env_int("HIFIC_NO_VC", 0))
         return HIFIC_ERR_UNSUPPORTED;
     // the virtual column order c * T + t is the weight tensor's own order: taps must be (r, s)-major and contiguous
     if (!(ss == 1 && sr > 0 && sc == (long long)T)) return HIFIC_ERR_UNSUPPORTED;
