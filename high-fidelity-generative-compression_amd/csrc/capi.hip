@@ -40,7 +40,9 @@ static bool geomT_ok(const ConvTGeom& g) {
 // y = act(conv2d(pad(x), w*w_scale) + bias [+ resid]);  x [N,C,H,W], w f32 [K,C,R,S], y [N,K,OH,OW]
 // flags: bit0 = x is f32 although dtype is bf16, bit1 = y (and resid) are f32 although dtype is bf16, bit2 = C is the
 // 3x split-bf16 reduction of a C/3-channel layer (hific_split3; only the profiler's FLOP count changes), bit3 = x and w
-// are in the PAIR layout (hific_split3 which = 2, C = 2 * C16): the native split kernel forms hi*hi + hi*lo + lo*hi; bits
+// are in the PAIR layout (hific_split3 which = 2, C = 2 * C16): the native split kernel forms hi*hi + hi*lo + lo*hi; bit4 =
+// w_scale (a device scalar: spectral norm's 1/sigma) multiplies the ACCUMULATOR in the epilogue instead of the weights in the
+// pack pass, so the packed image depends only on the weights and can live in the caller's cache across forwards; bits
 // 8.. = the layer's real channel count (profiler FLOPs)
 int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const float* bias, const void* resid, void* y,
                      int N, int C, int H, int W, int K, int R, int S, int stride, int pt, int pl, int pb, int pr,
@@ -53,6 +55,10 @@ int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const 
     g.red_split = (flags & 8) ? 2 : ((flags >> 2) & 1);
     g.red_C = flags >> 8;
     if ((flags & 8) && (dtype != HIFIC_BF16 || (flags & 1) || C % 32 != 0 || w_scale)) return HIFIC_ERR_ARG;
+    if (flags & 16) {            // w_scale multiplies the accumulator in the epilogue; the weights are packed unscaled
+        if (!w_scale || resid) return HIFIC_ERR_ARG;
+        g.oscale = w_scale; w_scale = nullptr;
+    }
     return gc_conv_fwd(g, x, w, w_scale, bias, y, resid, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 
@@ -65,6 +71,10 @@ int hific_conv2d_bwd_data(const void* dy, const float* w, const float* w_scale, 
     if (!geom_ok(g) || !dy || !w || !dx) return HIFIC_ERR_ARG;
     WsAlloc a{(char*)ws, ws_bytes, 0};
     a.wcache = wcache; a.wcache_bytes = wcache_bytes; a.wcache_state = wcache_state;
+    if (flags & 16) {            // as in hific_conv2d_fwd
+        if (!w_scale) return HIFIC_ERR_ARG;
+        g.oscale = w_scale; w_scale = nullptr;
+    }
     return gc_conv_bwd_data(g, dy, w, w_scale, dx, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 
@@ -123,6 +133,7 @@ int hific_conv2d_pack_plan(int kind, int N, int C, int H, int W, int K, int R, i
     a.plan_out = (PackJob*)job;
     const float* fake_w = (const float*)job;       // never dereferenced in a plan-only call
     g.red_split = (flags & 8) ? 2 : 0;                          // (the plan - and so the pack layout - depends on it)
+    if (flags & 16) g.oscale = fake_w;                          // ... and on the epilogue-scale form (kernel choice)
     if (kind == 0) return gc_conv_fwd(g, job, fake_w, nullptr, nullptr, job, nullptr, ACT_NONE, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
     return gc_conv_bwd_data(g, job, fake_w, nullptr, job, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
 }

@@ -51,6 +51,8 @@ struct GcParams {
     int ksplit, kchunks;
     float* kpart;
     long long kpart_stride;
+    const float* oscale; // device scalar multiplied into the accumulator before bias / activation (spectral norm's 1/sigma with
+                         // UNSCALED packed weights: the pack then depends only on the optimizer step and is cached)
     int split;           // native split-bf16 reduction (gconv_kernel SPLIT): both operands in the pair layout of
                          // hific_split3 which = 2 - every 32 reduction channels are (hi 16 | lo 16) of 16 real channels and
                          // a step issues hi*hi + hi*lo + lo*hi
@@ -91,6 +93,7 @@ struct ConvGeom {
     int red_split = 0;   // 1: C is 3x the layer's channels (split-bf16 operands, hific_split3): count 1/3 of the FLOPs
                          // 2: C is the pair layout (2 * C16) of the native split kernels; red_C = the layer's real channels
     int red_C = 0;
+    const float* oscale = nullptr;   // see GcParams::oscale (conv2d fwd / bwd-data flags bit 4)
     int OH() const { return (H + pt + pb - R) / stride + 1; }
     int OW() const { return (W + pl + pr - S) / stride + 1; }
 };

@@ -302,6 +302,7 @@ __device__ __forceinline__ void gc_store_block(const GcParams& p, const GcPhase&
         const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         bv[r] = bp[(hb && m < p.K) ? m : 0];
     }
+    const float osc = p.oscale ? *p.oscale : 1.f;
     const int oy = pu_ * p.ost + ph.ooy, ox = pv_ * p.ost + ph.oox;
     const bool okp = pvalid_ && pn_ < p.N && pu_ < ph.OHt && pv_ < ph.OWt &&
                      (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
@@ -326,7 +327,7 @@ __device__ __forceinline__ void gc_store_block(const GcParams& p, const GcPhase&
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        v[r] = a[r] + ((hb && m < p.K) ? bv[r] : 0.f);
+        v[r] = a[r] * osc + ((hb && m < p.K) ? bv[r] : 0.f);
     }
     if (p.resid) {          // rare path (no caller on the HiFIC graph fuses a residual): loads batched per fragment
         float rv[16];
@@ -379,6 +380,7 @@ __device__ __forceinline__ void gc_wide_rows(const GcParams& p, const f32x16_t a
                                              int lhi, int l31, bool hb, const float* bp, float slope, int ni0, int rowb,
                                              unsigned char* wave_lds) {
     float bv[16];                                           // the 16 bias loads of a row block in flight together
+    const float osc = p.oscale ? *p.oscale : 1.f;
 #pragma unroll 16
     for (int r = 0; r < 16; ++r) {
         const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -389,7 +391,7 @@ __device__ __forceinline__ void gc_wide_rows(const GcParams& p, const f32x16_t a
     for (int r = 0; r < 16; ++r) {
         const int ml = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const float b_ = (hb && mbase + ml < p.K) ? bv[r] : 0.f;
-        const float x0 = a0[r] + b_, x1 = a1[r] + b_;
+        const float x0 = a0[r] * osc + b_, x1 = a1[r] * osc + b_;
         va[r] = x0 > 0.f ? x0 : x0 * slope;
         vb[r] = x1 > 0.f ? x1 : x1 * slope;
     }
@@ -752,6 +754,7 @@ __device__ __forceinline__ void mp_store_pair(const GcParams& p, const GcPhase& 
         const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         bv[r] = bp[(hb && m < p.K) ? m : 0];
     }
+    const float osc = p.oscale ? *p.oscale : 1.f;
     const int oy = pu_ * 2 + phA.ooy, ox = pv_ * 2 + phA.oox;
     const bool okp = pvalid_ && pn_ < p.N && pu_ < phA.OHt && pv_ < phA.OWt && (unsigned)oy < (unsigned)p.OHf &&
                      (unsigned)(ox + 1) < (unsigned)p.OWf;
@@ -762,7 +765,7 @@ __device__ __forceinline__ void mp_store_pair(const GcParams& p, const GcPhase& 
     for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const float b_ = (hb && m < p.K) ? bv[r] : 0.f;
-        float x0 = a[r] + b_, x1 = b[r] + b_;
+        float x0 = a[r] * osc + b_, x1 = b[r] * osc + b_;
         x0 = x0 > 0.f ? x0 : x0 * slope;
         x1 = x1 > 0.f ? x1 : x1 * slope;
         if (m < p.K) {
@@ -2955,7 +2958,8 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         // >= 4 channel chunks: the software pipeline needs chunks to overlap; single-chunk large-plane layers are
         // HBM/epilogue-bound and did better with two co-resident generic workgroups (K60 C120 @128x128: 205 -> 230 us,
         // K480 C960 @16x16: 134 -> 89 us)
-        if (p.nphase == 4 && p.ist == 1 && !p.in_f32 && p.K > 32 && p.C >= 256 && !p.rfx && !p.split && !env_int("HIFIC_NO_PHS", 0)) {
+        if (p.nphase == 4 && p.ist == 1 && !p.in_f32 && p.K > 32 && p.C >= 256 && !p.rfx && !p.split && !p.oscale &&
+            !env_int("HIFIC_NO_PHS", 0)) {
             const int n0_ = p.ph[0].ntaps, n1_ = p.ph[1].ntaps, n2_ = p.ph[2].ntaps, n3_ = p.ph[3].ntaps;
             if (n0_ == 1 && n1_ == 2 && n2_ == 2 && n3_ == 4) phs = 1;
             else if (n0_ == 4 && n1_ == 2 && n2_ == 2 && n3_ == 1) phs = 2;
@@ -3166,7 +3170,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     // software-pipelined kernel: one phase of exactly 9 taps, input stride 1, bf16 input, halo patch <= 192 pixels
     bool use_sp9 = false;
     if constexpr (std::is_same<T, bf16_t>::value && BC == 64) {
-        use_sp9 = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 && !p.split &&
+        use_sp9 = bm >= 64 && p.nphase == 1 && p.ph[0].ntaps == 9 && p.ist == 1 && !p.in_f32 && !p.split && !p.oscale &&
                   p.NI * p.ph[0].PH * p.ph[0].PW <= 192 && !env_int("HIFIC_NO_SP", 0) &&
                   64 + 3 * (size_t)bm * PITCH + 2 * (((size_t)(p.NI * p.ph[0].PH * p.ph[0].PW + 2) * PITCH + 15) & ~(size_t)15) <= (size_t)kLdsBudget;
     }
@@ -3241,7 +3245,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                                        : (bm <= 32 ? env_int("HIFIC_KSPLIT_MAXGRID_32", 400) : env_int("HIFIC_KSPLIT_MAXGRID", 160));
         if (g0 <= gmax && nch >= 4 &&
             chain_us >= (use_sp9 ? env_int("HIFIC_KSPLIT_MIN_US_SP", 60) : env_int("HIFIC_KSPLIT_MIN_US", 20)) &&
-            !p.fold_h && !p.resid && !p.msplit && !p.csplit && env_int("HIFIC_KSPLIT", 1)) {
+            !p.fold_h && !p.resid && !p.msplit && !p.csplit && !p.oscale && env_int("HIFIC_KSPLIT", 1)) {
             int ks = (int)cdivl(env_int("HIFIC_KSPLIT_TARGET", 800), g0);
             if (ks > nch / 2) ks = nch / 2;
             if (ks > 16) ks = 16;
@@ -3717,7 +3721,7 @@ static int launch_gconv_vc(GcParams& p, const float* w, const float* w_scale, lo
 
 static int launch_gconv(GcParams& p, int dtype, const float* w, const float* w_scale, long long sm, long long sc,
                         long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
-    if (dtype == HIFIC_BF16) {
+    if (dtype == HIFIC_BF16 && !p.oscale) {
         int rcv = launch_gconv_vc(p, w, w_scale, sm, sc, sr, ss, ws, st);
         if (rcv != HIFIC_ERR_UNSUPPORTED) return rcv;
         int rc = launch_gconv_fewc(p, w, w_scale, sm, sc, sr, ss, ws, st);
@@ -3750,6 +3754,7 @@ int gc_conv_fwd(const ConvGeom& g, const void* x, const float* w, const float* w
     finish_phase(ph, p);
     const long long RS = (long long)g.R * g.S;
     p.split = g.red_split == 2;
+    p.oscale = g.oscale;
     const double cred = g.red_split == 2 ? (g.red_C > 0 ? g.red_C : g.C / 2) : (g.red_split ? g.C / 3.0 : g.C);
     p.aflops = 2.0 * g.K * cred * (double)RS * g.N * g.OH() * g.OW();
     return launch_gconv(p, dtype, w, w_scale, (long long)g.C * RS, RS, g.S, 1, ws, st);
@@ -3767,7 +3772,7 @@ int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const fl
     // domain through the software-pipelined kernel (see gconv_sp9_kernel RFX).  Falls through to the padded-domain
     // route when the plan cannot use that kernel.
     if (fold && dtype == HIFIC_BF16 && g.R == 3 && g.S == 3 && stv == 1 && g.pt == 1 && g.pl == 1 && g.pb == 1 && g.pr == 1 &&
-        g.H >= 4 && g.W >= 4 && g.C > 32 && g.K > 16 && !env_int("HIFIC_NO_RFX", 0)) {
+        g.H >= 4 && g.W >= 4 && g.C > 32 && g.K > 16 && !g.oscale && !env_int("HIFIC_NO_RFX", 0)) {
         const size_t ws_mark = ws.off;
         const size_t e_elems = (size_t)g.N * g.K * (g.H + 2) * (g.W + 2);
         bf16_t* E = (bf16_t*)ws.take(e_elems * sizeof(bf16_t));
@@ -3798,7 +3803,7 @@ int gc_conv_bwd_data(const ConvGeom& g, const void* dy, const float* w, const fl
         ws.off = ws_mark;
     }
     GcParams p; memset(&p, 0, sizeof(p));
-    p.in = dy; p.bias = nullptr; p.resid = nullptr;
+    p.in = dy; p.bias = nullptr; p.resid = nullptr; p.oscale = g.oscale;
     p.N = g.N; p.C = g.K; p.IH = g.OH(); p.IW = g.OW(); p.K = g.C;
     p.ist = 1; p.ost = stv; p.bmode = PAD_ZERO; p.act = ACT_NONE; p.in_f32 = in_f32;
     float* padbuf = nullptr;

@@ -211,11 +211,14 @@ __device__ __forceinline__ void cn_block_remap(int& bx, int& by, int remap) {
     by = (int)(bid / gridDim.x); bx = (int)(bid - (unsigned)by * gridDim.x);
 }
 
-template <typename T, int PXB, int NW, int CPT>
+// RES: y = act(norm(x)) + resid - the residual add of a ResidualBlock (generator.py:44: `torch.add(res, identity_map)`)
+// folded into the block's second norm (one 8 MB read-modify-write pass and a launch less per block and forward).
+template <typename T, int PXB, int NW, int CPT, bool RES = false>
 __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, T* __restrict__ y,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                             int C, int HW, float eps, int relu, int remap) {
+                                                             int C, int HW, float eps, int relu, int remap,
+                                                             const T* __restrict__ resid = nullptr) {
     constexpr int SUBS = 64 / PXB, G = NW * SUBS;
     __shared__ float red[2][NW][PXB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -230,12 +233,13 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict
     T* yb = y + (size_t)n * C * HW;
     // gamma/beta are loaded here, unconditionally, with everything else: a load inside the (predicated) output
     // loop costs one memory round trip per channel
-    float v[CPT], gm[CPT], bt[CPT];
+    float v[CPT], gm[CPT], bt[CPT], rs[RES ? CPT : 1];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int c = g + G * k; const int ci = c < C ? c : C - 1;
         v[k] = DT<T>::ld(xb + ((unsigned)ci * (unsigned)HW + (unsigned)hw));
         gm[k] = gamma[ci]; bt[k] = beta[ci];
+        if constexpr (RES) rs[k] = DT<T>::ld(resid + (size_t)n * C * HW + ((unsigned)ci * (unsigned)HW + (unsigned)hw));
     }
     float s = 0.f;
 #pragma unroll
@@ -264,6 +268,11 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict
         if (ok && c < C) {
             float o = gm[k] * ((v[k] - mu) * r) + bt[k];
             if (relu) o = o > 0.f ? o : 0.f;
+            if constexpr (RES) {
+                // the sum the separate add kernel would form: both terms rounded to the storage type first
+                T on; DT<T>::st(&on, o);
+                o = DT<T>::ld(&on) + rs[k];
+            }
             DT<T>::st(yb + ((unsigned)c * (unsigned)HW + (unsigned)hw), o);
         }
     }
@@ -611,6 +620,31 @@ static int cn_pit(int N, int HW, const CnCfg& cfg) {   // pixel groups per workg
 extern "C" {
 
 // x,y: [N,C,H*W] dtype; gamma,beta: [C] f32; mean,rstd: [N,H*W] f32 (saved for backward)
+// y = act(norm(x)) + resid (resid: same shape / dtype as x; the residual add of generator.py:44 folded into the block's second
+// norm).  HIFIC_ERR_UNSUPPORTED when the shape has no register-resident configuration: the caller adds separately.
+int hific_channelnorm_fwd_res(const void* x, const float* gamma, const float* beta, const void* resid, void* y, float* mean,
+                              float* rstd, int N, int C, int HW, float eps, int relu, int dtype, hipStream_t st) {
+    if (C < 2 || N <= 0 || HW <= 0 || !resid) return HIFIC_ERR_ARG;
+    if (dtype != HIFIC_F32 && dtype != HIFIC_BF16) return HIFIC_ERR_ARG;
+    CnCfg cfg;
+    if (!cn_pick(N, C, HW, cfg) || cfg.cpt != 16) return HIFIC_ERR_UNSUPPORTED;
+    dim3 rgrid(cdiv(HW, cfg.pxb), N);
+#define CN_FWD_RR(TT, PXB, NWV) hipLaunchKernelGGL((cn_fwd_reg_kernel<TT, PXB, NWV, 16, true>), rgrid, dim3(NWV * 64), 0, st, \
+                                       (const TT*)x, gamma, beta, (TT*)y, mean, rstd, C, HW, eps, relu, cn_remap_flag(1), (const TT*)resid)
+#define CN_FWD_RC(TT)                                                                         \
+    do {                                                                                      \
+        if (cfg.pxb == 64 && cfg.nw == 4) CN_FWD_RR(TT, 64, 4);                               \
+        else if (cfg.pxb == 64 && cfg.nw == 8) CN_FWD_RR(TT, 64, 8);                          \
+        else if (cfg.pxb == 64) CN_FWD_RR(TT, 64, 16);                                        \
+        else if (cfg.pxb == 32) CN_FWD_RR(TT, 32, 16);                                        \
+        else CN_FWD_RR(TT, 16, 16);                                                           \
+    } while (0)
+    if (dtype == HIFIC_F32) CN_FWD_RC(float); else CN_FWD_RC(bf16_t);
+#undef CN_FWD_RC
+#undef CN_FWD_RR
+    return hific_launch_status();
+}
+
 int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                           int N, int C, int HW, float eps, int relu, int dtype, hipStream_t st) {
     if (C < 2 || N <= 0 || HW <= 0) return HIFIC_ERR_ARG;

@@ -32,6 +32,7 @@ SIGNATURES = {
     "hific_conv_transpose2d_bwd_data": (I, [P, P, P] + [I] * 12 + [P, Z, P, Z, I, P]),
     "hific_conv_transpose2d_bwd_weight": (I, [P, P, P] + [I] * 13 + [P, Z, P]),
     "hific_channelnorm_fwd": (I, [P, P, P, P, P, P, I, I, I, F, I, I, P]),
+    "hific_channelnorm_fwd_res": (I, [P, P, P, P, P, P, P, I, I, I, F, I, I, P]),
     "hific_channelnorm_fwd_exact": (I, [P, P, P, P, P, P, P, P, I, I, I, F, I, I, P]),
     "hific_channelnorm_bwd_ws_bytes": (Z, [I, I, I]),
     "hific_channelnorm_bwd": (I, [P] * 9 + [I, I, I, I, I, I, P, Z, P, I, P]),

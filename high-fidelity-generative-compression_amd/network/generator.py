@@ -36,6 +36,8 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         x_conv, identity_map = ops.fork(x)
         res = self.norm1(self.conv1(x_conv))
+        if isinstance(self.norm2, channel.ChannelNorm2D):
+            return self.norm2(self.conv2(res), resid=identity_map)         # norm + residual add in one kernel
         res = self.norm2(self.conv2(res))
         return ops.add(res, identity_map)
 

@@ -32,10 +32,13 @@ class ChannelNorm2D(nn.Module):
             self.register_buffer("gamma", torch.ones(1, input_channels, 1, 1), persistent=False)
             self.register_buffer("beta", torch.zeros(1, input_channels, 1, 1), persistent=False)
 
-    def forward(self, x):
+    def forward(self, x, resid=None):
+        """`resid`: added to the normalised output in the same kernel (ResidualBlock: generator.py:44)."""
         prod = self.__dict__.get("_bias_producer")
         prev_bias = prod.bias if (prod is not None and prod.bias is not None and prod.bias_grad_in_norm) else None
-        return ops.channel_norm(x, self.gamma, self.beta, self.eps, relu=self.fuse_relu, prev_bias=prev_bias)
+        if resid is not None and (resid.dtype != x.dtype or resid.shape != x.shape):
+            return ops.add(ops.channel_norm(x, self.gamma, self.beta, self.eps, relu=self.fuse_relu, prev_bias=prev_bias), resid)
+        return ops.channel_norm(x, self.gamma, self.beta, self.eps, relu=self.fuse_relu, prev_bias=prev_bias, resid=resid)
 
 
 def fuse_bias_grad(conv, norm):

@@ -860,14 +860,29 @@ class ChannelNormFn(Function):
     convolution skips its own channel-sum pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, prev_bias=None):
-        require_gpu(x, gamma, beta)
+    def forward(ctx, x, gamma, beta, eps, relu, prev_bias=None, resid=None):
+        """`resid` (same shape / dtype as x): y = act(norm(x)) + resid in the same kernel (the residual add of a
+        ResidualBlock, generator.py:44); its gradient is dy itself."""
+        require_gpu(x, gamma, beta, resid)
         N, C, H, W = x.shape
         y = torch.empty_like(x)
         mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        call("hific_channelnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), N, C, H * W,
-             float(eps), int(relu), lib.dtype_code(x), stream())
+        fused = False
+        if resid is not None:
+            assert resid.shape == x.shape and resid.dtype == x.dtype
+            rc = lib.raw("hific_channelnorm_fwd_res")(ptr(x), ptr(gamma), ptr(beta), ptr(resid), ptr(y), ptr(mean), ptr(rstd), N,
+                                                      C, H * W, float(eps), int(relu), lib.dtype_code(x), stream())
+            if rc == 0:
+                fused = True
+            elif rc != -4:
+                raise lib.HificError(f"hific_channelnorm_fwd_res failed (rc={rc})")
+        if not fused:
+            call("hific_channelnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), N, C, H * W,
+                 float(eps), int(relu), lib.dtype_code(x), stream())
+            if resid is not None:
+                y = _add(y, resid)
+        ctx.has_resid = resid is not None
         ctx.relu = int(relu)
         ctx.g_slot, ctx.b_slot = _slot(gamma), _slot(beta)
         ctx.has_prev, ctx.p_slot = prev_bias is not None, _slot(prev_bias)
@@ -892,7 +907,7 @@ class ChannelNormFn(Function):
         call("hific_channelnorm_bwd", ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dgt),
              ptr(dbt), N, C, H * W, ctx.relu, acc_g, lib.dtype_code(x), wsp, wsb, ptr(dpt), acc_p, stream())
         _written(ctx.g_slot, ctx.b_slot, ctx.p_slot if dpt is not None else None)
-        return dx, dg, db, None, None, dp
+        return dx, dg, db, None, None, dp, (dy if ctx.has_resid else None)
 
 
 class ExactConvNormFn(Function):
@@ -1006,8 +1021,8 @@ def split3_act(x, layout=SPLIT_3C):
     return _split3_act(x.contiguous(), layout)
 
 
-def channel_norm(x, gamma, beta, eps=1e-3, relu=False, prev_bias=None):
-    return ChannelNormFn.apply(x.contiguous(), gamma, beta, eps, relu, prev_bias)
+def channel_norm(x, gamma, beta, eps=1e-3, relu=False, prev_bias=None, resid=None):
+    return ChannelNormFn.apply(x.contiguous(), gamma, beta, eps, relu, prev_bias, None if resid is None else resid.contiguous())
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -1404,6 +1419,10 @@ def spectral_norm_power_iteration(weight_orig, u, v, do_iter, eps=1e-12):
     return sig
 
 
+# spectral-norm convolutions: 1/sigma in the conv epilogue + cached packs (flags bit 4); HIFIC_SN_EPI_SCALE=0: scaled packs
+_SN_EPI_SCALE = 16 if os.environ.get("HIFIC_SN_EPI_SCALE", "1") not in ("0", "") else 0
+
+
 class SNConv2dFn(Function):
     """Conv2d with weight = weight_orig / sigma(u, v).  `sig` = [sigma, 1/sigma] from the power iteration; (u, v)
     are the post-iteration buffers (treated as constants, as in torch's spectral_norm)."""
@@ -1424,8 +1443,14 @@ class SNConv2dFn(Function):
             flags = _is_f32(x) | (_is_f32(y) << 1)
         wsp, wsb = _ws(x)
         inv_sigma = sig[1:]
+        # flags bit 4: 1/sigma multiplies the accumulator in the conv epilogue, so the packed weights are those of
+        # weight_orig alone and live in the pack cache like every other layer's (re-packed once per optimizer step in the
+        # batched pass) - the sigma-scaled pack was a 12 us launch per spectral-norm conv, forward and data gradient
+        flags |= _SN_EPI_SCALE
+        wc = _wcache(weight_orig, 0, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None) \
+            if _SN_EPI_SCALE else (None, 0, 0)
         call("hific_conv2d_fwd", ptr(x), ptr(weight_orig), ptr(inv_sigma), ptr(bias), None, ptr(y),
-             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, None, 0, 0,
+             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc,
              stream())
         ctx.geom, ctx.act, ctx.cd = geom, act, cd
         ctx.w_slot, ctx.b_slot = _slot(weight_orig), _slot(bias)
@@ -1454,9 +1479,11 @@ class SNConv2dFn(Function):
         ev = torch.cuda.current_stream(x.device).record_event() if side else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
+            flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0) | _SN_EPI_SCALE
+            wc = _wcache(weight_orig, 1, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None) \
+                if _SN_EPI_SCALE else (None, 0, 0)
             call("hific_conv2d_bwd_data", ptr(dy), ptr(weight_orig), ptr(inv_sigma), ptr(dx), N, C, H, W, K, R, S,
-                 stride, pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, None, 0, 0, stream())
+                 stride, pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, *wc, stream())
 
         def param_grads():
             nonlocal dw, db

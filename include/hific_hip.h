@@ -87,6 +87,11 @@ int hific_conv_transpose2d_bwd_weight(const void* x, const void* dy, float* dw, 
 /* ---- ChannelNorm2D (csrc/norm.hip) — src/normalisation/channel.py:48-59 (+ the ReLU after it) ------------- */
 int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                           int N, int C, int HW, float eps, int relu, int dtype, hipStream_t stream);
+/* y = act(norm(x)) + resid: the residual add of a ResidualBlock (src/network/generator.py:44) folded into the block's second
+ * norm (both terms rounded to the storage type first, i.e. bit-identical to hific_channelnorm_fwd followed by hific_add).
+ * Returns -4 when the shape has no register-resident configuration (callers then add separately). */
+int hific_channelnorm_fwd_res(const void* x, const float* gamma, const float* beta, const void* resid, void* y, float* mean,
+                              float* rstd, int N, int C, int HW, float eps, int relu, int dtype, hipStream_t stream);
 /* The norm between two split-bf16 convolutions of the exact-index chain (encoder.py:56-93 blocks in bf16 mode): z is the
  * float32 output of the exact convolution; writes zb = bf16(z) (for this norm's backward), y = bf16 of the float32 result
  * (the nominal activation of the bf16 autograd graph) and x3 [N,3C,HW] = (hi, lo, hi) of that result (operand of the next
