@@ -23,7 +23,7 @@ def trace(db, skip_cycles=0, adam_per_cycle=3):
     out, adam, cycles = {}, 0, 0
     for n, st, en in rows:
         cyc = adam // adam_per_cycle
-        if "adam_dev_kernel" in n or n.startswith("adam_kernel"):      # (not adam_prep_kernel: one per optimizer step too)
+        if "adam_dev_kernel" in n or "adam_dev4_kernel" in n or n.startswith("adam_kernel"):      # (not adam_prep_kernel: one per optimizer step too)
             adam += 1
         if cyc < skip_cycles:
             continue
