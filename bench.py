@@ -181,7 +181,8 @@ def choose_launch(args, step, world, fence, ncal=4):
     calibration is reported in the line.  HIFIC_BENCH_GRAPH=0 / 1 forces eager / graph.  Multi-rank runs launch eagerly:
     the bucketed all-reduce lives on its own stream."""
     flag = os.environ.get("HIFIC_BENCH_GRAPH", "auto")
-    if world > 1 or flag == "0":
+    # (HIFIC_FORCE_DIST: the one-rank RCCL smoke run drives the reducer - reduce stream, timed events - like a multi-rank job)
+    if world > 1 or flag == "0" or os.environ.get("HIFIC_FORCE_DIST") == "1":
         return step, False, None
     gstep, ok = graphed(args, step, world, force=True)
     if not ok:
