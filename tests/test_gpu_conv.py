@@ -209,3 +209,42 @@ def test_weight_pack_cache_tracks_weight_updates(hific, dev):
     opt.zero_grad()
     assert same(run(), ref3)
     ops.pack_cache.clear()
+
+
+def test_merged_phase_kernel_equals_the_per_phase_kernel(hific, dev):
+    """gconv_mp_kernel (round 4: the two column phases of an output-row parity in one workgroup, one staged patch, pair
+    stores) against the per-phase generic kernel on a launch large enough to take it (conv-transpose 120 -> 60, 8 x 64 x 64:
+    512 workgroups): same chunk / tap accumulation order per output element, so the results are bit-identical; also the
+    data gradient of a stride-2 reflect-padded conv (fold epilogue through the padded float32 buffer)."""
+    import os
+    from hific_amd import ops, lib
+    hific.set_compute_dtype(torch.bfloat16)
+    x = _rnd((8, 120, 64, 64), 11, torch.bfloat16).to(dev).bfloat16()
+    w = (_rnd((120, 60, 3, 3), 12, torch.float32) * 0.05).to(dev)
+    b = _rnd((60,), 13, torch.float32).to(dev)
+    dy = _rnd((8, 128, 64, 64), 14, torch.bfloat16).to(dev).bfloat16()
+    w2 = (_rnd((128, 64, 4, 4), 15, torch.float32) * 0.05).to(dev)
+    outs = {}
+    was = os.environ.get("HIFIC_MP")
+    try:
+        for mp in ("1", "0"):
+            os.environ["HIFIC_MP"] = mp
+            ops.pack_cache.clear()
+            with torch.no_grad():
+                y = ops.conv_transpose2d(x, w, b, 2, 1, 1, act="relu")
+            dx = torch.empty((8, 64, 128, 128), dtype=torch.bfloat16, device=dev)
+            ws = lib.workspace(dev)
+            lib.call("hific_conv2d_bwd_data", dy.data_ptr(), w2.data_ptr(), None, dx.data_ptr(), 8, 64, 128, 128, 128, 4, 4, 2,
+                     1, 1, 1, 1, lib.PAD_REFLECT, lib.HIFIC_BF16, 0, ws.data_ptr(), ws.numel(), None, 0, 0, lib.stream())
+            torch.cuda.synchronize()
+            outs[mp] = (y.clone(), dx.clone())
+    finally:
+        if was is None:
+            os.environ.pop("HIFIC_MP", None)
+        else:
+            os.environ["HIFIC_MP"] = was
+        ops.pack_cache.clear()
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert torch.equal(outs["1"][1], outs["0"][1])
+    yr = F.relu(F.conv_transpose2d(x.float().cpu(), w.cpu(), b.cpu(), stride=2, padding=1, output_padding=1))
+    assert _relerr(outs["1"][0].float().cpu(), yr) < 2e-2

@@ -443,3 +443,60 @@ def test_vectorised_coder_takes_device_tensors(hific, dev, shape):
     dec_d = rans.ans_decompress(enc_d, idx.to(dev), cdf, cl, co, cs_d, 16, vectorize=True, device=dev)
     assert isinstance(dec_d, torch.Tensor) and dec_d.is_cuda and dec_d.dtype == torch.int32
     assert tuple(dec_d.shape) == shape and np.array_equal(dec_d.cpu().numpy(), dec_h)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_channelnorm_with_residual_equals_norm_then_add(hific, dev, dt):
+    """hific_channelnorm_fwd_res (round 4: the ResidualBlock's add folded into its second norm, generator.py:44): bit-identical
+    to the norm followed by hific_add, and the residual's gradient is the incoming gradient itself."""
+    from hific_amd import ops
+    x = _rnd((2, 960, 16, 16), 1).to(dev).to(dt).requires_grad_(True)
+    r = _rnd((2, 960, 16, 16), 2).to(dev).to(dt).requires_grad_(True)
+    g = (torch.rand(1, 960, 1, 1, device=dev) + 0.5).requires_grad_(True)
+    b = (torch.rand(1, 960, 1, 1, device=dev) - 0.5).requires_grad_(True)
+    y1 = ops.channel_norm(x, g, b, 1e-3, relu=False, resid=r)
+    y2 = ops.add(ops.channel_norm(x, g, b, 1e-3, relu=False), r)
+    assert torch.equal(y1, y2)
+    dy = _rnd((2, 960, 16, 16), 3).to(dev).to(dt)
+    gx1, gr1, gg1 = torch.autograd.grad(y1, (x, r, g), dy)
+    gx2, gr2, gg2 = torch.autograd.grad(y2, (x, r, g), dy)
+    torch.cuda.synchronize()
+    assert torch.equal(gx1, gx2) and torch.equal(gr1, gr2) and torch.equal(gr1, dy) and torch.equal(gg1, gg2)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)], ids=["f32", "bf16"])
+def test_spectral_norm_conv_scale_in_the_epilogue(hific, dev, dt, tol):
+    """flags bit 4 (round 4): 1/sigma multiplies the accumulator in the conv epilogue and the packed weights are those of
+    weight_orig alone (cached across forwards) - against the scaled-pack form and against torch on W / sigma."""
+    from hific_amd import ops, lib
+    hific.set_compute_dtype(dt)
+    ops.pack_cache.clear()
+    x = _rnd((4, 64, 32, 32), 1).to(dev).to(dt)
+    w = (_rnd((128, 64, 4, 4), 2) * 0.05).to(dev)
+    bias = _rnd((128,), 3).to(dev)
+    u = F.normalize(_rnd((128,), 4), dim=0).to(dev)
+    v = F.normalize(_rnd((1024,), 5), dim=0).to(dev)
+    geom = (2, 1, 1, 1, 1, lib.PAD_REFLECT)
+    res = {}
+    was = ops._SN_EPI_SCALE
+    try:
+        for mode in (16, 0):
+            ops._SN_EPI_SCALE = mode
+            xd = x.clone().requires_grad_(True)
+            wd = w.clone().requires_grad_(True)
+            bd = bias.clone().requires_grad_(True)
+            uu, vv = u.clone(), v.clone()
+            sig = ops.spectral_norm_power_iteration(wd.detach(), uu, vv, do_iter=True)
+            y = ops.SNConv2dFn.apply(xd, wd, bd, uu, vv, sig, geom, "leaky_relu", False)
+            y.float().square().sum().backward()
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().float().cpu(), xd.grad.float().cpu(), wd.grad.cpu(), bd.grad.cpu(), float(sig[0]))
+    finally:
+        ops._SN_EPI_SCALE = was
+        ops.pack_cache.clear()
+        hific.set_compute_dtype(torch.float32)
+    for a, b2 in zip(res[16][:4], res[0][:4]):
+        assert _relerr(a, b2) < tol
+    xp = F.pad(x.float().cpu(), (1, 1, 1, 1), mode="reflect")
+    yr = F.leaky_relu(F.conv2d(xp, w.cpu() / res[16][4], bias.cpu(), stride=2), 0.2)
+    assert _relerr(res[16][0], yr) < tol
