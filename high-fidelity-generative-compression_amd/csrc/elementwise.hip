@@ -419,6 +419,77 @@ __global__ __launch_bounds__(256) void sn_sigma_kernel(const float* __restrict__
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) { sigma_out[0] = s; sigma_out[1] = 1.f / s; }
 }
+// ---- the same chain for several layers per launch (the Discriminator's four spectral-norm convolutions: their power
+// iterations depend only on the weights and run at the top of Discriminator.forward - 6 launches instead of 24) --------------
+#define SN_MAXJOBS 8
+struct SnJob { const float* W; float* u; float* v; float* sig; float* tmpM; float* tmpK; float* part; int K, M; };
+struct SnJobs { SnJob j[SN_MAXJOBS]; };
+__global__ __launch_bounds__(256) void sn_wtu_batch_kernel(const SnJobs J) {
+    const SnJob& q = J.j[blockIdx.z];
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int k0 = blockIdx.y * SN_ROWS;
+    if (m >= q.M || k0 >= q.K) return;
+    float w[SN_ROWS];
+#pragma unroll
+    for (int j = 0; j < SN_ROWS; ++j) {
+        const int k = k0 + j < q.K ? k0 + j : q.K - 1;
+        w[j] = q.W[(size_t)k * q.M + m];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < SN_ROWS; ++j) s += (k0 + j < q.K) ? w[j] * q.u[k0 + j] : 0.f;
+    q.part[(size_t)blockIdx.y * q.M + m] = s;
+}
+__global__ __launch_bounds__(256) void sn_colsum_batch_kernel(const SnJobs J) {
+    const SnJob& q = J.j[blockIdx.y];
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= q.M) return;
+    const int nslice = (q.K + SN_ROWS - 1) / SN_ROWS;
+    float s = 0.f;
+    int j = 0;
+    for (; j + 8 <= nslice; j += 8) {
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t[r] = q.part[(size_t)(j + r) * q.M + m];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += t[r];
+    }
+    for (; j < nslice; ++j) s += q.part[(size_t)j * q.M + m];
+    q.tmpM[m] = s;
+}
+// which 0: v <- normalize(tmpM); 1: u <- normalize(tmpK)
+__global__ __launch_bounds__(256) void sn_normalize_batch_kernel(const SnJobs J, int which, float eps) {
+    const SnJob& q = J.j[blockIdx.x];
+    const float* x = which ? q.tmpK : q.tmpM;
+    float* o = which ? q.u : q.v;
+    const int n = which ? q.K : q.M;
+    __shared__ float sh[4];
+    __shared__ float inv;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) inv = 1.f / fmaxf(sqrtf(s), eps);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) o[i] = x[i] * inv;
+}
+__global__ __launch_bounds__(256) void sn_wv_batch_kernel(const SnJobs J) {
+    const SnJob& q = J.j[blockIdx.y];
+    const int k = blockIdx.x;
+    if (k >= q.K) return;
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int m = threadIdx.x; m < q.M; m += 256) s += q.W[(size_t)k * q.M + m] * q.v[m];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) q.tmpK[k] = s;
+}
+__global__ __launch_bounds__(256) void sn_sigma_batch_kernel(const SnJobs J) {
+    const SnJob& q = J.j[blockIdx.x];
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < q.K; i += 256) s += q.u[i] * q.tmpK[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) { q.sig[0] = s; q.sig[1] = 1.f / s; }
+}
 // backward: dWorig = (dW - (sum dW*Worig)/sigma * u v^T) / sigma
 __global__ __launch_bounds__(256) void sn_dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              float* __restrict__ part, long long n) {
@@ -805,6 +876,40 @@ int hific_upcat_bwd(const void* dout, void* dimg, int n0, int nimg, void* dctx, 
             hipLaunchKernelGGL(upcat_bwd_ctx_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)dout, (float*)dctx, N, Ci, Cc, H, W, f),
             hipLaunchKernelGGL(upcat_bwd_ctx_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dctx, N, Ci, Cc, H, W, f));
     }
+    return hific_launch_status();
+}
+
+// n <= 8 layers per call: W[i] f32 [K[i], M[i]], u[i] [K[i]], v[i] [M[i]] updated in place (do_iter), sig[i] = [sigma, 1/sigma].
+// Same arithmetic per layer as hific_spectral_norm_fwd (bit-identical), 6 launches for the whole set.
+int hific_spectral_norm_fwd_batch(const float* const* W, float* const* u, float* const* v, float* const* sig, const int* K,
+                                  const int* M, int n, int do_iter, float eps, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n <= 0 || n > SN_MAXJOBS || !W || !u || !v || !sig || !K || !M) return HIFIC_ERR_ARG;
+    SnJobs J;
+    float* wp = (float*)ws;
+    size_t used = 0;
+    int maxK = 0, maxM = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!W[i] || !u[i] || !v[i] || !sig[i] || K[i] <= 0 || M[i] <= 0) return HIFIC_ERR_ARG;
+        const int nslice = cdiv(K[i], SN_ROWS);
+        const size_t need = (size_t)M[i] + K[i] + (size_t)nslice * M[i];
+        if ((used + need) * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
+        J.j[i].W = W[i]; J.j[i].u = u[i]; J.j[i].v = v[i]; J.j[i].sig = sig[i]; J.j[i].K = K[i]; J.j[i].M = M[i];
+        J.j[i].tmpM = wp + used; J.j[i].tmpK = J.j[i].tmpM + M[i]; J.j[i].part = J.j[i].tmpK + K[i];
+        used += need;
+        if (K[i] > maxK) maxK = K[i];
+        if (M[i] > maxM) maxM = M[i];
+    }
+    for (int i = n; i < SN_MAXJOBS; ++i) J.j[i] = J.j[0];
+    if (do_iter) {
+        hipLaunchKernelGGL(sn_wtu_batch_kernel, dim3(cdiv(maxM, 256), cdiv(maxK, SN_ROWS), n), dim3(256), 0, st, J);
+        hipLaunchKernelGGL(sn_colsum_batch_kernel, dim3(cdiv(maxM, 256), n), dim3(256), 0, st, J);
+        hipLaunchKernelGGL(sn_normalize_batch_kernel, dim3(n), dim3(256), 0, st, J, 0, eps);
+        hipLaunchKernelGGL(sn_wv_batch_kernel, dim3(maxK, n), dim3(256), 0, st, J);
+        hipLaunchKernelGGL(sn_normalize_batch_kernel, dim3(n), dim3(256), 0, st, J, 1, eps);
+    } else {
+        hipLaunchKernelGGL(sn_wv_batch_kernel, dim3(maxK, n), dim3(256), 0, st, J);
+    }
+    hipLaunchKernelGGL(sn_sigma_batch_kernel, dim3(n), dim3(256), 0, st, J);
     return hific_launch_status();
 }
 

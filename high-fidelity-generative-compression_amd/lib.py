@@ -59,6 +59,8 @@ SIGNATURES = {
     "hific_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "hific_upcat_bwd": (I, [P, P, I, I, P, I, I, I, I, I, I, I, P]),
     "hific_spectral_norm_fwd": (I, [P, P, P, P, I, I, I, F, P, Z, P]),
+    "hific_spectral_norm_fwd_batch": (I, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                          POINTER(c_int), POINTER(c_int), I, I, F, P, Z, P]),
     "hific_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, I, P, Z, P]),
     "hific_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
     "hific_adam_prepare": (I, [P, P, F, F, P]),

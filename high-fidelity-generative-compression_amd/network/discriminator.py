@@ -32,10 +32,13 @@ class SNConv2d(nn.Module):
         self.register_buffer("weight_v", v)
         self.stride, self.pad, self.act, self.eps = stride, pad, act, eps
 
-    def forward(self, x):
-        with torch.no_grad():
-            sig = ops.spectral_norm_power_iteration(self.weight_orig, self.weight_u, self.weight_v,
-                                                    do_iter=self.training, eps=self.eps)
+    def forward(self, x, sig=None):
+        """`sig`: [sigma, 1/sigma] of this forward when the owner already ran the power iteration (Discriminator.forward
+        batches the four layers: ops.spectral_norm_power_iteration_batch)."""
+        if sig is None:
+            with torch.no_grad():
+                sig = ops.spectral_norm_power_iteration(self.weight_orig, self.weight_u, self.weight_v,
+                                                        do_iter=self.training, eps=self.eps)
         geom = (self.stride, self.pad, self.pad, self.pad, self.pad, lib.PAD_REFLECT)
         return ops.SNConv2dFn.apply(x.contiguous(), self.weight_orig, self.bias, self.weight_u, self.weight_v, sig,
                                     geom, self.act, False)
@@ -67,10 +70,13 @@ class Discriminator(nn.Module):
         if x.dtype != y.dtype:
             x = ops.cast_grad(x, y.dtype)
         x = ops.UpsampleConcatFn.apply(x.contiguous(), y, self.upsample_factor)
-        x = self.conv1(x)
-        x = self.conv2(x)
-        x = self.conv3(x)
-        x = self.conv4(x)
+        # one power iteration per spectral-norm layer and forward (torch.nn.utils.spectral_norm), the four layers per launch
+        convs = (self.conv1, self.conv2, self.conv3, self.conv4)
+        with torch.no_grad():
+            sigs = ops.spectral_norm_power_iteration_batch([(c.weight_orig, c.weight_u, c.weight_v) for c in convs],
+                                                           do_iter=self.training, eps=convs[0].eps)
+        for c, sg in zip(convs, sigs):
+            x = c(x, sig=sg)
         out_logits = self.conv_out(x).view(-1, 1)
         out = ops.sigmoid(out_logits.detach())
         return out, out_logits

@@ -1419,6 +1419,22 @@ def spectral_norm_power_iteration(weight_orig, u, v, do_iter, eps=1e-12):
     return sig
 
 
+def spectral_norm_power_iteration_batch(layers, do_iter, eps=1e-12):
+    """`layers`: [(weight_orig, u, v), ...] (<= 8): one power iteration each (in place on u, v; no autograd), all layers per
+    launch (hific_spectral_norm_fwd_batch).  Returns one [sigma, 1/sigma] tensor per layer (views of one buffer)."""
+    n = len(layers)
+    ws0, us, vs = zip(*layers)
+    require_gpu(*ws0, *us, *vs)
+    sig = torch.empty((n, 2), dtype=torch.float32, device=ws0[0].device)
+    Ks = (ctypes.c_int * n)(*[w.shape[0] for w in ws0])
+    Ms = (ctypes.c_int * n)(*[w.numel() // w.shape[0] for w in ws0])
+    sp = (ctypes.c_void_p * n)(*[sig[i].data_ptr() for i in range(n)])
+    wsp, wsb = _ws(ws0[0])
+    call("hific_spectral_norm_fwd_batch", _ptr_array(ws0), _ptr_array(us), _ptr_array(vs), sp, Ks, Ms, n, int(do_iter),
+         float(eps), wsp, wsb, stream())
+    return [sig[i] for i in range(n)]
+
+
 # spectral-norm convolutions: 1/sigma in the conv epilogue + cached packs (flags bit 4); HIFIC_SN_EPI_SCALE=0: scaled packs
 _SN_EPI_SCALE = 16 if os.environ.get("HIFIC_SN_EPI_SCALE", "1") not in ("0", "") else 0
 

@@ -168,6 +168,11 @@ int hific_upcat_fwd(const void* img, const void* ctx, void* out, int N, int Ci, 
                     int dtype, hipStream_t stream);
 int hific_upcat_bwd(const void* dout, void* dimg, int n0, int nimg, void* dctx, int N, int Ci, int Cc, int H, int W,
                     int f, int dtype, hipStream_t stream);
+/* The same power iteration for n <= 8 layers in one call (src/network/discriminator.py:53-62: the four spectral-norm convs of
+ * the Discriminator; their iterations depend only on the weights): per layer bit-identical to hific_spectral_norm_fwd, 6
+ * launches for the whole set instead of 6 per layer.  ws >= sum_i (M_i + K_i + ceil(K_i / 16) M_i) floats. */
+int hific_spectral_norm_fwd_batch(const float* const* W, float* const* u, float* const* v, float* const* sig, const int* K,
+                                  const int* M, int n, int do_iter, float eps, void* ws, size_t ws_bytes, hipStream_t stream);
 /* torch.nn.utils.spectral_norm power iteration + sigma (discriminator.py:46-62); sigma_out = {sigma, 1/sigma} */
 int hific_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma_out, int K, int M, int do_iter,
                             float eps, void* ws, size_t ws_bytes, hipStream_t stream);
