@@ -776,6 +776,51 @@ __device__ __forceinline__ void mp_store_pair(const GcParams& p, const GcPhase& 
     }
 }
 
+// Pair stores for a REFLECT-FOLD data gradient (p.fold_h: interior pixels of the padded plane go straight to dx = out2, the rim
+// to the padded float32 buffer `out`) when the left pad is even: column phase 0 of pixel v is padded column 2v, phase 1 is
+// 2v + 1 - an aligned pair that lies entirely inside or entirely outside the interior (even origin, even width).  The last
+// padded column (odd plane width) has no partner and is stored alone.
+template <bool F32O2>
+__device__ __forceinline__ void mp_store_pair_fold(const GcParams& p, const GcPhase& phA, const GcPhase& phB, const f32x16_t a,
+                                                   const f32x16_t b, int mbase, int lhi, int pu_, int pv_, int pn_,
+                                                   bool pvalid_) {
+    const float osc = p.oscale ? *p.oscale : 1.f;
+    const int oy = pu_ * 2 + phA.ooy, ox = pv_ * 2 + phA.oox;
+    const bool okn = pvalid_ && pn_ < p.N && (unsigned)oy < (unsigned)p.OHf;
+    const bool inA = okn && pu_ < phA.OHt && pv_ < phA.OWt && (unsigned)ox < (unsigned)p.OWf;
+    const bool inB = okn && pu_ < phB.OHt && pv_ < phB.OWt && (unsigned)(ox + 1) < (unsigned)p.OWf;
+    if (!inA && !inB) return;
+    const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
+    const bool rowi = (unsigned)iy < (unsigned)p.fold_h;
+    const bool intA = inA && rowi && (unsigned)ix < (unsigned)p.fold_w;
+    const bool intB = inB && rowi && (unsigned)(ix + 1) < (unsigned)p.fold_w;
+    const size_t plane_p = (size_t)p.OHf * p.OWf, plane_i = (size_t)p.fold_h * p.fold_w;
+    const size_t base_p = (size_t)pn_ * p.K * plane_p + (size_t)oy * p.OWf + ox;
+    const size_t base_i = (size_t)pn_ * p.K * plane_i + (size_t)(rowi ? iy : 0) * p.fold_w + (intA || intB ? ix : 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (m >= p.K) continue;
+        const float x0 = a[r] * osc, x1 = b[r] * osc;
+        if (intA && intB) {
+            const size_t idx = base_i + (size_t)m * plane_i;
+            if constexpr (F32O2) *(float2*)((float*)p.out2 + idx) = make_float2(x0, x1);
+            else *(unsigned*)((bf16_t*)p.out2 + idx) = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+        } else {
+            if (inA) {
+                if (intA) { if constexpr (F32O2) ((float*)p.out2)[base_i + (size_t)m * plane_i] = x0;
+                            else ((bf16_t*)p.out2)[base_i + (size_t)m * plane_i] = f2bf(x0); }
+                else ((float*)p.out)[base_p + (size_t)m * plane_p] = x0;
+            }
+            if (inB) {
+                if (intB) { if constexpr (F32O2) ((float*)p.out2)[base_i + (size_t)m * plane_i + 1] = x1;
+                            else ((bf16_t*)p.out2)[base_i + (size_t)m * plane_i + 1] = f2bf(x1); }
+                else ((float*)p.out)[base_p + (size_t)m * plane_p + 1] = x1;
+            }
+        }
+    }
+}
+
 template <bool SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gconv_mp_kernel(const GcParams p) {
@@ -936,6 +981,14 @@ void gconv_mp_kernel(const GcParams p) {
 #undef MP_WSTORE
 #undef MP_WLOAD
     const int mbase = m0 + wm * 32;
+    if (p.epi_wide == 3) {
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            if (p.out2_f32) mp_store_pair_fold<true>(p, PA, PB, acc0[ni], acc1[ni], mbase, lhi, pu[ni], pv[ni], pn[ni], pvalid[ni]);
+            else mp_store_pair_fold<false>(p, PA, PB, acc0[ni], acc1[ni], mbase, lhi, pu[ni], pv[ni], pn[ni], pvalid[ni]);
+        }
+        return;
+    }
     if (p.epi_wide == 2) {
         const bool hb = p.bias != nullptr;
         const float* bp = hb ? p.bias : (const float*)p.in;
@@ -3197,6 +3250,12 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             p.ph[0].OHt == p.ph[1].OHt && p.ph[0].OWt == p.ph[1].OWt && p.ph[2].OHt == p.ph[3].OHt &&
             p.ph[2].OWt == p.ph[3].OWt && (((size_t)p.out) & 7) == 0 && !env_int("HIFIC_MP_NO_PAIR", 0))
             p.epi_wide = 2;
+        // reflect-fold data gradients with an even left pad (the Encoder's asymmetric pad (1, 0, 0, 1)): pair stores into dx
+        if (p.fold_h && p.out2 && !p.bias && p.act == ACT_NONE && p.fold_pl % 2 == 0 && p.fold_w % 2 == 0 &&
+            p.ph[0].ooy == p.ph[1].ooy && p.ph[2].ooy == p.ph[3].ooy && p.ph[0].oox == 0 && p.ph[1].oox == 1 &&
+            p.ph[2].oox == 0 && p.ph[3].oox == 1 && p.ph[0].OHt == p.ph[1].OHt && p.ph[2].OHt == p.ph[3].OHt &&
+            (((size_t)p.out2) & 7) == 0 && !env_int("HIFIC_MP_NO_PAIR", 0))
+            p.epi_wide = 3;
     }
     if (phs) {
         GcPhase& u = p.ph[4];

@@ -224,6 +224,7 @@ def test_merged_phase_kernel_equals_the_per_phase_kernel(hific, dev):
     b = _rnd((60,), 13, torch.float32).to(dev)
     dy = _rnd((8, 128, 64, 64), 14, torch.bfloat16).to(dev).bfloat16()
     w2 = (_rnd((128, 64, 4, 4), 15, torch.float32) * 0.05).to(dev)
+    w3 = (_rnd((128, 64, 3, 3), 16, torch.float32) * 0.05).to(dev)
     outs = {}
     was = os.environ.get("HIFIC_MP")
     try:
@@ -236,8 +237,13 @@ def test_merged_phase_kernel_equals_the_per_phase_kernel(hific, dev):
             ws = lib.workspace(dev)
             lib.call("hific_conv2d_bwd_data", dy.data_ptr(), w2.data_ptr(), None, dx.data_ptr(), 8, 64, 128, 128, 128, 4, 4, 2,
                      1, 1, 1, 1, lib.PAD_REFLECT, lib.HIFIC_BF16, 0, ws.data_ptr(), ws.numel(), None, 0, 0, lib.stream())
+            # the Encoder's asymmetric reflect pad (top 1, left 0, bottom 0, right 1), 3x3 stride 2: even left pad -> pair
+            # stores straight into dx for the interior, the rim through the padded float32 buffer
+            dx2 = torch.empty((8, 64, 128, 128), dtype=torch.bfloat16, device=dev)
+            lib.call("hific_conv2d_bwd_data", dy.data_ptr(), w3.data_ptr(), None, dx2.data_ptr(), 8, 64, 128, 128, 128, 3, 3, 2,
+                     1, 0, 0, 1, lib.PAD_REFLECT, lib.HIFIC_BF16, 0, ws.data_ptr(), ws.numel(), None, 0, 0, lib.stream())
             torch.cuda.synchronize()
-            outs[mp] = (y.clone(), dx.clone())
+            outs[mp] = (y.clone(), dx.clone(), dx2.clone())
     finally:
         if was is None:
             os.environ.pop("HIFIC_MP", None)
@@ -246,5 +252,9 @@ def test_merged_phase_kernel_equals_the_per_phase_kernel(hific, dev):
         ops.pack_cache.clear()
     assert torch.equal(outs["1"][0], outs["0"][0])
     assert torch.equal(outs["1"][1], outs["0"][1])
+    assert torch.equal(outs["1"][2], outs["0"][2])
+    xr = torch.zeros((8, 64, 128, 128), dtype=torch.float64, requires_grad=True)
+    F.conv2d(F.pad(xr, (0, 1, 1, 0), mode="reflect"), w3.double().cpu(), stride=2).backward(dy.double().cpu())
+    assert _relerr(outs["1"][2].float().cpu(), xr.grad.float()) < 2e-2
     yr = F.relu(F.conv_transpose2d(x.float().cpu(), w.cpu(), b.cpu(), stride=2, padding=1, output_padding=1))
     assert _relerr(outs["1"][0].float().cpu(), yr) < 2e-2
