@@ -459,13 +459,23 @@ __global__ __launch_bounds__(256) void cn_bwd_v8_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         bf16_t* __restrict__ dx, float* __restrict__ part,
-                                                        int C, int HW, int relu, int remap) {
+                                                        int C, int HW, int relu, int remap, int pit) {
+    // pit > 1 (round 4: the 120 / 240 / 480-channel planes of the Encoder and the up-convolutions, where cn_bwd_reg_kernel
+    // reaches its channel groups with 16-32-pixel runs at 1.1-1.6 TB/s): the workgroup walks `pit` consecutive 8-pixel
+    // groups - whole 128-byte lines of every channel row - and keeps the per-channel sums in its threads across them, so the
+    // partial rows are written once per workgroup.
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    __shared__ float red[4][16];
+    __shared__ float red[2][4][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx, n;
     cn_block_remap(bx, n, remap);                          // the 8 groups of a 128-byte line on one XCD
-    const int hw0 = bx * 8;
+    float pgs[CPT], pbs[CPT], pds[DB ? CPT : 1];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { pgs[k] = 0.f; pbs[k] = 0.f; if constexpr (DB) pds[k] = 0.f; }
+    for (int it = 0; it < pit; ++it) {
+    const int hw0 = (bx * pit + it) * 8;
+    if (hw0 >= HW) break;
+    float (*redp)[16] = red[it & 1];
     float mu[8], r[8];
     {
         const float4* mp = (const float4*)(mean + (size_t)n * HW + hw0);
@@ -515,19 +525,17 @@ __global__ __launch_bounds__(256) void cn_bwd_v8_kernel(const bf16_t* __restrict
     }
     if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { red[wave][j] = s1[j]; red[wave][8 + j] = s2[j]; }
+        for (int j = 0; j < 8; ++j) { redp[wave][j] = s1[j]; redp[wave][8 + j] = s2[j]; }
     }
-    __syncthreads();
+    __syncthreads();                                       // (the LDS buffer alternates per group: one barrier per group)
     float S1[8], S2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float t1 = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
-        const float t2 = (red[0][8 + j] + red[1][8 + j]) + (red[2][8 + j] + red[3][8 + j]);
+        const float t1 = (redp[0][j] + redp[1][j]) + (redp[2][j] + redp[3][j]);
+        const float t2 = (redp[0][8 + j] + redp[1][8 + j]) + (redp[2][8 + j] + redp[3][8 + j]);
         S1[j] = t1 / (float)C;
         S2[j] = t2 * r[j] * r[j] * r[j] / (float)(C - 1);
     }
-    constexpr int NR = DB ? 3 : 2;
-    const size_t blk = (size_t)n * gridDim.x + bx;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int c = tid + 256 * k;
@@ -542,9 +550,20 @@ __global__ __launch_bounds__(256) void cn_bwd_v8_kernel(const bf16_t* __restrict
                 if constexpr (DB) pd += bf2f(lo) + bf2f(hi);              // what the tensor holds
             }
             *(u32x4_t*)(dx + img + (size_t)c * HW) = o;
-            part[(blk * NR + 0) * C + c] = pg[k];
-            part[(blk * NR + 1) * C + c] = pb[k];
-            if constexpr (DB) part[(blk * NR + 2) * C + c] = pd;
+            pgs[k] += pg[k]; pbs[k] += pb[k];
+            if constexpr (DB) pds[k] += pd;
+        }
+    }
+    }   // pixel groups of this workgroup
+    constexpr int NR = DB ? 3 : 2;
+    const size_t blk = (size_t)n * gridDim.x + bx;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C) {
+            part[(blk * NR + 0) * C + c] = pgs[k];
+            part[(blk * NR + 1) * C + c] = pbs[k];
+            if constexpr (DB) part[(blk * NR + 2) * C + c] = pds[k];
         }
     }
 }
@@ -717,6 +736,14 @@ size_t hific_channelnorm_bwd_ws_bytes(int N, int C, int HW) {
         const size_t nblk = (size_t)cdiv(cdiv(HW, cfg.pxb), cn_pit(N, HW, cfg)) * N;
         const size_t r = nblk * 3 * C * sizeof(float);
         if (r > b) b = r;
+        if (HW % 8 == 0) {                                  // the 16-byte-per-lane kernel's partial rows (<= 1024 + N workgroups)
+            const int groups = HW / 8;
+            int pitv = (int)((long long)groups * N / 1024);
+            if (pitv < 1) pitv = 1; if (pitv > 16) pitv = 16;
+            while (groups % pitv) --pitv;
+            const size_t rv = (size_t)(groups / pitv) * N * 3 * C * sizeof(float);
+            if (rv > b) b = rv;
+        }
     }
     return b;
 }
@@ -740,22 +767,33 @@ int hific_channelnorm_bwd(const void* x, const void* dy, const float* gamma, con
         const int nr = dprev_bias ? 3 : 2;
         if (nblk * nr * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
         float* rpart = (float*)ws;
-        // 8-pixel runs (C > 512 on small planes): the 16-byte-per-lane kernel, same partial layout (cn_bwd_v8_kernel)
+        // 8-pixel runs per lane: the 16-byte-per-lane kernel (cn_bwd_v8_kernel), same partial layout.  Round 3: the 960-channel
+        // 16x16 planes (pxb 8).  Round 4: every plane with more than 256 channels (HIFIC_CN_BWD_V8=2: round-3 rule), `pitv`
+        // 8-pixel groups per workgroup so that ~1000 workgroups write partial rows: 480 channels @32x32 43.9 -> 27.5 us.  With one
+        // channel per thread (C <= 256: 240 @64x64 88.6 -> 103 us, 120 @128x128 123 -> 186 us) only two 16-byte loads are in
+        // flight per thread and group - not taken there.
         static const int v8 = getenv("HIFIC_CN_BWD_V8") ? atoi(getenv("HIFIC_CN_BWD_V8")) : 1;
-        if (v8 && dtype == HIFIC_BF16 && cfg.pxb == 8 && pit == 1 && HW % 8 == 0 && C <= 1024 &&
+        const bool v8_shape = cfg.pxb == 8 ? pit == 1 : (v8 != 2 && C > 256);
+        if (v8 && dtype == HIFIC_BF16 && v8_shape && HW % 8 == 0 && C <= 1024 &&
             (((size_t)x | (size_t)dy | (size_t)dx | (size_t)mean | (size_t)rstd) & 15) == 0) {
-            dim3 vgrid(HW / 8, N);
+            const int groups = HW / 8;
+            int pitv = (int)((long long)groups * N / 1024);
+            if (pitv < 1) pitv = 1; if (pitv > 16) pitv = 16;
+            while (groups % pitv) --pitv;
+            dim3 vgrid(groups / pitv, N);
+            const size_t nblk_v = (size_t)vgrid.x * vgrid.y;
+            if (nblk_v * nr * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
 #define CN_BWD_V8(CPT)                                                                                                  \
             do {                                                                                                        \
                 if (dprev_bias) hipLaunchKernelGGL((cn_bwd_v8_kernel<CPT, true>), vgrid, dim3(256), 0, st, (const bf16_t*)x,  \
-                    (const bf16_t*)dy, gamma, beta, mean, rstd, (bf16_t*)dx, rpart, C, HW, relu, cn_remap_flag(2));    \
+                    (const bf16_t*)dy, gamma, beta, mean, rstd, (bf16_t*)dx, rpart, C, HW, relu, cn_remap_flag(2), pitv);    \
                 else hipLaunchKernelGGL((cn_bwd_v8_kernel<CPT, false>), vgrid, dim3(256), 0, st, (const bf16_t*)x,      \
-                    (const bf16_t*)dy, gamma, beta, mean, rstd, (bf16_t*)dx, rpart, C, HW, relu, cn_remap_flag(2));    \
+                    (const bf16_t*)dy, gamma, beta, mean, rstd, (bf16_t*)dx, rpart, C, HW, relu, cn_remap_flag(2), pitv);    \
             } while (0)
-            if (C <= 768) CN_BWD_V8(3); else CN_BWD_V8(4);
+            if (C <= 256) CN_BWD_V8(1); else if (C <= 512) CN_BWD_V8(2); else if (C <= 768) CN_BWD_V8(3); else CN_BWD_V8(4);
 #undef CN_BWD_V8
             hipLaunchKernelGGL(cn_param_colsum_kernel, dim3(cdiv(nr * C, 64)), dim3(1024), 0, st, rpart, dgamma, dbeta, C,
-                               (int)nblk, accumulate, nr, dprev_bias, accumulate_prev);
+                               (int)nblk_v, accumulate, nr, dprev_bias, accumulate_prev);
             return hific_launch_status();
         }
 #define CN_BWD_R(TT, PXB, NWV, CPT)                                                                                    \
