@@ -82,6 +82,7 @@ struct WgParams {
     int wstage_a, wstage_b;   // wide-load staging (stage_W) of the a / b operand: legality checked by the plan
     // small-channel (im2col) mode: virtual columns j = tap*4 + c; see wgrad_im2col_kernel
     int im2col, creal, ntaps_real, tsign, swap_out, a_bmode, a_y0, a_x0, a_h, a_w, b_y0, b_x0;
+    int cqs;                  // im2col mode: log2 of the channel slots per tap (virtual column = (tap << cqs) + channel): 2 or 4
     GcPhase grp[GC_MAXPH];
     short tap_dy[GC_MAXTAPS], tap_dx[GC_MAXTAPS];
     short tap_r[GC_MAXTAPS], tap_s[GC_MAXTAPS];

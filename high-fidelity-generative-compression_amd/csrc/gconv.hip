@@ -2531,11 +2531,11 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
     // per pixel tile and re-used by every 64-column tile (it used to be re-read by one workgroup per column tile: 4x the
     // HBM traffic of the layer's dominant tensor).
     const int tdy_min = p.grp[0].dy_min, tdx_min = p.grp[0].dx_min, tdy_max = p.grp[0].PH, tdx_max = p.grp[0].PW;
-    const int PHh = p.TH + tdy_max - tdy_min, PWw = p.TW + tdx_max - tdx_min;
+    const int PHh = (p.TH - 1) * p.ist + 1 + tdy_max - tdy_min, PWw = (p.TW - 1) * p.ist + 1 + tdx_max - tdx_min;
     const int npl = PHh * PWw;
     if (tid < 256) {
         const int col = tid;
-        const int t = col >> 2, cc = col & 3;
+        const int t = col >> p.cqs, cc = col & ((1 << p.cqs) - 1);
         const bool v = col < p.Cpad && t < p.ntaps_real && cc < p.creal;
         const int tt = t < p.ntaps_real ? t : 0;
         const int dy = p.tsign * (int)p.tap_dy[tt], dx = p.tsign * (int)p.tap_dx[tt];
@@ -2568,7 +2568,7 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
         // the small operand's halo patch: rows y0 .. y0 + PHh - 1, columns x0 .. x0 + PWw - 1 of B (padding rule applied here,
         // so the gather below needs no bounds tests); consecutive threads take consecutive columns
         {
-            const int y0 = u0 + p.b_y0 + tdy_min, x0 = v0 + p.b_x0 + tdx_min;
+            const int y0 = u0 * p.ist + p.b_y0 + tdy_min, x0 = v0 * p.ist + p.b_x0 + tdx_min;
             // (eight loads in flight per thread: one per loop trip was a memory round trip per 256 elements)
             constexpr int SB = 8;
             for (int base = tid; base < npatch; base += 256 * SB) {
@@ -2627,7 +2627,7 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
                     unsigned raw[NCOL];
                     const bool pix_ok = (n < p.N) && (ud < p.AH) && (vd < p.AW);
                     const unsigned okm = pix_ok ? colv : 0u;
-                    const int pixl = img * p.creal * npl + tyy * PWw + txx;
+                    const int pixl = img * p.creal * npl + tyy * p.ist * PWw + txx * p.ist;
 #pragma unroll
                     for (int k = 0; k < NCOL; ++k) raw[k] = pb[pixl + cd[k].x];
                     unsigned char* row = bt + (size_t)q * PITCH + wv * 4;
@@ -2694,7 +2694,7 @@ __global__ void wgrad_im2col_finalize_kernel(const WgParams p, int Md, int Cd) {
         const int md = (int)(j / Cd);
         const int row = p.swap_out ? cd : md, col4 = p.swap_out ? md : cd;
         float s = 0.f;
-        for (int sp = 0; sp < p.nsplit; ++sp) s += p.ws[((size_t)sp * p.Mpad + row) * p.Cpad + t * 4 + col4];
+        for (int sp = 0; sp < p.nsplit; ++sp) s += p.ws[((size_t)sp * p.Mpad + row) * p.Cpad + (t << p.cqs) + col4];
         const long long o = md * p.sm + cd * p.sc + p.tap_r[t] * p.sr + p.tap_s[t] * p.ss;
         if (p.accumulate) p.dw[o] += s; else p.dw[o] = s;
     }
@@ -4171,11 +4171,14 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     using Cfg = WgCfg<T>;
     WgParams p; memset(&p, 0, sizeof(p));
     const bool swap = g.K <= 4 && g.C > 4;          // dY is the small operand
+    const int small = swap ? g.K : g.C;
+    const int cqs = small <= 4 ? 2 : 4;             // 4 or 16 channel slots per tap
     int nt = 0;
     for (int r = 0; r < g.R; ++r) for (int s = 0; s < g.S; ++s) {
         p.tap_dy[nt] = (short)(r - g.pt); p.tap_dx[nt] = (short)(s - g.pl); p.tap_r[nt] = (short)r; p.tap_s[nt] = (short)s; ++nt;
     }
-    p.im2col = 1; p.ntaps_real = nt; p.ntaps = 1; p.ngroups = 1; p.ist = 1; p.N = g.N;
+    p.im2col = 1; p.ntaps_real = nt; p.ntaps = 1; p.ngroups = 1; p.ist = g.stride; p.N = g.N; p.cqs = cqs;
+    if (swap && g.stride != 1) return HIFIC_ERR_UNSUPPORTED;
     p.swap_out = swap ? 1 : 0;
     const int Hp = g.H + g.pt + g.pb, Wp = g.W + g.pl + g.pr;
     if (!swap) {
@@ -4191,7 +4194,7 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
         p.b = dy; p.b_f32 = dy_f32; p.creal = g.K; p.BH = g.OH(); p.BW = g.OW(); p.bmode = PAD_ZERO;
         p.b_y0 = -g.pt; p.b_x0 = -g.pl; p.tsign = -1;
     }
-    p.C = nt * 4;                                   // virtual columns
+    p.C = nt << cqs;                                // virtual columns
     p.Mpad = cdiv(p.M, 64) * 64; p.Cpad = cdiv(p.C, 64) * 64;
     p.dbg = 0;
     {   // extent of the signed tap offsets (interior-tile test of the kernel's fast path)
@@ -4207,8 +4210,9 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     // pixel tile: 2 x 64 on wide planes (a 64-pixel bf16 row segment is a whole 128-byte line: 8x16 tiles made four
     // neighbouring tiles share every line of the big operand and thrashed L2: FETCH_SIZE 1.14 GB per launch for a
     // 126 MB tensor); 128 pixels = the whole K extent of a tile, multiple of 16 for the bf16 MFMA
-    p.TW = p.AW < 64 ? (p.AW < 16 ? p.AW : 16) : 64; p.TH = GC_NPIX / p.TW; if (p.TH > p.AH) p.TH = p.AH; p.NI = 1;
-    while ((p.NI * p.TH * p.TW) % 16 != 0) ++p.TH;
+    // (TW is 16 or 64 also on planes narrower than 16: TW = AW there needed TH rounded UP to a multiple-of-16 pixel count,
+    // which could pass the GC_NPIX rows of the LDS images - 12-wide plane: 12 x 12 = 144 pixels; the columns past AW are masked)
+    p.TW = p.AW < 64 ? 16 : 64; p.TH = GC_NPIX / p.TW; if (p.TH > p.AH) p.TH = p.AH; p.NI = 1;
     p.tiles_y = cdiv(p.AH, p.TH); p.tiles_x = cdiv(p.AW, p.TW); p.tiles_n = cdiv(p.N, p.NI);
     p.ntiles = p.tiles_n * p.tiles_y * p.tiles_x;
     if (p.Cpad / 64 > 4) return HIFIC_ERR_UNSUPPORTED;             // one workgroup covers all (<= 256) virtual columns
@@ -4223,8 +4227,9 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     p.dw = dw; p.sm = (long long)g.C * RS; p.sc = RS; p.sr = g.S; p.ss = 1; p.accumulate = accumulate;
     // + the small operand's halo patch [NI][creal][TH + span_y - 1][TW + span_x - 1]
     const size_t lds = 4096 + 2 * (size_t)GC_NPIX * Cfg::PITCH +
-                       (((size_t)p.NI * p.creal * (p.TH + p.grp[0].PH - p.grp[0].dy_min) * (p.TW + p.grp[0].PW - p.grp[0].dx_min) *
-                         sizeof(T) + 15) & ~(size_t)15);
+                       (((size_t)p.NI * p.creal * ((p.TH - 1) * p.ist + 1 + p.grp[0].PH - p.grp[0].dy_min) *
+                         ((p.TW - 1) * p.ist + 1 + p.grp[0].PW - p.grp[0].dx_min) * sizeof(T) + 15) & ~(size_t)15);
+    if (lds > 160 * 1024) return HIFIC_ERR_UNSUPPORTED;
     dim3 grid(base_blocks, 1, p.nsplit);
     void (*kfn)(const WgParams) = (std::is_same<T, float>::value || p.b_f32) ? wgrad_im2col_kernel<T, true>
                                                                               : wgrad_im2col_kernel<T, false>;
@@ -4258,11 +4263,17 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
 int gc_conv_bwd_weight(const ConvGeom& g, const void* x, const void* dy, float* dw, int accumulate,
                        int dtype, int x_f32, int dy_f32, WsAlloc& ws, hipStream_t st) {
     if (g.R * g.S > GC_MAXTAPS) return HIFIC_ERR_UNSUPPORTED;
-    if (g.stride == 1 && g.R * g.S >= 9 && g.R * g.S * 4 <= 256 && (g.C <= 4 || g.K <= 4) && (g.C > 4 || g.K > 4) &&
-        !env_int("HIFIC_NO_IM2COL", 0)) {
-        if (dtype == HIFIC_F32) return launch_wgrad_im2col_t<float>(g, x, dy, dw, accumulate, 1, 1, ws, st);
-        if (dtype == HIFIC_BF16) return launch_wgrad_im2col_t<bf16_t>(g, x, dy, dw, accumulate, x_f32, dy_f32, ws, st);
-        return HIFIC_ERR_ARG;
+    // im2col path: 7x7 layers with <= 4 channels on one side (stride 1), and (round 4) <= 16 INPUT channels with up to 16 taps at
+    // stride 1 or 2 - the Discriminator's first layer (15 -> 64, 4x4 stride 2: 240 of its 256 virtual columns are real, where the
+    // 64 x 64 tile of the generic kernel pads 15 channels to 64)
+    const bool im2col4 = g.stride == 1 && g.R * g.S >= 9 && g.R * g.S * 4 <= 256 && (g.C <= 4 || g.K <= 4) && (g.C > 4 || g.K > 4);
+    const bool im2col16 = !im2col4 && (g.stride == 1 || g.stride == 2) && g.C > 4 && g.C <= 16 && g.K > 16 && g.R * g.S >= 9 &&
+                          g.R * g.S * 16 <= 256 && env_int("HIFIC_IM2COL16", 1);
+    if ((im2col4 || im2col16) && !env_int("HIFIC_NO_IM2COL", 0)) {
+        int rc = HIFIC_ERR_ARG;
+        if (dtype == HIFIC_F32) rc = launch_wgrad_im2col_t<float>(g, x, dy, dw, accumulate, 1, 1, ws, st);
+        else if (dtype == HIFIC_BF16) rc = launch_wgrad_im2col_t<bf16_t>(g, x, dy, dw, accumulate, x_f32, dy_f32, ws, st);
+        if (rc != HIFIC_ERR_UNSUPPORTED) return rc;          // (nothing was launched: the generic kernel takes it)
     }
     WgParams p; memset(&p, 0, sizeof(p));
     p.a = dy; p.b = x; p.N = g.N; p.M = g.K; p.C = g.C; p.AH = g.OH(); p.AW = g.OW(); p.BH = g.H; p.BW = g.W;

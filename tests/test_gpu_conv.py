@@ -37,6 +37,11 @@ CONV_CASES = {
     # the 128-row software-pipelined kernel (four reduction quarters) with zero padding, and on a narrow 12x8 plane
     "SP128_zero_16":        (2, 128, 16, 16, 256, 3, 1, (1, 1, 1, 1), "zeros"),
     "SP128_12x8":           (2, 64, 12, 8, 128, 3, 1, (1, 1, 1, 1), "reflect"),
+    # weight gradient through the im2col kernel with 16 channel slots per tap (5..16 input channels; stride 1 and 2; D1 above
+    # and odd_s2 take it too): wide plane (2 x 64 pixel tiles), narrow plane, zero and reflect padding
+    "I16_3x3s1_c12":        (2, 12, 20, 28, 48, 3, 1, (1, 1, 1, 1), "reflect"),
+    "I16_4x4s2_c16_zero":   (2, 16, 40, 24, 40, 4, 2, (1, 1, 1, 1), "zeros"),
+    "I16_4x4s2_c15_wide":   (1, 15, 24, 256, 64, 4, 2, (1, 1, 1, 1), "reflect"),
 }
 # name: (N, Ci, H, W, Co, R, stride, pad, outpad)
 CONVT_CASES = {
