@@ -79,6 +79,7 @@ struct WgParams {
     int TH, TW, NI, tiles_y, tiles_x, tiles_n, ntiles, tiles_per_split, nsplit;
     int ntaps, ngroups;
     int dbg;
+    int xcd_remap;            // wgrad_s2_kernel: workgroups of one (channel block, pixel split) share an XCD
     int wstage_a, wstage_b;   // wide-load staging (stage_W) of the a / b operand: legality checked by the plan
     // small-channel (im2col) mode: virtual columns j = tap*4 + c; see wgrad_im2col_kernel
     int im2col, creal, ntaps_real, tsign, swap_out, a_bmode, a_y0, a_x0, a_h, a_w, b_y0, b_x0;

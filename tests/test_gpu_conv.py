@@ -42,6 +42,13 @@ CONV_CASES = {
     "I16_3x3s1_c12":        (2, 12, 20, 28, 48, 3, 1, (1, 1, 1, 1), "reflect"),
     "I16_4x4s2_c16_zero":   (2, 16, 40, 24, 40, 4, 2, (1, 1, 1, 1), "zeros"),
     "I16_4x4s2_c15_wide":   (1, 15, 24, 256, 64, 4, 2, (1, 1, 1, 1), "reflect"),
+    # phase-decomposed stride-2 weight gradient (wgrad_s2_kernel; E2 / E5 / D4 above take it too): partial pixel tiles
+    # (OH = 6, 10), channel tails (70, 72, 40, 100), several column tiles, reflect and zero padding, both pad layouts
+    "S2_3x3_rect_asym":     (3, 70, 12, 32, 72, 3, 2, (1, 0, 0, 1), "reflect"),
+    "S2_3x3_zero_asym":     (2, 33, 16, 96, 65, 3, 2, (1, 0, 0, 1), "zeros"),
+    "S2_3x3_sym_zero":      (2, 64, 16, 32, 64, 3, 2, (1, 1, 1, 1), "zeros"),
+    "S2_4x4_reflect":       (2, 40, 20, 64, 100, 4, 2, (1, 1, 1, 1), "reflect"),
+    "S2_4x4_zero":          (1, 130, 8, 32, 30, 4, 2, (1, 1, 1, 1), "zeros"),
 }
 # name: (N, Ci, H, W, Co, R, stride, pad, outpad)
 CONVT_CASES = {
@@ -51,6 +58,8 @@ CONVT_CASES = {
     "S2_5x5s2_8":  (3, 320, 8, 8, 320, 5, 2, 2, 1),
     "S3_3x3s1":    (2, 320, 16, 16, 220, 3, 1, 1, 0),
     "odd":         (1, 7, 5, 6, 9, 3, 2, 1, 1),
+    "S2T_rect":    (2, 70, 6, 16, 40, 3, 2, 1, 1),        # wgrad_s2_kernel, conv-transpose form (zero outside), partial tile rows
+    "S2T_wide":    (1, 20, 9, 48, 130, 3, 2, 1, 1),
 }
 DTYPES = [torch.float32, torch.bfloat16]
 TOL = {torch.float32: 2e-4, torch.bfloat16: 2e-2}
