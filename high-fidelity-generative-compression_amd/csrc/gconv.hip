@@ -2545,7 +2545,7 @@ struct S2Cfg {
 // `wset` enters the addresses only (3x3: set 1 has the single row 2 and skips d = 1).
 template <int R_, int S_, int PT, int PL, int NACC>
 __device__ __forceinline__ void s2_compute(f32x16_t (&acc)[NACC], const unsigned char* ab, const unsigned char* pb,
-                                           int wm, int wn, int l31, int lhi, int wset) {
+                                           int wm, int wn, int l31, int lhi, int wset, int k0, int k1) {
     using G = S2Cfg<R_, S_, PT, PL>;
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     constexpr int CP = G::cp();
@@ -2560,9 +2560,9 @@ __device__ __forceinline__ void s2_compute(f32x16_t (&acc)[NACC], const unsigned
 #ifndef S2_KU3
 #define S2_KU3 4
 #endif
-    constexpr int KU = R_ == 4 ? S2_KU4 : S2_KU3;    // 4x4 windows (128 accumulator registers): fragments of one slice at a time
+    constexpr int KU = R_ == 4 ? S2_KU4 : S2_KU3;    // (slices unrolled together when the whole tile is one call)
 #pragma unroll KU
-    for (int ks = 0; ks < G::TH; ++ks) {
+    for (int ks = k0; ks < k1; ++ks) {
         const bf16x8_t a = *(const bf16x8_t*)(arow + ks * 32);
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
@@ -2639,7 +2639,8 @@ void wgrad_s2_kernel(const WgParams p) {
     const int a_dst = a_m * APITCH + a_ty * 32 + a_h * 16;
     // b segments of this thread: segment e = tid + 512 i -> (channel, input row, 16-byte piece); the two LDS destinations
     // (even / odd pixel phase) are tile-independent and kept packed (16 + 16 bits), the rest is re-derived per tile
-    unsigned b_dst[NB];
+    unsigned b_dst[NB], b_rel[NB], b_okc = 0;
+    int b_r[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int e = tid + 512 * i;
@@ -2650,9 +2651,13 @@ void wgrad_s2_kernel(const WgParams p) {
         const int cb = c * CP + 8 * sg;
         const int d0 = cb + (py ? B10 : B00) + irow * PX0 + LM0, d1 = cb + (py ? B11 : B01) + irow * PX1 + LM1;
         b_dst[i] = e < NBI ? (unsigned)d0 | ((unsigned)d1 << 16) : 0u;
+        b_r[i] = r;
+        b_rel[i] = (unsigned)(c0 + c) * bplane + (unsigned)(8 * sg);
+        b_okc |= ((e < NBI && c0 + c < p.C) ? 1u : 0u) << i;
     }
     static_assert(PBYTES <= 65536, "packed LDS offsets");
-    unsigned e_dst[NE];
+    unsigned e_dst[NE], e_rel[NE], e_okc = 0;
+    int e_r[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = tid + 512 * i;
@@ -2661,6 +2666,9 @@ void wgrad_s2_kernel(const WgParams p) {
         const int irow = hy - (py ? SYMIN1 : SYMIN0);
         const int dl = c * CP + (py ? B11 : B01) + irow * PX1 + LM1 - 2, dr = c * CP + (py ? B10 : B00) + irow * PX0 + LM0 + 32;
         e_dst[i] = e < NEI ? (unsigned)(dl & 0xffff) | ((unsigned)dr << 16) : 0u;
+        e_r[i] = r;
+        e_rel[i] = (unsigned)(c0 + c) * bplane;
+        e_okc |= ((e < NEI && c0 + c < p.C) ? 1u : 0u) << i;
     }
 
     f32x16_t acc[NACC];
@@ -2677,38 +2685,48 @@ void wgrad_s2_kernel(const WgParams p) {
     u32x4_t breg[NB]; unsigned bokm = 0;
     unsigned short el[NE], er[NE]; unsigned eokm = 0;
 
-#define S2_LOAD(tile_)                                                                                              \
-    do {                                                                                                            \
+#define S2_LOAD_HEAD(tile_)                                                                                         \
         const int tx_t = (tile_) % p.tiles_x;                                                                       \
         const int ty_t = ((tile_) / p.tiles_x) % p.tiles_y;                                                         \
         const int n0 = (tile_) / (p.tiles_x * p.tiles_y);                                                           \
         const int u0 = ty_t * TH, v0 = tx_t * 16;                                                                   \
+        /* rows: iy = 2 u0 - PT + r, one reflection = abs, then min(iy, 2 (BH - 1) - iy); a row outside ends up negative */ \
+        const unsigned bbase = (unsigned)(n0 * p.C) * bplane + (unsigned)(2 * v0);                                  \
+        const int ybase = 2 * u0 - PT, ytop = 2 * (p.BH - 1);                                                       \
+        const bool refl = p.bmode == PAD_REFLECT;                                                                   \
+        bokm = 0; eokm = 0;
+#define S2_LOAD_A()                                                                                                 \
+    do {                                                                                                            \
         aok = (m0 + a_m < p.M) && (u0 + a_ty < p.AH);                                                               \
         areg = *(const u32x4_t*)(asrc + (aok ? (unsigned)(n0 * p.M) * aplane + (unsigned)(u0 * p.AW + v0) + a_rel : 0u)); \
-        const unsigned bbase = (unsigned)(n0 * p.C) * bplane + (unsigned)(2 * v0);                                  \
-        bokm = 0;                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                            \
-            const int e_ = tid + 512 * i, rc_ = e_ >> 2, c_ = rc_ / NRY;                                            \
-            int iy = 2 * u0 - PT + (rc_ - c_ * NRY);                                                                \
-            if (p.bmode == PAD_REFLECT) iy = reflect_idx(iy, p.BH);                                                 \
-            const bool ok_ = e_ < NBI && c0 + c_ < p.C && (unsigned)iy < (unsigned)p.BH;                            \
+    } while (0)
+#define S2_LOAD_B(i0_, i1_)                                                                                         \
+    do {                                                                                                            \
+        _Pragma("unroll") for (int i = (i0_); i < ((i1_) < NB ? (i1_) : NB); ++i) {                                 \
+            int iy = ybase + b_r[i];                                                                                \
+            if (refl) { iy = iy < 0 ? -iy : iy; const int m_ = ytop - iy; iy = iy < m_ ? iy : m_; }                 \
+            const bool ok_ = ((b_okc >> i) & 1u) && (unsigned)iy < (unsigned)p.BH;                                  \
             bokm |= (ok_ ? 1u : 0u) << i;                                                                           \
-            breg[i] = *(const u32x4_t*)(bsrc + (ok_ ? bbase + (unsigned)(c0 + c_) * bplane + (unsigned)(iy * p.BW + 8 * (e_ & 3)) : 0u)); \
+            breg[i] = *(const u32x4_t*)(bsrc + (ok_ ? bbase + b_rel[i] + (unsigned)(iy * p.BW) : 0u));             \
         }                                                                                                           \
-        eokm = 0;                                                                                                   \
+    } while (0)
+#define S2_LOAD_E()                                                                                                 \
+    do {                                                                                                            \
+        int xl = 2 * v0 - 1, xr = 2 * v0 + 32;                                                                      \
+        if (refl) { xl = xl < 0 ? -xl : xl; xr = xr > p.BW - 1 ? 2 * (p.BW - 1) - xr : xr; }                        \
+        const bool okl_ = (unsigned)xl < (unsigned)p.BW, okr_ = (unsigned)xr < (unsigned)p.BW;                      \
         _Pragma("unroll") for (int i = 0; i < NE; ++i) {                                                            \
-            const int e_ = tid + 512 * i, c_ = e_ / NRY;                                                            \
-            int iy = 2 * u0 - PT + (e_ - c_ * NRY);                                                                 \
-            int xl = 2 * v0 - 1, xr = 2 * v0 + 32;                                                                  \
-            if (p.bmode == PAD_REFLECT) { iy = reflect_idx(iy, p.BH); xl = reflect_idx(xl, p.BW); xr = reflect_idx(xr, p.BW); } \
-            const bool oky = e_ < NEI && c0 + c_ < p.C && (unsigned)iy < (unsigned)p.BH;                            \
-            const unsigned rb_ = (unsigned)(n0 * p.C + c0 + c_) * bplane + (unsigned)(iy * p.BW);                   \
-            if (HASL) { const bool ok_ = oky && (unsigned)xl < (unsigned)p.BW; eokm |= (ok_ ? 1u : 0u) << (2 * i);  \
+            int iy = ybase + e_r[i];                                                                                \
+            if (refl) { iy = iy < 0 ? -iy : iy; const int m_ = ytop - iy; iy = iy < m_ ? iy : m_; }                 \
+            const bool oky = ((e_okc >> i) & 1u) && (unsigned)iy < (unsigned)p.BH;                                  \
+            const unsigned rb_ = (unsigned)(n0 * p.C) * bplane + e_rel[i] + (unsigned)(iy * p.BW);                  \
+            if (HASL) { const bool ok_ = oky && okl_; eokm |= (ok_ ? 1u : 0u) << (2 * i);                           \
                         el[i] = bsrc[ok_ ? rb_ + (unsigned)xl : 0u]; }                                              \
-            if (HASR) { const bool ok_ = oky && (unsigned)xr < (unsigned)p.BW; eokm |= (ok_ ? 1u : 0u) << (2 * i + 1); \
+            if (HASR) { const bool ok_ = oky && okr_; eokm |= (ok_ ? 1u : 0u) << (2 * i + 1);                       \
                         er[i] = bsrc[ok_ ? rb_ + (unsigned)xr : 0u]; }                                              \
         }                                                                                                           \
     } while (0)
+#define S2_LOAD(tile_) do { S2_LOAD_HEAD(tile_) S2_LOAD_A(); S2_LOAD_B(0, NB); S2_LOAD_E(); } while (0)
 #define S2_STORE(ab_, pb_)                                                                                          \
     do {                                                                                                            \
         u32x4_t av = areg;                                                                                          \
@@ -2743,12 +2761,34 @@ void wgrad_s2_kernel(const WgParams p) {
             const unsigned char* pb = pbuf + cur * PBYTES;
             __syncthreads();
             S2_STORE(abuf + (cur ^ 1) * ABYTES, pbuf + (cur ^ 1) * PBYTES);
-            { const int t2 = tile + 2 < tile_hi ? tile + 2 : tile_last; S2_LOAD(t2); }
-            s2_compute<R_, S_, PT, PL, NACC>(acc, ab, pb, wm, wn, l31, lhi, wset);
+#ifndef S2_ILV
+#define S2_ILV 1
+#endif
+            const int t2 = tile + 2 < tile_hi ? tile + 2 : tile_last;
+#if S2_ILV
+            // the address arithmetic and requests of tile t+2 in three pieces between the reduction slices of tile t: the
+            // wave's VALU work runs while its MFMAs execute (all 8 waves leave the barrier together, so without this
+            // every SIMD first sits through two waves' staging code and only then starts its matrix pipe)
+            S2_LOAD_HEAD(t2)
+            s2_compute<R_, S_, PT, PL, NACC>(acc, ab, pb, wm, wn, l31, lhi, wset, 0, 1);
+            S2_LOAD_A(); S2_LOAD_B(0, 2);
+            s2_compute<R_, S_, PT, PL, NACC>(acc, ab, pb, wm, wn, l31, lhi, wset, 1, 2);
+            S2_LOAD_B(2, 4);
+            s2_compute<R_, S_, PT, PL, NACC>(acc, ab, pb, wm, wn, l31, lhi, wset, 2, 3);
+            S2_LOAD_B(4, NB); S2_LOAD_E();
+            s2_compute<R_, S_, PT, PL, NACC>(acc, ab, pb, wm, wn, l31, lhi, wset, 3, 4);
+#else
+            S2_LOAD(t2);
+            s2_compute<R_, S_, PT, PL, NACC>(acc, ab, pb, wm, wn, l31, lhi, wset, 0, 4);
+#endif
         }
     }
 #undef S2_STORE
 #undef S2_LOAD
+#undef S2_LOAD_E
+#undef S2_LOAD_B
+#undef S2_LOAD_A
+#undef S2_LOAD_HEAD
 
     const int r0 = wset ? RSET : 0, nr = wset ? R_ - RSET : RSET;
 #pragma unroll

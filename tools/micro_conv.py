@@ -14,6 +14,7 @@ E = lambda k, d: int(os.environ.get(k, d))
 N, C, K, H, R, ST = E("MN", 16), E("MC", 960), E("MK", 960), E("MH", 16), E("MR", 3), E("MS", 1)
 if ST == 1: pads = (R // 2,) * 4
 else: pads = (1, 0, 0, 1)                    # (top, left, bottom, right) of the encoder's asymmetric reflect pad
+if os.environ.get("MPAD"): pads = tuple(int(v) for v in os.environ["MPAD"].split(","))
 OH = (H + pads[0] + pads[2] - R) // ST + 1
 x = torch.randn(N, C, H, H, device=dev).bfloat16().requires_grad_(True)
 w = (torch.randn(K, C, R, R, device=dev) * 0.01).requires_grad_(True)
@@ -21,12 +22,23 @@ b = torch.zeros(K, device=dev, requires_grad=True)
 gy = torch.randn(N, K, OH, OH, device=dev).bfloat16()
 ws = lib.workspace(dev)
 def run(name, fn):
+    import ctypes
     for _ in range(3): fn()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(iters): fn()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / iters
     fl = 2.0 * N * OH * OH * K * C * R * R
-    print(f"{name}: {dt*1e6:.1f} us  ({fl/dt/1e12:.1f} TFLOP/s incl. pack)", flush=True)
+    extra = ""
+    if os.environ.get("MPROF") == "1":           # the in-library profiler: the GEMM kernel alone (HIP events around its launch)
+        lib.call("hific_prof_begin")
+        for _ in range(iters): fn()
+        ms = (ctypes.c_double * 32)(); flp = (ctypes.c_double * 32)(); cnt = (ctypes.c_int * 32)()
+        names = ctypes.create_string_buffer(32 * 64)
+        nk = lib.raw("hific_prof_end")(32, ms, flp, cnt, names)
+        for k in range(max(nk, 0)):
+            if cnt[k]:
+                extra += f"  [{names.raw[k * 64:(k + 1) * 64].split(bytes(1), 1)[0].decode()} {ms[k] * 1e3 / cnt[k]:.1f} us]"
+    print(f"{name}: {dt*1e6:.1f} us  ({fl/dt/1e12:.1f} TFLOP/s incl. pack){extra}", flush=True)
 geom = (N, C, H, H, K, R, R, ST, pads[0], pads[1], pads[2], pads[3], lib.PAD_REFLECT)
 y = torch.empty(N, K, OH, OH, device=dev, dtype=torch.bfloat16)
 dx = torch.empty_like(x)
