@@ -251,22 +251,33 @@ def profile_kernels(step, nsteps):
 
 
 # ---- HBM traffic of one kernel function: rocprofv3 --pmc child runs ---------------------------------------------
-def _rocpd_counter(dbdir, counter, kernel_substr):
-    """-> (average counter value per launch of the kernels matching `kernel_substr`, sum over ALL launches)."""
+def _rocpd_counter(dbdir, counter, kernel_substr, grid=None):
+    """-> (average counter value per launch of the kernels matching `kernel_substr` (compared without spaces; `grid` = total
+    work-items of the launch, when given), sum over ALL launches)."""
     import sqlite3
     tot, n, everything = 0.0, 0, 0.0
+    want = kernel_substr.replace(" ", "")
     for db in glob.glob(os.path.join(dbdir, "**", "*.db"), recursive=True):
         cur = sqlite3.connect(db).cursor()
         try:
-            rows = cur.execute("select kernel_name, count(*), sum(value) from counters_collection "
-                               "where counter_name=? group by kernel_name", (counter,)).fetchall()
+            rows = cur.execute("select kernel_name, grid_size, count(*), sum(value) from counters_collection "
+                               "where counter_name=? group by kernel_name, grid_size", (counter,)).fetchall()
         except Exception:
             continue
-        for name, c, v in rows:
+        for name, g, c, v in rows:
             everything += v
-            if kernel_substr in name:
+            if want in name.replace(" ", "") and (grid is None or g == grid):
                 tot += v; n += c
     return ((tot / n) if n else None), everything
+
+
+def _trace_filter(kind):
+    """In-library profiler kind -> (substring of the rocprofv3 kernel name, total work-items or None).  The residual-block trunk
+    launches of gconv_sp9_kernel<2,4> (the profiler's own class: K, C >= 512) are the 256-workgroup grids of the non-gather
+    instantiation; the 220 / 320-channel launches of the same function have 320 / 768 workgroups."""
+    if kind == "gconv_sp9_kernel<2,4>":
+        return "gconv_sp9_kernel<2,4,false", 256 * 512
+    return kind, None
 
 
 def measure_traffic(args, kernel_name):
@@ -296,7 +307,7 @@ def measure_traffic(args, kernel_name):
                 os.killpg(p.pid, 9)
                 return None, f"{counter} pass timed out"
             # exact template instance when it is unambiguous in the trace, else the function family
-            v, everything = _rocpd_counter(d, counter, kernel_name)
+            v, everything = _rocpd_counter(d, counter, *_trace_filter(kernel_name))
             if v is None:
                 v, everything = _rocpd_counter(d, counter, sub)
         finally:

@@ -3714,6 +3714,10 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
                           sp9_w4 ? 4 : phs ? 1 : p.rfx ? (bm == 128 ? 2 : 1)
                                 : ((env_int("HIFIC_SP9_KSPLIT", 2) == 2 && (bm == 128 || env_int("HIFIC_SP9_KSPLIT64", 0))) ? 2 : 1),
                           phs ? (phs == 1 ? ",phs1" : ",phs2") : (p.rfx ? ",rfx" : ""));
+    // the profiler keeps the residual-block trunk (>= 512 x 512 channels, one workgroup per CU) apart from the 220 / 320-channel
+    // launches of the same instantiation (K-split grids, a third of the rows): roofline.frac of the trunk is a property of the
+    // kernel, the average over both classes was a property of the layer mix
+    if (use_sp9) { if (!(p.K >= 512 && p.C >= 512) && strlen(kname) + 8 < sizeof(kname)) strcat(kname, " narrow"); }
     else if (mp) snprintf(kname, sizeof(kname), "gconv_mp_kernel%s", p.split ? "<split>" : "");
     else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
                   bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
