@@ -38,7 +38,7 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
 // bf16 forms with 8 elements per thread (16-byte loads / stores; same per-element arithmetic, so the same bits): the
 // residual adds and ReLU backward passes over the 7.8 MB residual-block tensors were ~10 us launches of two-byte accesses
 typedef unsigned int ew_u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned ew_pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned ew_pack2(float lo, float hi) { return f2bf2(lo, hi); }
 __global__ void add_bf16x8_kernel(const ew_u32x4_t* __restrict__ a, const ew_u32x4_t* __restrict__ b,
                                   ew_u32x4_t* __restrict__ o, long long n8) {
     EW_LOOP(i, n8) {

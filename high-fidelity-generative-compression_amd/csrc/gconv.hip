@@ -340,12 +340,17 @@ __device__ __forceinline__ void gc_store_block(const GcParams& p, const GcPhase&
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] += rv[r];
     }
+    // one 64-bit row base per fragment, 32-bit row strides (kr * plane < 2^32), the row bound tested once per wave when the
+    // whole 32-row block is inside
+    const size_t rowbase = pbase + (size_t)(mbase + mi * 32 + 4 * lhi) * plane;
+    const unsigned plane32 = (unsigned)plane;
+    const bool full = mbase + mi * 32 + 32 <= p.K;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int kr = (r & 3) + 8 * (r >> 2);
         const float y = v[r] > 0.f ? v[r] : v[r] * slope;
-        if (m < p.K) {
-            const size_t idx = pbase + (size_t)m * plane;
+        if (full || mbase + mi * 32 + kr + 4 * lhi < p.K) {
+            const size_t idx = rowbase + (size_t)((unsigned)kr * plane32);
             if (of32) ((float*)optr)[idx] = y; else ((bf16_t*)optr)[idx] = f2bf(y);
         }
     }
@@ -759,19 +764,23 @@ __device__ __forceinline__ void mp_store_pair(const GcParams& p, const GcPhase& 
     const bool okp = pvalid_ && pn_ < p.N && pu_ < phA.OHt && pv_ < phA.OWt && (unsigned)oy < (unsigned)p.OHf &&
                      (unsigned)(ox + 1) < (unsigned)p.OWf;
     if (!okp) return;
-    const size_t plane = (size_t)p.OHf * p.OWf;
-    const size_t pbase = (size_t)pn_ * p.K * plane + (size_t)oy * p.OWf + ox;
+    // 32-bit element offsets (the plan checks N K OH OW < 2^31); the row bound is tested once per wave when the whole 32-row
+    // block is inside (per-row branches with 64-bit index arithmetic were most of this kernel's VALU work)
+    const unsigned plane = (unsigned)(p.OHf * p.OWf);
+    const unsigned pb32 = (unsigned)(pn_ * p.K + mbase + 4 * lhi) * plane + (unsigned)(oy * p.OWf + ox);
+    const bool full = mbase + 32 <= p.K;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const float b_ = (hb && m < p.K) ? bv[r] : 0.f;
+        const int kr = (r & 3) + 8 * (r >> 2);
+        const int m = mbase + kr + 4 * lhi;
+        const float b_ = (hb && (full || m < p.K)) ? bv[r] : 0.f;
         float x0 = a[r] * osc + b_, x1 = b[r] * osc + b_;
         x0 = x0 > 0.f ? x0 : x0 * slope;
         x1 = x1 > 0.f ? x1 : x1 * slope;
-        if (m < p.K) {
-            const size_t idx = pbase + (size_t)m * plane;
+        if (full || m < p.K) {
+            const unsigned idx = pb32 + (unsigned)kr * plane;
             if constexpr (F32) *(float2*)((float*)p.out + idx) = make_float2(x0, x1);
-            else *(unsigned*)((bf16_t*)p.out + idx) = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+            else *(unsigned*)((bf16_t*)p.out + idx) = f2bf2(x0, x1);
         }
     }
 }
@@ -805,7 +814,7 @@ __device__ __forceinline__ void mp_store_pair_fold(const GcParams& p, const GcPh
         if (intA && intB) {
             const size_t idx = base_i + (size_t)m * plane_i;
             if constexpr (F32O2) *(float2*)((float*)p.out2 + idx) = make_float2(x0, x1);
-            else *(unsigned*)((bf16_t*)p.out2 + idx) = (unsigned)f2bf(x0) | ((unsigned)f2bf(x1) << 16);
+            else *(unsigned*)((bf16_t*)p.out2 + idx) = f2bf2(x0, x1);
         } else {
             if (inA) {
                 if (intA) { if constexpr (F32O2) ((float*)p.out2)[base_i + (size_t)m * plane_i] = x0;
@@ -1865,8 +1874,8 @@ __device__ __forceinline__ void pack_w2_body(const GcParams& p, const float* __r
                 *(float4*)d = make_float4(v0, v1, v2, v3);
             } else {
                 uint2 o;
-                o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                o.x = f2bf2(v0, v1);
+                o.y = f2bf2(v2, v3);
                 *(uint2*)d = o;
             }
         }
@@ -3357,7 +3366,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         // (K <= 32: a 64-row tile would be mostly padding - the 15-channel data gradient of the Discriminator's first layer ran
         //  252 -> 291 us on it)
         if (!phs && p.nphase == 4 && p.ist == 1 && p.ost == 2 && p.K > 32 && !p.rfx && !p.resid && !p.csplit && !p.msplit &&
-            !p.in_f32 && env_int("HIFIC_MP", 1)) {
+            !p.in_f32 && (long long)p.N * p.K * p.OHf * p.OWf < (1ll << 31) && env_int("HIFIC_MP", 1)) {   // (32-bit store offsets)
             mp = true;
             int nt_ = 0;
             for (int i = 0; i < 4; ++i) { if (p.ph[i].tap0 != nt_ || p.ph[i].ntaps < 1) mp = false; nt_ += p.ph[i].ntaps; }

@@ -544,10 +544,9 @@ __global__ __launch_bounds__(256) void cn_bwd_v8_kernel(const bf16_t* __restrict
             float pd = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-                const bf16_t lo = f2bf(r[j] * (gv[k][j] - S1[j]) - dv[k][j] * S2[j]);
-                const bf16_t hi = f2bf(r[j + 1] * (gv[k][j + 1] - S1[j + 1]) - dv[k][j + 1] * S2[j + 1]);
-                o[j >> 1] = (unsigned)lo | ((unsigned)hi << 16);
-                if constexpr (DB) pd += bf2f(lo) + bf2f(hi);              // what the tensor holds
+                o[j >> 1] = f2bf2(r[j] * (gv[k][j] - S1[j]) - dv[k][j] * S2[j],
+                                  r[j + 1] * (gv[k][j + 1] - S1[j + 1]) - dv[k][j + 1] * S2[j + 1]);
+                if constexpr (DB) pd += __uint_as_float(o[j >> 1] << 16) + __uint_as_float(o[j >> 1] & 0xffff0000u);   // what the tensor holds
             }
             *(u32x4_t*)(dx + img + (size_t)c * HW) = o;
             pgs[k] += pg[k]; pbs[k] += pb[k];
