@@ -245,13 +245,27 @@ __device__ __forceinline__ void stage_W(unsigned char* lds, const bf16_t* __rest
         }
 #pragma unroll
         for (int b = 0; b < WB; ++b) {
+            // every lane's group entirely inside the patch (all but the first / last group of a row and the items past the end):
+            // one base address, the eight rows at immediate offsets - 2 VALU instructions per element instead of 8 (the
+            // per-element column test + dump-row select + address multiply made this stage ~57 VALU instructions per 16-byte
+            // load, half the VALU time of the strided forward layers)
+            const bool whole = qrow[b] >= 0 && px0[b] >= 0 && px0[b] + 8 <= PW;
+            if (__builtin_amdgcn_ballot_w64(!whole) == 0) {
+                unsigned char* d = lds + (size_t)(qrow[b] + px0[b]) * PITCH + cp * 4;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned a_dw = va[b][e >> 1], b_dw = vb[b][e >> 1];
-                const unsigned v = __builtin_amdgcn_perm(b_dw, a_dw, (e & 1) ? 0x07060302u : 0x05040100u) & vm[b];
-                const int px = px0[b] + e;
-                const int q = ((unsigned)px < (unsigned)PW && qrow[b] >= 0) ? qrow[b] + px : qdump;
-                *(unsigned*)(lds + (size_t)q * PITCH + cp * 4) = v;
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned a_dw = va[b][e >> 1], b_dw = vb[b][e >> 1];
+                    *(unsigned*)(d + e * PITCH) = __builtin_amdgcn_perm(b_dw, a_dw, (e & 1) ? 0x07060302u : 0x05040100u) & vm[b];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned a_dw = va[b][e >> 1], b_dw = vb[b][e >> 1];
+                    const unsigned v = __builtin_amdgcn_perm(b_dw, a_dw, (e & 1) ? 0x07060302u : 0x05040100u) & vm[b];
+                    const int px = px0[b] + e;
+                    const int q = ((unsigned)px < (unsigned)PW && qrow[b] >= 0) ? qrow[b] + px : qdump;
+                    *(unsigned*)(lds + (size_t)q * PITCH + cp * 4) = v;
+                }
             }
         }
     }

@@ -272,3 +272,51 @@ def test_merged_phase_kernel_equals_the_per_phase_kernel(hific, dev):
     assert _relerr(outs["1"][2].float().cpu(), xr.grad.float()) < 2e-2
     yr = F.relu(F.conv_transpose2d(x.float().cpu(), w.cpu(), b.cpu(), stride=2, padding=1, output_padding=1))
     assert _relerr(outs["1"][0].float().cpu(), yr) < 2e-2
+
+
+def _kinds_of(fn):
+    """Kernel kinds (in-library profiler names) launched by fn()."""
+    import ctypes
+    from hific_amd import lib
+    lib.call("hific_prof_begin")
+    fn()
+    ms = (ctypes.c_double * 32)(); fl = (ctypes.c_double * 32)(); cnt = (ctypes.c_int * 32)()
+    names = ctypes.create_string_buffer(32 * 64)
+    nk = lib.raw("hific_prof_end")(32, ms, fl, cnt, names)
+    assert nk >= 0
+    return {names.raw[k * 64:(k + 1) * 64].split(bytes(1), 1)[0].decode() for k in range(nk) if cnt[k]}
+
+
+def test_strided_weight_gradients_take_their_kernels(hific, dev):
+    """The parity cases above would also pass on the generic kernel: pin the dispatch.  3x3 / 4x4 stride-2 layers with
+    OW % 16 == 0 -> wgrad_s2_kernel (conv and conv-transpose form); 5..16 input channels -> the 16-slot im2col kernel."""
+    from hific_amd import ops, lib
+    hific.set_compute_dtype(torch.bfloat16)
+
+    def conv_wgrad(name):
+        N, C, H, W, K, R, stride, pads, mode = CONV_CASES[name]
+        x = _rnd((N, C, H, W), 1, torch.bfloat16).to(dev).bfloat16()
+        w = (_rnd((K, C, R, R), 2, torch.bfloat16) * 0.05).to(dev).requires_grad_(True)
+        pm = lib.PAD_REFLECT if mode == "reflect" else lib.PAD_ZERO
+        y = ops.conv2d(x, w, None, stride=stride, pads=pads, pad_mode=pm)
+        gy = torch.ones_like(y)
+        torch.cuda.synchronize()
+        return _kinds_of(lambda: (y.backward(gy), torch.cuda.synchronize()))
+
+    def convt_wgrad(name):
+        N, Ci, H, W, Co, R, stride, pad, outpad = CONVT_CASES[name]
+        x = _rnd((N, Ci, H, W), 1, torch.bfloat16).to(dev).bfloat16()
+        w = (_rnd((Ci, Co, R, R), 2, torch.bfloat16) * 0.05).to(dev).requires_grad_(True)
+        y = ops.conv_transpose2d(x, w, None, stride, pad, outpad)
+        gy = torch.ones_like(y)
+        torch.cuda.synchronize()
+        return _kinds_of(lambda: (y.backward(gy), torch.cuda.synchronize()))
+
+    for name in ("E2_3x3s2_asym", "E5_3x3s2_asym_480", "D4_4x4s2_256_512", "S2_3x3_rect_asym", "S2_4x4_zero"):
+        assert "wgrad_s2_kernel" in conv_wgrad(name), name
+    for name in ("U1_960_480", "S2T_rect"):
+        assert "wgrad_s2_kernel" in convt_wgrad(name), name
+    for name in ("D1_4x4s2", "I16_3x3s1_c12", "odd_s2"):
+        assert "wgrad_im2col_kernel<bf16>" in conv_wgrad(name), name
+    assert "wgrad_s2_kernel" not in conv_wgrad("odd_s2")
+    hific.set_compute_dtype(torch.float32)
