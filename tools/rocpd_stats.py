@@ -10,7 +10,20 @@ cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                    f"from kernels group by {name_col} order by sum(end-start) desc").fetchall()
-total = sum(r[2] for r in rows) or 1
+# gconv_sp9_kernel instantiations serve the residual-block trunk (256 workgroups at the benchmark shape) and the 220 / 320-channel
+# layers (320 / 768 workgroups): also list them per grid, so that the trunk's average launch can be read off (bench.py's
+# roofline counts the trunk launches only)
+gcol = "grid_size" if "grid_size" in cols else None
+wcol = "workgroup_size" if "workgroup_size" in cols else None
+if gcol and wcol:
+    try:
+        extra = cur.execute(f"select {name_col} || ' [' || ({gcol} / {wcol}) || ' workgroups]', count(*), sum(end-start), "
+                            f"avg(end-start), min(end-start), max(end-start) from kernels where {name_col} like '%gconv_sp9_kernel%' "
+                            f"group by {name_col}, {gcol} order by sum(end-start) desc").fetchall()
+        rows = rows + extra
+    except Exception as e:                      # older schema: the per-name table stands alone
+        print("per-grid rows unavailable:", e, file=sys.stderr)
+total = sum(r[2] for r in rows if ' workgroups]' not in r[0]) or 1
 lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
 for n, c, s, a, mn, mx in rows:
     short = n if len(n) < 110 else n[:107] + "..."
