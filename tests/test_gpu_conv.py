@@ -49,6 +49,10 @@ CONV_CASES = {
     "S2_3x3_sym_zero":      (2, 64, 16, 32, 64, 3, 2, (1, 1, 1, 1), "zeros"),
     "S2_4x4_reflect":       (2, 40, 20, 64, 100, 4, 2, (1, 1, 1, 1), "reflect"),
     "S2_4x4_zero":          (1, 130, 8, 32, 30, 4, 2, (1, 1, 1, 1), "zeros"),
+    # natural-order stride-1 weight gradient (wgrad_s1_kernel; R_3x3_960 / E6 / A1 / SP128_zero_16 above take it too): several
+    # column tiles, a partial tile row (H = 12, 20), channel tails, reflect and zero padding
+    "S1_rect_reflect":      (2, 70, 12, 32, 100, 3, 1, (1, 1, 1, 1), "reflect"),
+    "S1_wide_zero":         (1, 130, 20, 48, 40, 3, 1, (1, 1, 1, 1), "zeros"),
 }
 # name: (N, Ci, H, W, Co, R, stride, pad, outpad)
 CONVT_CASES = {
@@ -316,6 +320,8 @@ def test_strided_weight_gradients_take_their_kernels(hific, dev):
         assert "wgrad_s2_kernel" in conv_wgrad(name), name
     for name in ("U1_960_480", "S2T_rect"):
         assert "wgrad_s2_kernel" in convt_wgrad(name), name
+    for name in ("R_3x3_960", "E6_960_220", "A1_zero", "S1_rect_reflect", "S1_wide_zero"):
+        assert "wgrad_s1_kernel" in conv_wgrad(name), name
     for name in ("D1_4x4s2", "I16_3x3s1_c12", "odd_s2"):
         assert "wgrad_im2col_kernel<bf16>" in conv_wgrad(name), name
     assert "wgrad_s2_kernel" not in conv_wgrad("odd_s2")
