@@ -13,8 +13,14 @@ rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start)
 # gconv_sp9_kernel instantiations serve the residual-block trunk (256 workgroups at the benchmark shape) and the 220 / 320-channel
 # layers (320 / 768 workgroups): also list them per grid, so that the trunk's average launch can be read off (bench.py's
 # roofline counts the trunk launches only)
-gcol = "grid_size" if "grid_size" in cols else None
-wcol = "workgroup_size" if "workgroup_size" in cols else None
+def _size_expr(kind):
+    """SQL expression for the launch's total work-items (kind 'grid') / work-items per workgroup (kind 'workgroup')."""
+    if f"{kind}_size" in cols:
+        return f"{kind}_size"
+    xyz = [c for c in (f"{kind}_size_x", f"{kind}_size_y", f"{kind}_size_z") if c in cols] or \
+          [c for c in (f"{kind}_x", f"{kind}_y", f"{kind}_z") if c in cols]
+    return "(" + " * ".join(xyz) + ")" if len(xyz) == 3 else None
+gcol, wcol = _size_expr("grid"), _size_expr("workgroup")
 if gcol and wcol:
     try:
         extra = cur.execute(f"select {name_col} || ' [' || ({gcol} / {wcol}) || ' workgroups]', count(*), sum(end-start), "
@@ -23,6 +29,8 @@ if gcol and wcol:
         rows = rows + extra
     except Exception as e:                      # older schema: the per-name table stands alone
         print("per-grid rows unavailable:", e, file=sys.stderr)
+else:
+    print("per-grid rows unavailable; columns of `kernels`:", cols, file=sys.stderr)
 total = sum(r[2] for r in rows if ' workgroups]' not in r[0]) or 1
 lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
 for n, c, s, a, mn, mx in rows:
