@@ -5075,6 +5075,22 @@ int gc_conv_bwd_weight(const ConvGeom& g, const void* x, const void* dy, float* 
     const bool im2col4 = g.stride == 1 && g.R * g.S >= 9 && g.R * g.S * 4 <= 256 && (g.C <= 4 || g.K <= 4) && (g.C > 4 || g.K > 4);
     const bool im2col16 = !im2col4 && (g.stride == 1 || g.stride == 2) && g.C > 4 && g.C <= 16 && g.K > 16 && g.R * g.S >= 9 &&
                           g.R * g.S * 16 <= 256 && env_int("HIFIC_IM2COL16", 1);
+    if (im2col16 && g.stride == 2 && dtype == HIFIC_BF16 && env_int("HIFIC_S2_FEWC", 1)) {
+        // a stride-2 3x3 / 4x4 layer on a 16-pixel-multiple plane: the phase-decomposed kernel, although 15 of its 64 channel
+        // columns are real - the layer is bound by its operand bytes, not by MFMA slots (Discriminator conv1: 199 us on the
+        // im2col kernel, whose halo-patch staging is six dependent batches of two-byte loads per tile)
+        WgParams q; memset(&q, 0, sizeof(q));
+        q.a = dy; q.b = x; q.N = g.N; q.M = g.K; q.C = g.C; q.AH = g.OH(); q.AW = g.OW(); q.BH = g.H; q.BW = g.W;
+        q.ist = g.stride; q.bmode = g.pad_mode; q.a_f32 = dy_f32; q.b_f32 = x_f32;
+        int nq = 0;
+        for (int r = 0; r < g.R; ++r) for (int s = 0; s < g.S; ++s) {
+            q.tap_dy[nq] = (short)(r - g.pt); q.tap_dx[nq] = (short)(s - g.pl); q.tap_r[nq] = (short)r; q.tap_s[nq] = (short)s; ++nq;
+        }
+        q.ntaps = nq;
+        const long long RSq = (long long)g.R * g.S;
+        const int rc = launch_wgrad_s2(q, dw, (long long)g.C * RSq, RSq, g.S, 1, accumulate, ws, st);
+        if (rc != HIFIC_ERR_UNSUPPORTED) return rc;
+    }
     if ((im2col4 || im2col16) && !env_int("HIFIC_NO_IM2COL", 0)) {
         int rc = HIFIC_ERR_ARG;
         if (dtype == HIFIC_F32) rc = launch_wgrad_im2col_t<float>(g, x, dy, dw, accumulate, 1, 1, ws, st);

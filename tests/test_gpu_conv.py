@@ -316,13 +316,14 @@ def test_strided_weight_gradients_take_their_kernels(hific, dev):
         torch.cuda.synchronize()
         return _kinds_of(lambda: (y.backward(gy), torch.cuda.synchronize()))
 
-    for name in ("E2_3x3s2_asym", "E5_3x3s2_asym_480", "D4_4x4s2_256_512", "S2_3x3_rect_asym", "S2_4x4_zero"):
+    for name in ("E2_3x3s2_asym", "E5_3x3s2_asym_480", "D4_4x4s2_256_512", "S2_3x3_rect_asym", "S2_4x4_zero", "D1_4x4s2",
+                 "I16_4x4s2_c15_wide"):
         assert "wgrad_s2_kernel" in conv_wgrad(name), name
     for name in ("U1_960_480", "S2T_rect"):
         assert "wgrad_s2_kernel" in convt_wgrad(name), name
     for name in ("R_3x3_960", "E6_960_220", "A1_zero", "S1_rect_reflect", "S1_wide_zero"):
         assert "wgrad_s1_kernel" in conv_wgrad(name), name
-    for name in ("D1_4x4s2", "I16_3x3s1_c12", "odd_s2"):
+    for name in ("I16_3x3s1_c12", "I16_4x4s2_c16_zero", "odd_s2"):
         assert "wgrad_im2col_kernel<bf16>" in conv_wgrad(name), name
     assert "wgrad_s2_kernel" not in conv_wgrad("odd_s2")
     hific.set_compute_dtype(torch.float32)
