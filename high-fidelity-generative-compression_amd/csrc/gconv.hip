@@ -4714,6 +4714,7 @@ static int launch_wgrad_s1(WgParams& p, float* dw, long long sm, long long sc, l
                            WsAlloc& ws, hipStream_t st) {
     if (p.ist != 1 || p.a_f32 || p.b_f32 || p.ntaps != 9 || !env_int("HIFIC_WGRAD_S1", 1)) return HIFIC_ERR_UNSUPPORTED;
     if (p.AW % 16 != 0 || p.BW != p.AW || p.BH != p.AH || p.BH < 2 || (((size_t)p.a | (size_t)p.b) & 15) != 0) return HIFIC_ERR_UNSUPPORTED;
+    if ((long long)p.N * p.M * p.AH * p.AW >= (1ll << 32) || (long long)p.N * p.C * p.BH * p.BW >= (1ll << 32)) return HIFIC_ERR_UNSUPPORTED;
     for (int t = 0; t < 9; ++t)
         if (p.tap_r[t] != t / 3 || p.tap_s[t] != t % 3 || p.tap_dy[t] != t / 3 - 1 || p.tap_dx[t] != t % 3 - 1) return HIFIC_ERR_UNSUPPORTED;
     p.Mpad = cdiv(p.M, 64) * 64; p.Cpad = cdiv(p.C, 64) * 64;
@@ -4754,6 +4755,8 @@ static int launch_wgrad_s2(WgParams& p, float* dw, long long sm, long long sc, l
                            WsAlloc& ws, hipStream_t st) {
     if (p.ist != 2 || p.a_f32 || p.b_f32 || !env_int("HIFIC_WGRAD_S2", 1)) return HIFIC_ERR_UNSUPPORTED;
     if (p.AW % 16 != 0 || p.BW < 2 * p.AW || p.BW % 8 != 0 || (((size_t)p.a | (size_t)p.b) & 15) != 0) return HIFIC_ERR_UNSUPPORTED;
+    // (the kernel addresses both operands with 32-bit element offsets)
+    if ((long long)p.N * p.M * p.AH * p.AW >= (1ll << 32) || (long long)p.N * p.C * p.BH * p.BW >= (1ll << 32)) return HIFIC_ERR_UNSUPPORTED;
     int R = 0, S = 0;
     for (int t = 0; t < p.ntaps; ++t) { if (p.tap_r[t] + 1 > R) R = p.tap_r[t] + 1; if (p.tap_s[t] + 1 > S) S = p.tap_s[t] + 1; }
     if (R * S != p.ntaps) return HIFIC_ERR_UNSUPPORTED;
