@@ -58,6 +58,9 @@ struct GcParams {
                          // a step issues hi*hi + hi*lo + lo*hi
     int afrag;           // packed weights in MFMA A-fragment order (gc_wp_index): gconv_sp9_kernel AG streams them
                          // global -> registers, bypassing LDS
+                         // (2: the 8 KB per (row tile, 32-channel chunk, tap) blocks of gconv_pl_kernel)
+    int pl_tpw;          // gconv_pl_kernel: pixel tiles per workgroup (persistent loop)
+    int pl_wshare;       // gconv_pl_kernel: workgroups of one XCD share a row tile (big weights) instead of their pixel tiles
     // reflect-padded data gradient: `out` is the f32 padded plane buffer (only its rim is written); pixels inside
     // [fold_pt, fold_pt+fold_h) x [fold_pl, fold_pl+fold_w) go straight to out2 = dx[N,K,fold_h,fold_w]
     void* out2;

@@ -9,6 +9,7 @@
 // Weight-gradient kernel: D[64 m][64 c] per tap += A^T[pixels][m] * Xpatch^T[pixels + tap][c], reduction over
 // pixels; both operands use the same transposed LDS image, bf16 fragments come from ds_read_b64_tr_b16.
 #include "gconv.h"
+#include "gconv_dev.h"
 #include <type_traits>
 #include <string.h>
 #include <stdio.h>
@@ -31,7 +32,7 @@
 // leaves the per-launch host path once a function has reached its maximum.
 #include <mutex>
 #include <unordered_map>
-static void gc_set_max_lds(const void* fn, int bytes) {
+void gc_set_max_lds(const void* fn, int bytes) {
     // the attribute belongs to the CURRENT device's function object: one record per (device, function)
     static std::mutex mu;
     static std::unordered_map<unsigned long long, int> cur;
@@ -302,73 +303,6 @@ __device__ __forceinline__ void stage_W(unsigned char* lds, const bf16_t* __rest
 // wave-uniform) branch makes hipcc wait `vmcnt(0)` right behind it, and the per-element `if (p.bias) v += p.bias[m]`
 // this replaces was 16*WM*WN serialised L2 round trips at the end of every workgroup (~10 us on a 90 us launch).
 // ---------------------------------------------------------------------------------------------------
-// One (32-row block mi, pixel fragment ni) of the tile; the accumulator vector arrives BY VALUE and every index is a
-// compile-time constant (references to the accumulator array / runtime fragment indices made hipcc keep the whole
-// accumulator array in scratch on some instantiations).
-template <bool TF32>
-__device__ __forceinline__ void gc_store_block(const GcParams& p, const GcPhase& ph, const f32x16_t a, int mi, int mbase,
-                                               int lhi, int pu_, int pv_, int pn_, bool pvalid_, bool hb, const float* bp,
-                                               float slope) {
-    const bool out_f32 = TF32 || p.out_f32;
-    float bv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        bv[r] = bp[(hb && m < p.K) ? m : 0];
-    }
-    const float osc = p.oscale ? *p.oscale : 1.f;
-    const int oy = pu_ * p.ost + ph.ooy, ox = pv_ * p.ost + ph.oox;
-    const bool okp = pvalid_ && pn_ < p.N && pu_ < ph.OHt && pv_ < ph.OWt &&
-                     (unsigned)oy < (unsigned)p.OHf && (unsigned)ox < (unsigned)p.OWf;
-    if (!okp) return;
-    size_t plane = (size_t)p.OHf * p.OWf;
-    size_t pbase = (size_t)pn_ * p.K * plane + (size_t)oy * p.OWf + ox;
-    // split-K partial sums (GcParams::ksplit): the same store path with the destination redirected to this split's float32
-    // plane set; the caller passes no bias and slope 1.  (A separate store loop here spilled the accumulators of the
-    // 128-row sp9 instantiations to scratch: 320 B/lane, 12x slower.)
-    const bool part = p.ksplit > 1;
-    void* optr = part ? (void*)(p.kpart + (size_t)blockIdx.y * (size_t)p.kpart_stride) : p.out;
-    bool of32 = out_f32 || part;
-    if (p.fold_h) {      // reflect-pad data gradient: interior pixels straight to dx, only the rim to the plane buffer
-        const int iy = oy - p.fold_pt, ix = ox - p.fold_pl;
-        if ((unsigned)iy < (unsigned)p.fold_h && (unsigned)ix < (unsigned)p.fold_w) {
-            plane = (size_t)p.fold_h * p.fold_w;
-            pbase = (size_t)pn_ * p.K * plane + (size_t)iy * p.fold_w + ix;
-            optr = p.out2; of32 = TF32 || p.out2_f32;
-        }
-    }
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        v[r] = a[r] * osc + ((hb && m < p.K) ? bv[r] : 0.f);
-    }
-    if (p.resid) {          // rare path (no caller on the HiFIC graph fuses a residual): loads batched per fragment
-        float rv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            const size_t idx = pbase + (size_t)(m < p.K ? m : 0) * plane;
-            rv[r] = out_f32 ? ((const float*)p.resid)[idx] : bf2f(((const bf16_t*)p.resid)[idx]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += rv[r];
-    }
-    // one 64-bit row base per fragment, 32-bit row strides (kr * plane < 2^32), the row bound tested once per wave when the
-    // whole 32-row block is inside
-    const size_t rowbase = pbase + (size_t)(mbase + mi * 32 + 4 * lhi) * plane;
-    const unsigned plane32 = (unsigned)plane;
-    const bool full = mbase + mi * 32 + 32 <= p.K;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int kr = (r & 3) + 8 * (r >> 2);
-        const float y = v[r] > 0.f ? v[r] : v[r] * slope;
-        if (full || mbase + mi * 32 + kr + 4 * lhi < p.K) {
-            const size_t idx = rowbase + (size_t)((unsigned)kr * plane32);
-            if (of32) ((float*)optr)[idx] = y; else ((bf16_t*)optr)[idx] = f2bf(y);
-        }
-    }
-}
 // NI_ONLY >= 0: this wave writes only that pixel fragment (K-split kernels); -1: all.
 template <bool TF32, int WM, int WN, int NI_ONLY>
 __device__ __forceinline__ void gc_epilogue(const GcParams& p, const GcPhase& ph, const f32x16_t a00, const f32x16_t a01,
@@ -1756,26 +1690,6 @@ void gconv_sp9_kernel(const GcParams p) {
 // ---------------------------------------------------------------------------------------------------
 // Weight packing: wp[phase][m][t][c] = w[m*sm + c*sc + r_t*sr + s_t*ss] * scale   (zero padded)
 // ---------------------------------------------------------------------------------------------------
-// Source index of packed element (row m, reduction channel c, tap (r, s)).  With virtual channels (csplit) the packed
-// channel cc = c * csplit + j stands for channel c at kernel column vcol_s[j]; with virtual rows (msplit) the packed row
-// mm = k * msplit + j stands for output channel k at kernel column vcol_s[j] (the tap then only carries the kernel row).
-__host__ __device__ __forceinline__ long long gc_weight_index(const GcParams& p, int m, int c, int r, int s, long long sm,
-                                                              long long sc, long long sr, long long ss) {
-    if (p.csplit) { s = p.vcol_s[c % p.csplit]; c = c / p.csplit; }
-    if (p.msplit) { s = p.vcol_s[m % p.msplit]; m = m / p.msplit; }
-    return m * sm + c * sc + r * sr + s * ss;
-}
-// Destination element index of packed weight (row m, tap t of phase ph, reduction channel c).  Default: [m][t][c].
-// afrag (gconv_sp9_kernel AG): MFMA A-fragment order - for every (32-row block, tap, 64-channel chunk, 16-deep slice) the
-// 64 lanes' 16-byte operands are contiguous (lane = (c / 8 % 2) * 32 + m % 32 holds channels c..c+7 of row m), so one
-// wave-wide 16-byte-per-lane load brings a whole v_mfma_f32_32x32x16_bf16 A operand as 1 KB of consecutive bytes.
-__host__ __device__ __forceinline__ long long gc_wp_index(const GcParams& p, const GcPhase& ph, int m, int t, int c) {
-    if (!p.afrag) return ((long long)m * ph.ntaps + t) * p.Cpad + c;
-    const int nch = p.Cpad >> 6;
-    const long long blk = (((long long)(m >> 5) * ph.ntaps + t) * nch + (c >> 6)) * 4 + ((c >> 4) & 3);   // 1 KB operand
-    const int lane = ((c >> 3) & 1) * 32 + (m & 31);
-    return (blk * 64 + lane) * 8 + (c & 7);
-}
 template <typename T>
 __global__ void pack_w_kernel(const GcParams p, const float* __restrict__ w, const float* scale,
                               long long sm, long long sc, long long sr, long long ss) {
@@ -3573,6 +3487,8 @@ static int prof_open(const char* kname, double flops, hipStream_t st, const char
     return i;
 }
 static void prof_close(int i, hipStream_t st) { if (i >= 0) hipEventRecord(g_prof_ev[i][1], st); }
+int gc_prof_open(const char* kname, double flops, hipStream_t st, const char* tag) { return prof_open(kname, flops, st, tag); }
+void gc_prof_close(int slot, hipStream_t st) { prof_close(slot, st); }
 
 extern "C" int hific_prof_begin(void) { g_prof_on = true; g_prof_n = 0; g_prof_nk = 0; return HIFIC_OK; }
 // Synchronises the recorded events.  Fills, for up to max_kinds kernel functions: total ms, total algorithmic FLOPs,
@@ -3632,7 +3548,26 @@ __global__ void ksplit_reduce_kernel(const float* __restrict__ part, long long s
     }
 }
 
-static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s ? atoi(s) : dflt; }
+// Environment knobs are read ONCE per process and call site (the planner asks for dozens per launch: getenv walks the
+// whole environment block each time).  Key = the address of the name literal.  hific_env_refresh() drops the cache (tests and
+// tools that flip a knob inside one process).
+static std::mutex g_env_mu;
+static std::unordered_map<const void*, int> g_env_cache;
+int gc_env_int(const char* name, int dflt) {
+    std::lock_guard<std::mutex> lock(g_env_mu);
+    auto it = g_env_cache.find((const void*)name);
+    if (it != g_env_cache.end()) return it->second;
+    const char* s = getenv(name);
+    const int v = s ? atoi(s) : dflt;
+    g_env_cache.emplace((const void*)name, v);
+    return v;
+}
+extern "C" int hific_env_refresh(void) {
+    std::lock_guard<std::mutex> lock(g_env_mu);
+    g_env_cache.clear();
+    return HIFIC_OK;
+}
+static inline int env_int(const char* name, int dflt) { return gc_env_int(name, dflt); }
 
 static const int kLdsBudget = 150 * 1024;
 
@@ -3686,6 +3621,74 @@ static void finish_phase(GcPhase& ph, const GcParams& p) {
     }
     ph.dy_min = dymin; ph.dx_min = dxmin;
     ph.PH = dymax - dymin + 1; ph.PW = dxmax - dxmin + 1;   // spans; converted to patch extents later
+}
+
+// Weight packing for plan `p` (destination layout = gc_wp_index): pack tiling choice, plan-only hand-over of the job
+// (hific_*_pack_plan), destination in the caller's cache or the workspace, and the pack launch unless the cache is current.
+template <typename T>
+static int gc_pack_weights(GcParams& p, long long wp_elems, const float* w, const float* w_scale, long long sm, long long sc,
+                           long long sr, long long ss, WsAlloc& ws, hipStream_t st, bool* plan_only) {
+    *plan_only = false;
+    const size_t wp_bytes = (size_t)(wp_elems > 0 ? wp_elems : 1) * sizeof(T);
+    // pack tiling (coalesced LDS-transposing kernel when the taps of a (m,c) pair are contiguous and one of m/c is adjacent)
+    PackJob job; memset(&job, 0, sizeof(job));
+    {
+        int RS = 0;
+        for (int i = 0; i < p.nphase; ++i) RS += p.ph[i].ntaps;       // phases partition the R*S taps
+        const bool contiguous = (sr == p.tap_sw && ss == 1 && RS > 0);
+        job.sm = sm; job.sc = sc; job.sr = sr; job.ss = ss; job.RS = RS; job.MB = 1; job.dtype = DT<T>::code;
+        job.wp_bytes = (long long)wp_bytes;
+        if (contiguous && sc == RS && !p.csplit && !p.msplit && !env_int("HIFIC_OLD_PACK", 0)) {
+            int MB = 40960 / (64 * RS * 4); if (MB > 16) MB = 16; if (MB < 1) MB = 1;
+            job.mode = 0; job.MB = MB; job.gx = p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0); job.gy = cdiv(p.Kpad, MB);
+            job.lds_bytes = (int)((size_t)64 * ((MB * RS) | 1) * sizeof(float));
+        } else if (contiguous && sm == RS && !p.csplit && !p.msplit && !env_int("HIFIC_OLD_PACK", 0)) {
+            int MB = env_int("HIFIC_PACK_MB", 144) / RS; if (MB > 32) MB = 32; if (MB < 1) MB = 1;
+            job.mode = 1; job.MB = MB; job.gx = p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0); job.gy = cdiv(p.Kpad, MB);
+            job.lds_bytes = (int)((size_t)64 * ((MB * RS) | 1) * sizeof(float));
+        } else {
+            long long mx = 0;
+            for (int i = 0; i < p.nphase; ++i) {
+                long long e = (long long)p.Kpad * p.ph[i].ntaps * p.Cpad;
+                if (e > mx) mx = e;
+            }
+            int gx = (int)((mx + 255) / 256); if (gx > 4096) gx = 4096; if (gx < 1) gx = 1;
+            job.mode = 2; job.gx = gx; job.gy = p.nphase; job.lds_bytes = 0;
+        }
+    }
+    if (ws.plan_out) {          // plan-only call (hific_conv_pack_plan): hand the job to the caller, launch nothing
+        job.p = p; job.p.wp = nullptr;
+        *ws.plan_out = job;
+        *plan_only = true;
+        return HIFIC_OK;
+    }
+    void* wp;
+    if (ws.wcache_state != 0) {
+        if (!ws.wcache || ws.wcache_bytes < wp_bytes) return HIFIC_ERR_WS;
+        wp = ws.wcache;
+    } else {
+        wp = ws.take(wp_bytes);
+        if (!wp) return HIFIC_ERR_WS;
+    }
+    p.wp = wp;
+    if (ws.wcache_state != 2) {
+        if (job.mode == 0) {
+            if (job.lds_bytes > 48 * 1024)
+                gc_set_max_lds((const void*)pack_w2_kernel<T, 0>, job.lds_bytes);
+            hipLaunchKernelGGL((pack_w2_kernel<T, 0>), dim3(job.gx, job.gy), dim3(256), job.lds_bytes, st, p, w, w_scale, sm, sc, job.RS, job.MB);
+        } else if (job.mode == 1) {
+            if (job.lds_bytes > 48 * 1024)
+                gc_set_max_lds((const void*)pack_w2_kernel<T, 1>, job.lds_bytes);
+            hipLaunchKernelGGL((pack_w2_kernel<T, 1>), dim3(job.gx, job.gy), dim3(256), job.lds_bytes, st, p, w, w_scale, sm, sc, job.RS, job.MB);
+        } else {
+            hipLaunchKernelGGL(pack_w_kernel<T>, dim3(job.gx, p.nphase), dim3(256), 0, st, p, w, w_scale, sm, sc, sr, ss);
+        }
+    }
+    return HIFIC_OK;
+}
+int gc_pack_weights_bf16(GcParams& p, long long wp_elems, const float* w, const float* w_scale, long long sm, long long sc,
+                         long long sr, long long ss, WsAlloc& ws, hipStream_t st, bool* plan_only) {
+    return gc_pack_weights<bf16_t>(p, wp_elems, w, w_scale, sm, sc, sr, ss, ws, st, plan_only);
 }
 
 template <typename T, int BC>
@@ -4007,59 +4010,10 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             }
         }
     }
-    const size_t wp_bytes = (size_t)(wp_elems > 0 ? wp_elems : 1) * sizeof(T);
-    // pack tiling (coalesced LDS-transposing kernel when the taps of a (m,c) pair are contiguous and one of m/c is adjacent)
-    PackJob job; memset(&job, 0, sizeof(job));
     {
-        int RS = 0;
-        for (int i = 0; i < p.nphase; ++i) RS += p.ph[i].ntaps;       // phases partition the R*S taps
-        const bool contiguous = (sr == p.tap_sw && ss == 1 && RS > 0);
-        job.sm = sm; job.sc = sc; job.sr = sr; job.ss = ss; job.RS = RS; job.MB = 1; job.dtype = DT<T>::code;
-        job.wp_bytes = (long long)wp_bytes;
-        if (contiguous && sc == RS && !p.csplit && !p.msplit && !env_int("HIFIC_OLD_PACK", 0)) {
-            int MB = 40960 / (64 * RS * 4); if (MB > 16) MB = 16; if (MB < 1) MB = 1;
-            job.mode = 0; job.MB = MB; job.gx = p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0); job.gy = cdiv(p.Kpad, MB);
-            job.lds_bytes = (int)((size_t)64 * ((MB * RS) | 1) * sizeof(float));
-        } else if (contiguous && sm == RS && !p.csplit && !p.msplit && !env_int("HIFIC_OLD_PACK", 0)) {
-            int MB = env_int("HIFIC_PACK_MB", 144) / RS; if (MB > 32) MB = 32; if (MB < 1) MB = 1;
-            job.mode = 1; job.MB = MB; job.gx = p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0); job.gy = cdiv(p.Kpad, MB);
-            job.lds_bytes = (int)((size_t)64 * ((MB * RS) | 1) * sizeof(float));
-        } else {
-            long long mx = 0;
-            for (int i = 0; i < p.nphase; ++i) {
-                long long e = (long long)p.Kpad * p.ph[i].ntaps * p.Cpad;
-                if (e > mx) mx = e;
-            }
-            int gx = (int)((mx + 255) / 256); if (gx > 4096) gx = 4096; if (gx < 1) gx = 1;
-            job.mode = 2; job.gx = gx; job.gy = p.nphase; job.lds_bytes = 0;
-        }
-    }
-    if (ws.plan_out) {          // plan-only call (hific_conv_pack_plan): hand the job to the caller, launch nothing
-        job.p = p; job.p.wp = nullptr;
-        *ws.plan_out = job;
-        return HIFIC_OK;
-    }
-    void* wp;
-    if (ws.wcache_state != 0) {
-        if (!ws.wcache || ws.wcache_bytes < wp_bytes) return HIFIC_ERR_WS;
-        wp = ws.wcache;
-    } else {
-        wp = ws.take(wp_bytes);
-        if (!wp) return HIFIC_ERR_WS;
-    }
-    p.wp = wp;
-    if (ws.wcache_state != 2) {
-        if (job.mode == 0) {
-            if (job.lds_bytes > 48 * 1024)
-                gc_set_max_lds((const void*)pack_w2_kernel<T, 0>, job.lds_bytes);
-            hipLaunchKernelGGL((pack_w2_kernel<T, 0>), dim3(job.gx, job.gy), dim3(256), job.lds_bytes, st, p, w, w_scale, sm, sc, job.RS, job.MB);
-        } else if (job.mode == 1) {
-            if (job.lds_bytes > 48 * 1024)
-                gc_set_max_lds((const void*)pack_w2_kernel<T, 1>, job.lds_bytes);
-            hipLaunchKernelGGL((pack_w2_kernel<T, 1>), dim3(job.gx, job.gy), dim3(256), job.lds_bytes, st, p, w, w_scale, sm, sc, job.RS, job.MB);
-        } else {
-            hipLaunchKernelGGL(pack_w_kernel<T>, dim3(job.gx, p.nphase), dim3(256), 0, st, p, w, w_scale, sm, sc, sr, ss);
-        }
+        bool plan_only = false;
+        const int rcp = gc_pack_weights<T>(p, wp_elems, w, w_scale, sm, sc, sr, ss, ws, st, &plan_only);
+        if (rcp != HIFIC_OK || plan_only) return rcp;
     }
     p.max_tiles = max_tiles;
     if (p.ksplit > 1) {
@@ -4216,6 +4170,12 @@ static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, lon
     if constexpr (std::is_same<T, float>::value) {
         return launch_gconv_tb<float, 16>(p, w, w_scale, sm, sc, sr, ss, ws, st);
     } else {
+        {   // pipelined persistent kernel for the stride-2 layers (gconv_pl.hip); it leaves the plan untouched when it declines
+            const GcParams saved = p;
+            const int rcp = launch_gconv_pl(p, w, w_scale, sm, sc, sr, ss, ws, st);
+            if (rcp != HIFIC_ERR_UNSUPPORTED) return rcp;
+            p = saved;
+        }
         if (p.C <= 16 || (p.csplit && p.C <= 32)) return launch_gconv_tb<bf16_t, 16>(p, w, w_scale, sm, sc, sr, ss, ws, st);
         return launch_gconv_tb<bf16_t, 64>(p, w, w_scale, sm, sc, sr, ss, ws, st);
     }

@@ -88,6 +88,7 @@ SIGNATURES = {
     "hific_pack_batch": (I, [P, P, I, I, Z, I, P]),
     "hific_augment_crop": (I, [P, P, P, P, P, I, I, I, I, P, P]),
     "hific_prof_begin": (I, []),
+    "hific_env_refresh": (I, []),
     "hific_prof_end": (I, [I, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int), c_char_p]),
 }
 

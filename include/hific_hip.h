@@ -279,6 +279,11 @@ int hific_augment_crop(const void* imgs, const int* xb, const int* xk, const int
 int hific_prof_begin(void);
 int hific_prof_end(int max_kinds, double* ms, double* flops, int* count, char* names);
 
+/* The planner's HIFIC_* environment knobs (A/B switches of the conv engine; the reference has no counterpart - its knobs are
+ * cuDNN's) are read once per process and cached.  A caller that changes one inside a running process (tests, tools) calls this
+ * to drop the cache; packed weights made under the old setting must be dropped by the caller too. */
+int hific_env_refresh(void);
+
 #ifdef __cplusplus
 }
 #endif

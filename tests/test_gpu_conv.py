@@ -51,6 +51,13 @@ CONV_CASES = {
     "S2_4x4_zero":          (1, 130, 8, 32, 30, 4, 2, (1, 1, 1, 1), "zeros"),
     # natural-order stride-1 weight gradient (wgrad_s1_kernel; R_3x3_960 / E6 / A1 / SP128_zero_16 above take it too): several
     # column tiles, a partial tile row (H = 12, 20), channel tails, reflect and zero padding
+    # pipelined stride-2 forward kernel (gconv_pl_kernel; E2 / E5 / D1 / D4 / S2_* above take it too): 32-pixel tile rows with a
+    # partial last tile row (OH = 6, 10), several row tiles (K = 200), channel tails (C = 40, 70, 100), one workgroup walking
+    # several tiles and channel chunks, reflect (rim columns on both sides) and zero padding, 3x3 and 4x4 windows
+    "PL_3x3_wide_reflect":  (2, 70, 12, 128, 200, 3, 2, (1, 0, 0, 1), "reflect"),
+    "PL_4x4_wide_reflect":  (3, 40, 20, 64, 100, 4, 2, (1, 1, 1, 1), "reflect"),
+    "PL_3x3_sym_reflect":   (1, 100, 24, 64, 130, 3, 2, (1, 1, 1, 1), "reflect"),
+    "PL_3x3_zero_many":     (9, 64, 32, 64, 64, 3, 2, (1, 1, 0, 0), "zeros"),
     "S1_rect_reflect":      (2, 70, 12, 32, 100, 3, 1, (1, 1, 1, 1), "reflect"),
     "S1_wide_zero":         (1, 130, 20, 48, 40, 3, 1, (1, 1, 1, 1), "zeros"),
 }
@@ -248,6 +255,7 @@ def test_merged_phase_kernel_equals_the_per_phase_kernel(hific, dev):
     try:
         for mp in ("1", "0"):
             os.environ["HIFIC_MP"] = mp
+            lib.call("hific_env_refresh")          # the planner caches its knobs
             ops.pack_cache.clear()
             with torch.no_grad():
                 y = ops.conv_transpose2d(x, w, b, 2, 1, 1, act="relu")
@@ -267,6 +275,7 @@ def test_merged_phase_kernel_equals_the_per_phase_kernel(hific, dev):
             os.environ.pop("HIFIC_MP", None)
         else:
             os.environ["HIFIC_MP"] = was
+        lib.call("hific_env_refresh")
         ops.pack_cache.clear()
     assert torch.equal(outs["1"][0], outs["0"][0])
     assert torch.equal(outs["1"][1], outs["0"][1])
@@ -326,4 +335,54 @@ def test_strided_weight_gradients_take_their_kernels(hific, dev):
     for name in ("I16_3x3s1_c12", "I16_4x4s2_c16_zero", "odd_s2"):
         assert "wgrad_im2col_kernel<bf16>" in conv_wgrad(name), name
     assert "wgrad_s2_kernel" not in conv_wgrad("odd_s2")
+    hific.set_compute_dtype(torch.float32)
+
+
+def test_stride2_forward_layers_take_the_pipelined_kernel(hific, dev):
+    """Pins the dispatch of the stride-2 forward-type layers to gconv_pl_kernel (the parity cases would also pass on the
+    generic kernel), checks what it must decline (odd planes, few output channels, float32 parity mode), and that it agrees with
+    the generic kernel (HIFIC_PL=0) to bf16 output rounding - same products, different summation order inside a chunk."""
+    import os
+    from hific_amd import ops, lib
+    hific.set_compute_dtype(torch.bfloat16)
+
+    def fwd(name, with_out=False):
+        N, C, H, W, K, R, stride, pads, mode = CONV_CASES[name]
+        x = _rnd((N, C, H, W), 1, torch.bfloat16).to(dev).bfloat16()
+        w = (_rnd((K, C, R, R), 2, torch.bfloat16) * 0.05).to(dev)
+        b = _rnd((K,), 3, torch.float32).to(dev)
+        pm = lib.PAD_REFLECT if mode == "reflect" else lib.PAD_ZERO
+        out = {}
+        def run():
+            with torch.no_grad():
+                out["y"] = ops.conv2d(x, w, b, stride=stride, pads=pads, pad_mode=pm, act="leaky_relu")
+            torch.cuda.synchronize()
+        kinds = _kinds_of(run)
+        return (kinds, out["y"]) if with_out else kinds
+
+    for name in ("E2_3x3s2_asym", "E5_3x3s2_asym_480", "D1_4x4s2", "D4_4x4s2_256_512", "S2_3x3_rect_asym", "S2_3x3_zero_asym",
+                 "S2_4x4_reflect", "PL_3x3_wide_reflect", "PL_4x4_wide_reflect", "PL_3x3_sym_reflect", "PL_3x3_zero_many"):
+        kinds = fwd(name)
+        assert any(k.startswith("gconv_pl_kernel") for k in kinds), (name, kinds)
+    for name in ("odd_s2", "S2_4x4_zero", "A2_5x5s2_reflect2", "R_3x3_960"):
+        kinds = fwd(name)
+        assert not any(k.startswith("gconv_pl_kernel") for k in kinds), (name, kinds)
+    was = os.environ.get("HIFIC_PL")
+    try:
+        for name in ("PL_3x3_wide_reflect", "PL_4x4_wide_reflect", "D1_4x4s2"):
+            _, y1 = fwd(name, with_out=True)
+            os.environ["HIFIC_PL"] = "0"
+            lib.call("hific_env_refresh"); ops.pack_cache.clear()
+            kinds0, y0 = fwd(name, with_out=True)
+            assert not any(k.startswith("gconv_pl_kernel") for k in kinds0)
+            os.environ.pop("HIFIC_PL")
+            lib.call("hific_env_refresh"); ops.pack_cache.clear()
+            scale = y0.float().abs().max().item()
+            assert (y1.float() - y0.float()).abs().max().item() <= 2.0 ** -7 * scale, name
+    finally:
+        if was is None:
+            os.environ.pop("HIFIC_PL", None)
+        else:
+            os.environ["HIFIC_PL"] = was
+        lib.call("hific_env_refresh"); ops.pack_cache.clear()
     hific.set_compute_dtype(torch.float32)
