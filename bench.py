@@ -622,6 +622,19 @@ def parity_leg(args, dev):
                 rec_x = model.Generator(dec.contiguous()).float().cpu()
         finally:
             hops.set_exact_reconstruction(False)
+    rec_t = None
+    if args.dtype == "bf16":
+        # the exact-TRAINING option (ops.set_exact_training): the same forward with autograd enabled - the mode `exact_training`
+        # below times; its reconstruction comes from this training forward (same noise), indices compared as above
+        hops.set_exact_training(True)
+        try:
+            noises = [nh.to(dev), nl.to(dev)]
+            _, inter_t = model(x.to(dev), train_generator=True, return_intermediates=True, writeout=False)
+            same_idx = bool(torch.equal(inter_t.latents_quantized.detach().float(), dec))
+            rec_t = inter_t.reconstruction.detach().float().cpu() if same_idx else None
+            del inter_t
+        finally:
+            hops.set_exact_training(False)
     dec = dec.cpu()
     del model, losses, inter
     hops.pack_cache.clear(); hops.split_weights.clear()
@@ -662,6 +675,8 @@ def parity_leg(args, dev):
                              "activations); *_exact_reconstruction_option: the same latents through the Generator under "
                              "hific_amd.set_exact_reconstruction(True) (no-grad forwards only: decompress / EVALUATION), the "
                              "mode that meets north_star's 1e-3 on the reconstruction; its cost is fwd.exact_reconstruction_*")
+    if rec_t is not None:
+        res["recon_rel_exact_training_option"] = float((rec_t - ref).abs().max() / ref.abs().max())
     return {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in res.items()}
 
 
@@ -848,6 +863,28 @@ def main():
         hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
         torch.cuda.empty_cache()
         default_shape = args.size == 256 and args.regime == "low"
+        # ---- the same cycle under the exact-TRAINING option: split-bf16 Generator forward with autograd (float32 Generator
+        #      activations, bf16 MFMA everywhere): what north_star's 1e-3 on the reconstruction costs a bf16 training step ----
+        if args.dtype == "bf16" and default_shape:
+            hific_ops.set_exact_training(True)
+            try:
+                m4, o4, r4 = build(args, dev, cfg)
+                s4 = make_step(args, m4, o4, r4, dev, cfg)
+                s4(); s4()
+                n4 = max(3, min(args.steps, 6))
+                e4 = timed(s4, n4, 1, fence)
+                out["exact_training"] = {
+                    "value": round(imgs_per_step * n4 / e4, 3), "unit": "images/s", "ms_per_step": round(e4 / n4 * 1e3, 3),
+                    "launch": "eager",
+                    "workload": "the headline cycle with hific_amd.set_exact_training(True): exact-index chain + split-bf16 "
+                                "Generator forward under autograd (float32 Generator activations, bf16 MFMA operands in forward "
+                                "and backward); reconstruction of the training forward: parity.recon_rel_exact_training_option, "
+                                "gradients: tests/test_gpu_golden.py::test_fullsize_bf16_exact_training_mode"}
+                del m4, o4, r4, s4
+            finally:
+                hific_ops.set_exact_training(False)
+            hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
+            torch.cuda.empty_cache()
         # ---- the same cycle in float32 parity mode (f32 MFMA: exact fma chains) ---------------------------------------
         if args.dtype == "bf16" and default_shape:
             a32 = argparse.Namespace(**vars(args)); a32.dtype = "f32"

@@ -7,7 +7,7 @@ Import name: `hific_amd` (the on-disk directory keeps the project's hyphenated n
 from . import lib  # noqa: F401  (raises if the HIP library is not built: there is no fallback)
 from . import ops  # noqa: F401
 from .ops import (set_compute_dtype, get_compute_dtype, set_exact_index, exact_index_on,  # noqa: F401
-                  set_exact_reconstruction, exact_reconstruction_on)
+                  set_exact_reconstruction, exact_reconstruction_on, set_exact_training, exact_training_on)
 from . import normalisation, network, compression, hyperprior, loss, helpers, default_config, model, graph  # noqa: F401
 from .model import Model  # noqa: F401
 

@@ -26,7 +26,7 @@ class HipConv2d(nn.Conv2d):
     def forward(self, x):
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], pads=self.pads,
                           pad_mode=self.hip_pad_mode, act=self.act, out_f32=self.out_f32,
-                          exact=_exact_mode(self), bias_grad=not self.bias_grad_in_norm)
+                          exact=_exact_mode(self, x), bias_grad=not self.bias_grad_in_norm)
 
     def extra_repr(self):
         return super().extra_repr() + f", pads(t,l,b,r)={self.pads}, hip_act={self.act}"
@@ -48,18 +48,33 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x):
         return ops.conv_transpose2d(x, self.weight, self.bias, self.stride[0], self.padding[0],
                                     self.output_padding[0], act=self.act, out_f32=self.out_f32,
-                                    exact=_exact_mode(self), bias_grad=not self.bias_grad_in_norm)
+                                    exact=_exact_mode(self, x), bias_grad=not self.bias_grad_in_norm)
 
 
 # hyper nets: the 5x5 stride-2 layers (generic kernel) in the pair layout of the native split kernel (ops.SPLIT_PAIR)
 _PAIR_HYPER = os.environ.get("HIFIC_EXACT_PAIR_HYPER", "1") not in ("0", "")
 
 
-def _exact_mode(m):
+_warned_recon_big = False
+
+
+def _exact_mode(m, x=None):
     """False (plain bf16), True (split operands over 3C channels) or "pair" (native split kernel) for layer m's forward."""
     chain = m.exact_index_chain and ops.exact_index_on()
     # exact-reconstruction option: the Generator's layers in no-grad forwards (ops.set_exact_reconstruction)
-    recon = m.exact_recon and ops.exact_reconstruction_on() and not torch.is_grad_enabled()
+    # ... and, with ops.set_exact_training, in training forwards too (float32 activations through the autograd graph)
+    recon = m.exact_recon and ((ops.exact_reconstruction_on() and not torch.is_grad_enabled()) or ops.exact_training_on())
+    if recon and not chain:
+        # the split images are addressed with 32-bit element offsets: beyond that (a 60-channel plane of ~11.9 MP) this
+        # forward degrades to the plain bf16 path instead of failing (ADVICE round 4)
+        global _warned_recon_big
+        h, w = (int(x.shape[-2]), int(x.shape[-1])) if x is not None else (1, 1)
+        if not ops.exact_chain_fits([(m.in_channels, h, w)]):
+            if not _warned_recon_big:
+                import warnings
+                warnings.warn("exact-reconstruction option: input plane beyond the split-image limit, plain bf16 forward")
+                _warned_recon_big = True
+            return False
     if not (chain or recon):
         return False
     pair = _PAIR_HYPER and ops.exact_pair_on() and m.stride[0] == 2 and m.in_channels >= 32

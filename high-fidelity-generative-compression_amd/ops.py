@@ -322,6 +322,25 @@ def exact_reconstruction_on():
     return _EXACT_RECON
 
 
+# Exact-TRAINING option: the same split-bf16 Generator forward WITH autograd, so that a training step
+# - not only decompress / evaluation - produces a reconstruction within north_star's 1e-3 of the reference's.  The Generator then
+# keeps float32 activations (Conv2dFn / ConvTranspose2dFn exact=True: split-bf16 forward, float32 output), its backward runs the
+# bf16 MFMA kernels on those float32 tensors (operands rounded to bf16 in the tile loaders, f32 accumulate) - the arithmetic of
+# the hyper nets' exact chain.  Costs the trunk three MFMAs per product and float32 activation traffic: the bench reports it
+# as `exact_training`; the default training mode stays plain bf16 in the Generator.  HIFIC_EXACT_TRAIN=1 /
+# hific_amd.set_exact_training(True).
+_EXACT_TRAIN = os.environ.get("HIFIC_EXACT_TRAIN", "0") not in ("0", "")
+
+
+def set_exact_training(on):
+    global _EXACT_TRAIN
+    _EXACT_TRAIN = bool(on)
+
+
+def exact_training_on():
+    return _EXACT_TRAIN
+
+
 class exact_index_suspended:
     """`with ops.exact_index_suspended():` - the plain bf16 chain for the calls inside (restores the previous setting)."""
 

@@ -268,6 +268,54 @@ def test_fullsize_bf16_exact_reconstruction_option(hific, dev, fullsize_oracle):
     assert err_rec < 1e-3 and rms_rec < 1e-3
 
 
+def test_fullsize_bf16_exact_training_mode(hific, dev, fullsize_oracle):
+    """The exact-TRAINING option (ops.set_exact_training): the same split-bf16 Generator forward with autograd.  A G-turn
+    forward + backward at the benchmarked shape: reconstruction given equal indices and the loss within north_star's 1e-3 of
+    the oracle, and every Generator / Encoder gradient finite and within bf16-operand distance of the plain bf16 mode's
+    (same weights, images and noise: the two backward passes differ in the activations' precision only)."""
+    from hific_amd import ops
+    fo = fullsize_oracle
+    out = fo["out"]
+    grads = {}
+    for mode in ("plain", "exact"):
+        ops.set_exact_training(mode == "exact")
+        try:
+            model = _build(hific, dev, False, True, torch.bfloat16, batch=16, size=256)
+            noises = [fo["nh"].to(dev), fo["nl"].to(dev)]
+            model.Hyperprior._draw_noise = lambda t: noises.pop(0)
+            losses, inter = model(fo["x"].to(dev), train_generator=True, return_intermediates=True, writeout=False)
+            losses["compression"].backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_exact_training(False)
+        grads[mode] = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()
+                       if p.grad is not None and (n.startswith("Generator.") or n.startswith("Encoder."))}
+        if mode == "exact":
+            sym_o = O.quantized_indices(out["y"], out["hyperinfo"].latent_means)
+            frac = out["y"] - out["hyperinfo"].latent_means + 0.5
+            frac = frac - torch.floor(frac)
+            n_flips = _assert_tie_only(_symbols(model, inter).cpu(), sym_o, torch.minimum(frac, 1 - frac), "bf16 + exact training")
+            rec = inter.reconstruction.detach().float().cpu()
+            rec_ref = out["reconstruction"]
+            if n_flips:
+                with torch.no_grad():
+                    rec_ref = O.generator_forward(fo["sd"], inter.latents_quantized.detach().float().cpu(), 9)
+            err_rec = _relerr(rec, rec_ref)
+            loss_rel = _rel(float(losses["compression"].detach()), float(out["compression"]))
+    worst, worst_name = 0.0, ""
+    for n, g in grads["exact"].items():
+        assert torch.isfinite(g).all(), n
+        e = _relerr(g, grads["plain"][n])
+        if e > worst:
+            worst, worst_name = e, n
+    print(f"\n[bf16 + exact-training option, full size] reconstruction given equal indices max-rel {err_rec:.2e}, loss rel "
+          f"{loss_rel:.2e}; {len(grads['exact'])} Generator / Encoder gradients vs the plain bf16 mode: worst max-rel "
+          f"{worst:.2e} ({worst_name})")
+    assert err_rec < 1e-3
+    assert loss_rel < 1e-3
+    assert len(grads["exact"]) == len(grads["plain"]) and worst < 8e-2
+
+
 def test_fullsize_plain_bf16_chain_is_what_the_exact_mode_fixes(hific, dev, fullsize_oracle):
     """HIFIC_EXACT_INDEX=0 behaviour kept for comparison: plain bf16 Encoder / hyper nets flip ~0.4 % of the indices."""
     from hific_amd import ops
