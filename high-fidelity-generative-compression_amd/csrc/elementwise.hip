@@ -350,6 +350,71 @@ __global__ void upcat_bwd_ctx_kernel(const T* __restrict__ dout, T* __restrict__
     }
 }
 
+// ---- Discriminator input from its three sources (src/model.py:176-179 + src/network/discriminator.py:36,75-77): the reference
+//      builds cat([real, gen]) and repeat_interleave(latents, 2) and runs the context conv on the 2B repeated latents.  Here
+//      image n < B is real[n], image n >= B is gen[n - B], and image n takes the context map of latent n >> 1 (the pairing
+//      quirk: repeat_interleave duplicates neighbours, cat stacks halves) - the context conv runs on the B latents once.
+__global__ void upcat_pair_fwd_kernel(const bf16_t* __restrict__ real, const bf16_t* __restrict__ gen,
+                                      const bf16_t* __restrict__ ctx, bf16_t* __restrict__ out, unsigned B, int Ci, int Cc,
+                                      int H, int W, int f) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const int C = Ci + Cc, h = H / f, w = W / f, W8 = W / 8;
+    const unsigned total = 2u * B * (unsigned)(C * H * W8);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int x8 = (int)(i % (unsigned)W8);
+        unsigned t = i / (unsigned)W8;
+        const int y = (int)(t % (unsigned)H); t /= (unsigned)H;
+        const int c = (int)(t % (unsigned)C);
+        const unsigned n = t / (unsigned)C;
+        u32x4_t v;
+        if (c < Ci) {
+            const bf16_t* src = n < B ? real + (size_t)n * Ci * H * W : gen + (size_t)(n - B) * Ci * H * W;
+            v = *(const u32x4_t*)(src + ((size_t)c * H + y) * W + x8 * 8);
+        } else {
+            const unsigned e = ctx[(((size_t)(n >> 1) * Cc + (c - Ci)) * h + y / f) * w + (x8 * 8) / f];
+            const unsigned d = e | (e << 16);
+            v = (u32x4_t){d, d, d, d};
+        }
+        *(u32x4_t*)(out + (size_t)i * 8) = v;
+    }
+}
+template <typename T>
+__global__ void upcat_pair_fwd_elem_kernel(const T* __restrict__ real, const T* __restrict__ gen, const T* __restrict__ ctx,
+                                           T* __restrict__ out, int B, int Ci, int Cc, int H, int W, int f) {
+    const int C = Ci + Cc, h = H / f, w = W / f;
+    const long long total = 2ll * B * C * H * W;
+    EW_LOOP(i, total) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int c = (int)((i / ((long long)W * H)) % C);
+        const int n = (int)(i / ((long long)W * H * C));
+        T v;
+        if (c < Ci) v = (n < B ? real : gen)[(((size_t)(n < B ? n : n - B) * Ci + c) * H + y) * W + x];
+        else v = ctx[(((size_t)(n >> 1) * Cc + (c - Ci)) * h + y / f) * w + x / f];
+        out[i] = v;
+    }
+}
+// dctx[k] = block sums of dout[2k, Ci:] + dout[2k+1, Ci:] (the two images that read latent k's context map)
+template <typename T>
+__global__ void upcat_pair_bwd_ctx_kernel(const T* __restrict__ dout, T* __restrict__ dctx, int B, int Ci, int Cc, int H,
+                                          int W, int f) {
+    const int C = Ci + Cc, h = H / f, w = W / f;
+    const long long total = (long long)B * Cc * h * w;          // one wave per output element
+    const int lane = threadIdx.x & 63;
+    for (long long gi = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; gi < total;
+         gi += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const int x = (int)(gi % w), y = (int)((gi / w) % h);
+        const int c = (int)((gi / ((long long)w * h)) % Cc);
+        const int k = (int)(gi / ((long long)w * h * Cc));
+        float s = 0.f;
+        for (int j = 0; j < 2; ++j) {
+            const T* p = dout + (((size_t)(2 * k + j) * C + Ci + c) * H + (size_t)y * f) * W + (size_t)x * f;
+            for (int q = lane; q < f * f; q += 64) s += DT<T>::ld(p + (size_t)(q / f) * W + (q % f));
+        }
+        s = wave_sum(s);
+        if (lane == 0) DT<T>::st(dctx + gi, s);
+    }
+}
+
 // ---- spectral norm (one power iteration, torch.nn.utils.spectral_norm semantics) --------------------
 // W: [K, M] row-major f32.  step 1: vraw[m] = sum_k W[k,m] u[k]
 // The K rows are cut into slices of SN_ROWS (blockIdx.y): all loads of a thread are independent and issued together,
@@ -875,6 +940,41 @@ int hific_upcat_bwd(const void* dout, void* dimg, int n0, int nimg, void* dctx, 
         DISPATCH_T(dtype,
             hipLaunchKernelGGL(upcat_bwd_ctx_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)dout, (float*)dctx, N, Ci, Cc, H, W, f),
             hipLaunchKernelGGL(upcat_bwd_ctx_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dctx, N, Ci, Cc, H, W, f));
+    }
+    return hific_launch_status();
+}
+
+// out [2B, Ci+Cc, H, W] from real [B,Ci,H,W], gen [B,Ci,H,W] and ctx [B,Cc,H/f,W/f] (image n reads ctx[n >> 1])
+int hific_upcat_pair_fwd(const void* real, const void* gen, const void* ctx, void* out, int B, int Ci, int Cc, int H, int W,
+                         int f, int dtype, hipStream_t st) {
+    if (!real || !gen || !ctx || !out || B <= 0 || f <= 0 || H % f || W % f) return HIFIC_ERR_ARG;
+    const long long total = 2ll * B * (Ci + Cc) * H * W;
+    if (dtype == HIFIC_BF16 && W % 8 == 0 && f % 8 == 0 && total / 8 < (1ll << 32) &&
+        !((((size_t)real) | ((size_t)gen) | ((size_t)out)) & 15)) {
+        hipLaunchKernelGGL(upcat_pair_fwd_kernel, EW_GRID(total / 8), dim3(256), 0, st, (const bf16_t*)real, (const bf16_t*)gen,
+                           (const bf16_t*)ctx, (bf16_t*)out, (unsigned)B, Ci, Cc, H, W, f);
+        return hific_launch_status();
+    }
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(upcat_pair_fwd_elem_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)real, (const float*)gen, (const float*)ctx, (float*)out, B, Ci, Cc, H, W, f),
+        hipLaunchKernelGGL(upcat_pair_fwd_elem_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)real, (const bf16_t*)gen, (const bf16_t*)ctx, (bf16_t*)out, B, Ci, Cc, H, W, f));
+    return hific_launch_status();
+}
+// dgen [B,Ci,H,W] = dout[B:, :Ci] (null: skipped - the D-turn detaches the generated images), dctx [B,Cc,H/f,W/f] (null: skipped)
+int hific_upcat_pair_bwd(const void* dout, void* dgen, void* dctx, int B, int Ci, int Cc, int H, int W, int f, int dtype,
+                         hipStream_t st) {
+    if (!dout || B <= 0 || f <= 0) return HIFIC_ERR_ARG;
+    if (dgen) {
+        const long long total = (long long)B * Ci * H * W;
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL(upcat_bwd_img_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)dout, (float*)dgen, B, B, Ci, Cc, H, W),
+            hipLaunchKernelGGL(upcat_bwd_img_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dgen, B, B, Ci, Cc, H, W));
+    }
+    if (dctx) {
+        const long long total = (long long)B * Cc * (H / f) * (W / f) * 64;
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL(upcat_pair_bwd_ctx_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)dout, (float*)dctx, B, Ci, Cc, H, W, f),
+            hipLaunchKernelGGL(upcat_pair_bwd_ctx_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dctx, B, Ci, Cc, H, W, f));
     }
     return hific_launch_status();
 }

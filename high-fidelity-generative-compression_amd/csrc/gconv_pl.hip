@@ -450,14 +450,16 @@ int launch_gconv_pl(GcParams& p, const float* w, const float* w_scale, long long
         if (p.IW < 2 || p.IH < 2) return HIFIC_ERR_UNSUPPORTED;
     }
     // tile: 128 output pixels of one image, rows of 32 (wide planes) or 16 pixels
-    const int TW = ph.OWt >= 32 && ph.OWt % 32 == 0 ? 32 : 16, TH = 128 / TW;
+    int TW = ph.OWt >= 32 && ph.OWt % 32 == 0 ? 32 : 16;
+    if (gc_env_int("HIFIC_PL_TW", 0) == 16) TW = 16;                        // (A/B knob: 16-pixel tile rows everywhere)
+    const int TH = 128 / TW;
     const int PH = (TH - 1) * 2 + span_y, PW = (TW - 1) * 2 + span_x;
     const int RH = (PH + 1) / 2, RW = (PW + 1) / 2;
     const int acol = ((ph.dx_min % 8) + 8) & 7;
     const int NGR = (acol + PW + 7) / 8;
     if (PH * NGR > 128) return HIFIC_ERR_UNSUPPORTED;             // (patch row, aligned group) units: two per lane
     const size_t pbytes = (size_t)(4 * RH * RW + 1) * 64;         // 16 channel-pair planes of 4 RH RW + 1 dwords
-    int tg = nt == 9 ? 3 : 4;
+    int tg = nt == 9 ? 3 : (gc_env_int("HIFIC_PL_TG", 4) == 2 ? 2 : 4);
     if (2 * (size_t)tg * PL_SLOT_TAP + 2 * pbytes + 512 > (size_t)150 * 1024) {
         if (nt == 16) tg = 2;
         if (2 * (size_t)tg * PL_SLOT_TAP + 2 * pbytes + 512 > (size_t)150 * 1024) return HIFIC_ERR_UNSUPPORTED;

@@ -107,8 +107,12 @@ class Model(nn.Module):
             x_gen = x_gen.detach()
         if x_real.dtype != x_gen.dtype:
             x_real = ops.cast(x_real.contiguous(), x_gen.dtype)
-        latents = torch.repeat_interleave(intermediates.latents_quantized.detach(), 2, dim=0)
-        D_out, D_out_logits = self.Discriminator(torch.cat([x_real, x_gen], dim=0), latents)
+        if hasattr(self.Discriminator, "forward_pairs") and x_gen.is_cuda:
+            # cat([x_real, x_gen]) x repeat_interleave(latents, 2) as one gather inside the Discriminator (forward_pairs)
+            D_out, D_out_logits = self.Discriminator.forward_pairs(x_real, x_gen, intermediates.latents_quantized.detach())
+        else:
+            latents = torch.repeat_interleave(intermediates.latents_quantized.detach(), 2, dim=0)
+            D_out, D_out_logits = self.Discriminator(torch.cat([x_real, x_gen], dim=0), latents)
         D_real, D_gen = torch.chunk(torch.squeeze(D_out), 2, dim=0)
         D_real_logits, D_gen_logits = torch.chunk(torch.squeeze(D_out_logits), 2, dim=0)
         return Disc_out(D_real, D_gen, D_real_logits, D_gen_logits)

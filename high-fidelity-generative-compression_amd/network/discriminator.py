@@ -70,6 +70,21 @@ class Discriminator(nn.Module):
         if x.dtype != y.dtype:
             x = ops.cast_grad(x, y.dtype)
         x = ops.UpsampleConcatFn.apply(x.contiguous(), y, self.upsample_factor)
+        return self._trunk(x)
+
+    def forward_pairs(self, x_real, x_gen, latents):
+        """The same as forward(cat([x_real, x_gen]), repeat_interleave(latents, 2)) - how src/model.py:176-179 calls the
+        Discriminator - without materialising either: the context conv runs once per latent and the input gather reads
+        latent n >> 1 for image n (ops.UpsamplePairConcatFn).  x_real / x_gen (B,3,H,W), latents (B,C,H/16,W/16)."""
+        y = self.context_conv(latents)
+        if x_gen.dtype != y.dtype:
+            x_gen = ops.cast_grad(x_gen, y.dtype)
+        if x_real.dtype != y.dtype:
+            x_real = ops.cast(x_real.contiguous(), y.dtype)
+        x = ops.UpsamplePairConcatFn.apply(x_real.contiguous(), x_gen.contiguous(), y, self.upsample_factor)
+        return self._trunk(x)
+
+    def _trunk(self, x):
         # one power iteration per spectral-norm layer and forward (torch.nn.utils.spectral_norm), the four layers per launch
         convs = (self.conv1, self.conv2, self.conv3, self.conv4)
         with torch.no_grad():

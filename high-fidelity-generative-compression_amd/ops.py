@@ -1425,6 +1425,37 @@ class UpsampleConcatFn(Function):
         return dimg, dctx, None
 
 
+class UpsamplePairConcatFn(Function):
+    """The Discriminator input of one turn from (real, gen, per-latent context maps): rows [0, B) = real images, [B, 2B) =
+    generated images, image n reads the context map of latent n >> 1 - what the reference builds with torch.cat and
+    repeat_interleave (src/model.py:176-179) and an upsample + cat (discriminator.py:36,75-77), in one gather kernel."""
+
+    @staticmethod
+    def forward(ctx_, real, gen, ctxt, f):
+        require_gpu(real, gen, ctxt)
+        B, Ci, H, W = real.shape
+        assert gen.shape == real.shape and gen.dtype == real.dtype == ctxt.dtype and ctxt.shape[0] == B
+        Cc = ctxt.shape[1]
+        out = torch.empty((2 * B, Ci + Cc, H, W), dtype=real.dtype, device=real.device)
+        call("hific_upcat_pair_fwd", ptr(real), ptr(gen), ptr(ctxt), ptr(out), B, Ci, Cc, H, W, int(f), lib.dtype_code(real),
+             stream())
+        ctx_.dims = (B, Ci, Cc, H, W, int(f))
+        return out
+
+    @staticmethod
+    def backward(ctx_, g):
+        B, Ci, Cc, H, W, f = ctx_.dims
+        g = g.contiguous()
+        dgen = dctx = None
+        if ctx_.needs_input_grad[1]:
+            dgen = torch.empty((B, Ci, H, W), dtype=g.dtype, device=g.device)
+        if ctx_.needs_input_grad[2]:
+            dctx = torch.empty((B, Cc, H // f, W // f), dtype=g.dtype, device=g.device)
+        if dgen is not None or dctx is not None:
+            call("hific_upcat_pair_bwd", ptr(g), ptr(dgen), ptr(dctx), B, Ci, Cc, H, W, f, lib.dtype_code(g), stream())
+        return None, dgen, dctx, None
+
+
 def spectral_norm_power_iteration(weight_orig, u, v, do_iter, eps=1e-12):
     """In place on the (u, v) buffers, no autograd (torch.nn.utils.spectral_norm semantics: one iteration per
     training-mode forward).  Returns a 2-element tensor [sigma, 1/sigma]."""

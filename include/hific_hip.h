@@ -168,6 +168,14 @@ int hific_upcat_fwd(const void* img, const void* ctx, void* out, int N, int Ci, 
                     int dtype, hipStream_t stream);
 int hific_upcat_bwd(const void* dout, void* dimg, int n0, int nimg, void* dctx, int N, int Ci, int Cc, int H, int W,
                     int f, int dtype, hipStream_t stream);
+/* The Discriminator input of a G / D turn from its three sources, without materialising torch.cat([x_real, x_gen]) and
+ * repeat_interleave(latents, 2) (src/model.py:176-179): image n < B is real[n], image n >= B is gen[n - B], image n reads the
+ * context map ctx[n >> 1] (the reference's latent-pairing quirk), so the context conv runs once per latent.  bwd: dgen =
+ * dout[B:, :Ci] and dctx[k] = block sums of dout[2k, Ci:] + dout[2k+1, Ci:]; either may be null. */
+int hific_upcat_pair_fwd(const void* real, const void* gen, const void* ctx, void* out, int B, int Ci, int Cc, int H, int W,
+                         int f, int dtype, hipStream_t stream);
+int hific_upcat_pair_bwd(const void* dout, void* dgen, void* dctx, int B, int Ci, int Cc, int H, int W, int f, int dtype,
+                         hipStream_t stream);
 /* The same power iteration for n <= 8 layers in one call (src/network/discriminator.py:53-62: the four spectral-norm convs of
  * the Discriminator; their iterations depend only on the weights): per layer bit-identical to hific_spectral_norm_fwd, 6
  * launches for the whole set instead of 6 per layer.  ws >= sum_i (M_i + K_i + ceil(K_i / 16) M_i) floats. */

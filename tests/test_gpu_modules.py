@@ -181,6 +181,46 @@ def test_discriminator(hific, dev, sd, dt, tol):
     _check_grads(got, ref, _gtol(tol), f"Discriminator {dt}", lambda: oracle(torch.float64)[4])
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_discriminator_pair_input_equals_cat_and_repeat_interleave(hific, dev, sd, dt):
+    """Discriminator.forward_pairs(real, gen, latents) against forward(cat([real, gen]), repeat_interleave(latents, 2)) - the
+    call of src/model.py:176-179: same outputs bit for bit (the context conv of a repeated latent is the conv of the latent),
+    same gradients for the generated images; the context-conv gradients agree to rounding (the pair path adds the two
+    images' context gradients before the weight gradient instead of inside it)."""
+    from hific_amd.network.discriminator import Discriminator
+    hific.set_compute_dtype(dt)
+    D = _load(Discriminator((3, 128, 128), (220, 8, 8), C=220), sd, "Discriminator.").to(dev).eval()    # eval: no power iteration
+    B = 3
+    real = O.make_image(9, B, 128, 128).to(dev).to(dt)
+    gen0 = O.make_image(12, B, 128, 128).to(dev).to(dt)
+    lat = (O.make_noise(10, (B, 220, 8, 8)) * 4).to(dev)
+    g = None
+    res = {}
+    for mode in ("cat", "pair"):
+        D.zero_grad()
+        gen = gen0.clone().requires_grad_(True)
+        if mode == "cat":
+            out, logits = D(torch.cat([real, gen], dim=0), torch.repeat_interleave(lat, 2, dim=0))
+        else:
+            out, logits = D.forward_pairs(real, gen, lat)
+        if g is None:
+            g = O.make_noise(11, tuple(logits.shape)).to(dev)
+        logits.backward(g)
+        torch.cuda.synchronize()
+        res[mode] = (out.clone(), logits.detach().clone(), gen.grad.clone(),
+                     {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None})
+    assert torch.equal(res["cat"][0], res["pair"][0]) and torch.equal(res["cat"][1], res["pair"][1])
+    assert torch.equal(res["cat"][2], res["pair"][2])
+    for k, gc in res["cat"][3].items():
+        gp = res["pair"][3][k]
+        tol = 1e-5 if dt == torch.float32 else 2e-2
+        if not k.startswith("context_conv."):
+            assert torch.equal(gc, gp), k
+        else:
+            assert _relerr(gp.float().cpu(), gc.float().cpu()) < tol, k
+    hific.set_compute_dtype(torch.float32)
+
+
 @pytest.mark.parametrize("gan", [False, True], ids=["compression", "compression_gan"])
 def test_model_losses_and_grads_fp32(hific, dev, sd, gan):
     """End-to-end training forward/backward (config 1 semantics at reduced size): losses within 1e-3 of the oracle,
