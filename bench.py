@@ -201,6 +201,63 @@ def choose_launch(args, step, world, fence, ncal=4):
     return (gstep if use_graph else step), use_graph, cal
 
 
+def scale_report(args, step, reducers, opts, world, rank, dev, fence, ms_step):
+    """What a multi-rank line needs to explain itself (rank 0 reports; every rank takes part): the per-bucket timeline of the
+    last backward (issue and duration on the reduce stream), the same cycle with the other gradient payload, and the same
+    cycle on rank 0 ALONE (reducers off, the other ranks parked in a barrier) - `weak_scaling_eff` = that time / the job's."""
+    import torch
+    import torch.distributed as dist
+    from hific_amd import parallel
+    n = max(3, min(args.steps, 6))
+    rep = {"buckets_timeline": {k: [{"bucket": b, "wire_mbytes": mb, "issue_ms": ti, "duration_ms": td}
+                                    for b, mb, ti, td in r.bucket_timeline()] for k, r in reducers.items()},
+           "buckets_timeline_note": "last measured backward on this rank: issue = ms after the first bucket reached its "
+                                    "collective on the reduce stream, duration = collective start to end"}
+    for r in reducers.values():
+        r.measure_exposed(False)
+    # ---- the other payload, same model state ------------------------------------------------------------------------------
+    cur = next(iter(reducers.values())).payload
+    other = "bf16" if cur == "f32" else "f32"
+    sweep = {cur: round(ms_step, 3)}
+    for r in reducers.values():
+        r.payload = other
+    step(); step()
+    e = timed(step, n, 0, fence)
+    t = torch.tensor([e], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sweep[other] = round(float(t.item()) / n * 1e3, 3)
+    for r in reducers.values():
+        r.payload = cur
+    rep["payload_sweep_ms_per_step"] = sweep
+    # ---- rank 0 alone on the same box: no collectives, the other ranks idle in a barrier -------------------------------------
+    solo = None
+    was = {k: r.active for k, r in reducers.items()}
+    if rank == 0:
+        for k, r in reducers.items():
+            r.active = False
+            r.arena.on_write = None
+        step(); step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        solo = (time.perf_counter() - t0) / n * 1e3
+        for k, r in reducers.items():
+            r.active = was[k]
+            if r.active and r.eager:
+                r.arena.on_write = r._on_write
+    fence()
+    t = torch.tensor([solo or 0.0], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    solo = float(t.item())
+    rep["one_rank_same_box_ms_per_step"] = round(solo, 3)
+    rep["weak_scaling_eff"] = round(solo / ms_step, 4) if ms_step > 0 else None
+    rep["weak_scaling_note"] = ("rank 0 alone on this box (reducers off, other ranks idle in a barrier; note that the solo "
+                                "model's parameters then drift from the other ranks': measurement runs only) over the "
+                                f"{world}-rank step time")
+    return rep
+
+
 def timed(step, steps, warmup, fence):
     for _ in range(warmup):
         step()
@@ -730,6 +787,9 @@ def main():
     elapsed = timed(run_step, args.steps, args.warmup, fence)
     rccl = None
     if use_dist:
+        # the job the driver launched is the job the collectives run in
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == world == int(os.environ.get("WORLD_SIZE", "1")), \
+            (dist.get_backend(), dist.get_world_size(), world, os.environ.get("WORLD_SIZE"))
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -745,6 +805,7 @@ def main():
                 "exposed_comm_ms": round(float(t.item()), 3),
                 "exposed_comm_note": "GPU time per step the compute stream waits in BucketedGradReducer.finish() for "
                                      "collectives the backward pass did not hide (max over ranks)"}
+        rccl.update(scale_report(args, step, reducers, opts, world, rank, dev, fence, elapsed / args.steps * 1e3))
     imgs_per_step = args.batch * (2 if cfg == "gan" else 1)
     value = world * imgs_per_step * args.steps / elapsed
     ms_step = elapsed / args.steps * 1e3

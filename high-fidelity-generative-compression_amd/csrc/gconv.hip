@@ -4061,6 +4061,9 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             if constexpr (nwp_ * 4 <= 8) { if (tps == 4) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 4>; } \
             if constexpr (nwp_ * 7 <= 8) { if (tps == 7) kfn = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 7>; } \
         }                                                                                                \
+        if constexpr (!(std::is_same<T, bf16_t>::value && BC >= 32)) {                                   \
+            if (p.split) kfn = nullptr;      /* pair layout: only the SPLIT instantiations (bf16, >= 32-channel chunks) */ \
+        }                                                                                                \
         if constexpr (std::is_same<T, bf16_t>::value && BC >= 32) {                                      \
             if (p.split) {                                                                               \
                 constexpr int nwp_ = (WGM * WM * 32 * (BC * (int)sizeof(T) / 16) + 255) / 256;           \
@@ -4214,7 +4217,8 @@ static int launch_gconv_t_bf16(GcParams& p, const float* w, const float* w_scale
 static int launch_gconv_fewc(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
                              long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
     const GcPhase& ph = p.ph[0];
-    if (p.C > 4 || p.nphase != 1 || p.ist != 1 || ph.ntaps < 25 || p.csplit || p.msplit || env_int("HIFIC_NO_FEWC", 0))
+    if (p.C > 4 || p.nphase != 1 || p.ist != 1 || ph.ntaps < 25 || p.csplit || p.msplit || p.split ||      // (pair layout:
+        env_int("HIFIC_NO_FEWC", 0))                                                // only the SPLIT kernels form the cross terms)
         return HIFIC_ERR_UNSUPPORTED;
     // the taps must form a full (dy_i) x (dx_j) grid with equally spaced dx
     int dys[16], dxv[16], rs_[16], ss_[16], ny = 0, nx = 0;
@@ -4299,7 +4303,7 @@ __global__ void vrow_shift_add_kernel(const float* __restrict__ P, const float* 
 static int launch_gconv_fewk(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc,
                              long long sr, long long ss, WsAlloc& ws, hipStream_t st) {
     const GcPhase& ph = p.ph[0];
-    if (p.K > 4 || p.C < 16 || p.nphase != 1 || p.ist != 1 || p.ost != 1 || ph.ntaps < 25 || p.csplit || p.msplit ||
+    if (p.K > 4 || p.C < 16 || p.nphase != 1 || p.ist != 1 || p.ost != 1 || ph.ntaps < 25 || p.csplit || p.msplit || p.split ||
         p.fold_h || p.resid || ph.ooy || ph.oox || ph.OHt != p.OHf || ph.OWt != p.OWf || env_int("HIFIC_NO_FEWK", 0))
         return HIFIC_ERR_UNSUPPORTED;
     int dys[16], dxv[16], rs_[16], ss_[16], ny = 0, nx = 0;
@@ -4691,8 +4695,17 @@ static int launch_wgrad_s1(WgParams& p, float* dw, long long sm, long long sc, l
     p.direct = p.nsplit == 1;
     p.dw = dw; p.sm = sm; p.sc = sc; p.sr = sr; p.ss = ss; p.accumulate = accumulate;
     if (!p.direct) {
-        p.ws = (float*)ws.take((size_t)p.nsplit * p.Mpad * p.ntaps * p.Cpad * sizeof(float));
-        if (!p.ws) return HIFIC_ERR_WS;
+        // the split-partial planes must fit the caller's workspace: fewer splits first, and if even two do not fit the launcher
+        // declines (nothing has been launched or written yet) and the generic weight-gradient path takes the layer
+        const size_t ws_mark = ws.off;
+        for (;;) {
+            p.ws = (float*)ws.take((size_t)p.nsplit * p.Mpad * p.ntaps * p.Cpad * sizeof(float));
+            if (p.ws || p.nsplit <= 2) break;
+            ws.off = ws_mark;
+            p.tiles_per_split = cdiv(p.ntiles, p.nsplit / 2);
+            p.nsplit = cdiv(p.ntiles, p.tiles_per_split);
+        }
+        if (!p.ws) { ws.off = ws_mark; return HIFIC_ERR_UNSUPPORTED; }
     }
     p.xcd_remap = ((ct * p.nsplit) % 8 == 0) && env_int("HIFIC_WGS1_XCD", 1);
     const int grid = base_blocks * p.nsplit;
@@ -4746,8 +4759,17 @@ static int launch_wgrad_s2(WgParams& p, float* dw, long long sm, long long sc, l
     p.direct = p.nsplit == 1;
     p.dw = dw; p.sm = sm; p.sc = sc; p.sr = sr; p.ss = ss; p.accumulate = accumulate;
     if (!p.direct) {
-        p.ws = (float*)ws.take((size_t)p.nsplit * p.Mpad * p.ntaps * p.Cpad * sizeof(float));
-        if (!p.ws) return HIFIC_ERR_WS;
+        // the split-partial planes must fit the caller's workspace: fewer splits first, and if even two do not fit the launcher
+        // declines (nothing has been launched or written yet) and the generic weight-gradient path takes the layer
+        const size_t ws_mark = ws.off;
+        for (;;) {
+            p.ws = (float*)ws.take((size_t)p.nsplit * p.Mpad * p.ntaps * p.Cpad * sizeof(float));
+            if (p.ws || p.nsplit <= 2) break;
+            ws.off = ws_mark;
+            p.tiles_per_split = cdiv(p.ntiles, p.nsplit / 2);
+            p.nsplit = cdiv(p.ntiles, p.tiles_per_split);
+        }
+        if (!p.ws) { ws.off = ws_mark; return HIFIC_ERR_UNSUPPORTED; }
     }
     p.xcd_remap = ((ct * p.nsplit) % 8 == 0) && env_int("HIFIC_WGS2_XCD", 1);
     const int grid = base_blocks * p.nsplit;

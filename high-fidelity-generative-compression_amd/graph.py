@@ -49,14 +49,31 @@ class GraphedStep:
             self.out = fn()
         # the graph holds raw pointers into the packed-weight cache: its entries must outlive it (replays never touch the
         # cache's LRU bookkeeping)
-        self._pins = ops.pack_cache.pin_all()
+        self._pins, self._pin_keys = ops.pack_cache.pin_all()
         self.replays = 0
+
+    def close(self):
+        """Releases the graph and its pins on the packed-weight cache (pinned entries are exempt from eviction: without this
+        every re-capture would grow the cache past its cap)."""
+        keys, self._pin_keys = getattr(self, "_pin_keys", None), None
+        if keys:
+            from . import ops
+            ops.pack_cache.unpin(keys)
+        self.graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __call__(self):
         from . import ops
         if ops.pack_cache.pins_broken != self._pins:
             raise RuntimeError("GraphedStep: a packed-weight buffer this graph reads was dropped (a parameter was moved, "
                                "re-created, or the cache was cleared) - capture the step again")
+        if self.graph is None:
+            raise RuntimeError("GraphedStep: closed")
         self.graph.replay()
         self.replays += 1
         return self.out

@@ -80,9 +80,19 @@ class WeightPackCache:
         self.pins_broken = 0
 
     def pin_all(self):
-        for e in self.entries.values():
-            e.pinned = True
-        return self.pins_broken
+        """Pins every current entry on behalf of ONE graph (reference-counted: several captured graphs may share entries) and
+        returns (pins_broken, the pinned keys); the graph hands the keys back to unpin() when it is closed or collected."""
+        keys = list(self.entries.keys())
+        for k in keys:
+            e = self.entries[k]
+            e.pinned = int(e.pinned) + 1
+        return self.pins_broken, keys
+
+    def unpin(self, keys):
+        for k in keys:
+            e = self.entries.get(k)
+            if e is not None and e.pinned:
+                e.pinned = int(e.pinned) - 1
 
     def _drop(self, key):
         e = self.entries.pop(key)
@@ -702,6 +712,11 @@ class Conv2dFn(Function):
             # x3 given (ExactConvNormFn chain): x is the nominal bf16 activation, only saved for the weight gradient
             x3 = x3 if x3 is not None else _split3_act(x, lay)
             Cx = x3.shape[1]
+            # a caller-supplied split image must be in the layout the weights are taken in (a pair-layout activation against
+            # 3C weights - or the reverse - would contract silently to garbage)
+            if Cx != (pair_channels(C) if lay == SPLIT_PAIR else 3 * C):
+                raise lib.HificError(f"conv2d(exact): split image has {Cx} channels, layout {lay} of {C} channels needs "
+                                     f"{pair_channels(C) if lay == SPLIT_PAIR else 3 * C}")
             w3 = split_weights.get(weight, transposed=False, layout=lay)
             flags = _exact_flags(lay, C)
             wc = _wcache(w3, 0, (N, Cx, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags & 0xff, None)

@@ -79,7 +79,7 @@ class BucketedGradReducer:
         self.works = []
         # exposed communication: GPU time the launching stream spends in finish() waiting for collectives that the backward
         # pass did not hide (event pairs, read by exposed_comm_ms() after a synchronize); off unless measure_exposed(True)
-        self._measure, self._ev_pairs = False, []
+        self._measure, self._ev_pairs, self._bucket_ev = False, [], []
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('HIFIC_FORCE_DIST') == '1')
         self.eager = bool(eager)
         self._reset()
@@ -128,7 +128,18 @@ class BucketedGradReducer:
                 red.wait_stream(st)
             with torch.cuda.stream(red):
                 wire = self._to_stage(lo, hi) if bf16 else grad
-                self.works.append(dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self._measure:
+                    # per-bucket timeline (bench.py `rccl.buckets_timeline`): issue = the reduce stream reaches the collective
+                    # (every producer stream has delivered the bucket), done = the collective has finished.  The reduce stream
+                    # is made to wait for the collective here, which changes nothing for the compute streams.
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(red)
+                    w = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    w.wait()
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(red)
+                    self._bucket_ev.append((b, (hi - lo) * (2 if bf16 else 4), e0, e1))
+                    self.works.append(w)
+                else:
+                    self.works.append(dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             return
         # the collective is ordered after the CURRENT stream: bring the side / branch streams in
         if grad.is_cuda:
@@ -176,7 +187,19 @@ class BucketedGradReducer:
 
 
     def measure_exposed(self, on=True):
-        self._measure, self._ev_pairs = bool(on), []
+        self._measure, self._ev_pairs, self._bucket_ev = bool(on), [], []
+
+    def bucket_timeline(self):
+        """[(bucket, MiB on the wire, issue ms after the first bucket's issue, duration ms)] of the LAST measured backward;
+        call after a device synchronize.  Empty unless measure_exposed(True) and the collectives ran on the reduce stream."""
+        ev, self._bucket_ev = self._bucket_ev, []
+        if not ev:
+            return []
+        nb = len(self.buckets)
+        last = ev[-nb:] if len(ev) >= nb else ev
+        t0 = last[0][2]
+        return [(b, round(nbytes / 2 ** 20, 2), round(t0.elapsed_time(e0), 3), round(e0.elapsed_time(e1), 3))
+                for b, nbytes, e0, e1 in last]
 
     def exposed_comm_ms(self):
         """Total GPU time (ms) the launching stream waited inside finish() since measure_exposed(True); call after a

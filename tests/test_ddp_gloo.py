@@ -22,6 +22,7 @@ def _worker(rank, world, port, eager, q):
         arena = optim.ParamArena(ps)
         red = parallel.BucketedGradReducer(arena, bucket_mbytes=0.25, eager=eager)
         assert red.world == world and len(red.buckets) >= 3
+        red.measure_exposed(True)        # the measurement hooks of bench.py's multi-rank line must not disturb the reduction
         for it in range(2):                                  # two backward passes: bookkeeping must reset
             for i in reversed(range(len(ps))):               # backward order
                 s = ps[i]._hific_slot
@@ -38,6 +39,7 @@ def _worker(rank, world, port, eager, q):
                 want = sum(float(r + 1) * (i + 1) + it for r in range(world))
                 assert torch.allclose(p.grad, torch.full_like(p.grad, want)), (it, i)
             arena.zero_grad()
+        assert red.bucket_timeline() == [] and red.exposed_comm_ms() == 0.0     # device events only: nothing on CPU tensors
         m = parallel.allreduce_scalar_mean(torch.tensor(float(rank)))
         assert abs(float(m) - (world - 1) / 2.0) < 1e-6
         q.put((rank, "ok"))
