@@ -7,12 +7,12 @@ OUT=${OUT:-../libhific_hip.so}
 OBJDIR=${OBJDIR:-.}
 mkdir -p $OBJDIR
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value $EXTRA"
-SRCS="gconv gconv_pl elementwise norm entropy lpips augment capi"
+SRCS="gconv gconv_mpvc gconv_sp9 gconv_pack gconv_wgrad gconv_wgrad_nat gconv_pl elementwise norm entropy lpips augment capi"
 OBJS=""
 PIDS=""
 NAMES=""
 for f in $SRCS; do
-  if [ ! -f $OBJDIR/$f.o ] || [ $f.hip -nt $OBJDIR/$f.o ] || [ common.h -nt $OBJDIR/$f.o ] || [ gconv.h -nt $OBJDIR/$f.o ] || [ gconv_dev.h -nt $OBJDIR/$f.o ]; then
+  if [ ! -f $OBJDIR/$f.o ] || [ $f.hip -nt $OBJDIR/$f.o ] || [ common.h -nt $OBJDIR/$f.o ] || [ gconv.h -nt $OBJDIR/$f.o ] || [ gconv_dev.h -nt $OBJDIR/$f.o ] || [ gconv_stage.h -nt $OBJDIR/$f.o ]; then
     rm -f $OBJDIR/$f.o                            # a failed compile must never leave a stale object to link
     hipcc $FLAGS -c $f.hip -o $OBJDIR/$f.o &
     PIDS="$PIDS $!"

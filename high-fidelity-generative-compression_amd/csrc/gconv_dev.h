@@ -4,6 +4,17 @@
 
 // host-side services of gconv.hip used by the other translation units of the engine
 int gc_env_int(const char* name, int dflt);                 // environment knob, read once per process and cached
+static inline int env_int(const char* name, int dflt) { return gc_env_int(name, dflt); }
+static const int kLdsBudget = 150 * 1024;
+// (TH, TW, NI) of a (u, v) tile domain under an LDS budget: exhaustive search over tile shapes (gconv.hip)
+bool gc_choose_tile(int N, int OHt, int OWt, int ist, int span_y, int span_x, int pitch, int fixed_bytes, int pref_budget,
+                    int& TH, int& TW, int& NI, int ntaps, bool need16);
+// gconv_sp9_kernel family (gconv_sp9.hip): launches the instantiation the plan asks for; false when its LDS image does not fit
+bool gc_launch_sp9(const GcParams& p, dim3 grid, hipStream_t st, int bm, int phs, int sp9_w4);
+// launches the pack kernel of an already planned bf16 job (job.p.wp set)
+void gc_pack_launch_bf16(const PackJob& job, const float* w, const float* w_scale, hipStream_t st);
+int gc_pack_weights_f32(GcParams& p, long long wp_elems, const float* w, const float* w_scale, long long sm, long long sc,
+                        long long sr, long long ss, WsAlloc& ws, hipStream_t st, bool* plan_only);
 void gc_set_max_lds(const void* fn, int bytes);             // dynamic-LDS opt-in per (device, kernel function), raised monotonically
 int gc_prof_open(const char* kname, double flops, hipStream_t st, const char* tag);
 void gc_prof_close(int slot, hipStream_t st);
@@ -111,3 +122,16 @@ __device__ __forceinline__ void gc_store_block(const GcParams& p, const GcPhase&
         }
     }
 }
+
+// weight-gradient family (gconv_wgrad.hip, gconv_wgrad_nat.hip)
+int gc_wgrad_finish(WgParams& p, float* dw, long long sm, long long sc, long long sr, long long ss, int accumulate, WsAlloc& ws,
+                    hipStream_t st);
+int gc_launch_wgrad_s1(WgParams& p, float* dw, long long sm, long long sc, long long sr, long long ss, int accumulate, WsAlloc& ws,
+                       hipStream_t st);
+int gc_launch_wgrad_s2(WgParams& p, float* dw, long long sm, long long sc, long long sr, long long ss, int accumulate, WsAlloc& ws,
+                       hipStream_t st);
+
+// gconv_mpvc.hip
+void gc_launch_mp(const GcParams& p, dim3 grid, size_t lds, hipStream_t st);
+int gc_launch_vc(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc, long long sr, long long ss,
+                 WsAlloc& ws, hipStream_t st);
