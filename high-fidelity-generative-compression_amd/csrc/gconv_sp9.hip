@@ -9,6 +9,9 @@
 #ifndef SP9_ABL
 #define SP9_ABL 0           // timing ablations of gconv_sp9_kernel's A-from-global loop (WRONG RESULTS; tools/micro_sp9.py only):
 #endif                      // 1 = no patch loads / LDS writes, 2 = no A loads, 4 = no B fragment reads, 8 = no chunk barrier
+#ifndef SP9_EXP
+#define SP9_EXP 0           // bit 0: static wave priority, bit 1: pixel-shared XCD mapping (round-5 experiments, see docs/ENGINEERING_LOG.md)
+#endif
 #ifndef SP9_TOFF_ARG
 #define SP9_TOFF_ARG 1      // gconv_sp9_kernel: tap offsets from the kernel arguments instead of the LDS table (-1..2 %)
 #endif
@@ -93,6 +96,10 @@ void gconv_sp9_kernel(const GcParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kgrp = wave / NPOS, tw = wave % NPOS;             // reduction part, wave position inside the tile
+#if SP9_EXP & 1
+    // (experiment: static priority for the second-dispatched half of an 8-wave workgroup - MI355X_MICROARCH "two waves per SIMD" item 4)
+    if (NWAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int wm = tw / WGN, wn = tw % WGN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -104,8 +111,13 @@ void gconv_sp9_kernel(const GcParams p) {
         const int q8 = nwg >> 3, r8 = nwg & 7;
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int q = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+#if SP9_EXP & 2
+        // (experiment: XCD-contiguous q shares the PIXEL tile, the row tile varies fastest)
+        { const int mtiles_ = nwg / p.max_tiles; mtile = q % mtiles_; tile = q / mtiles_; }
+#else
         mtile = q / p.max_tiles;
         tile = q - mtile * p.max_tiles;
+#endif
     }
     if (tile >= ntile_ph) return;
     const int tx = tile % ph.tiles_x;

@@ -732,7 +732,14 @@ class Conv2dFn(Function):
         ctx.cd = cd
         ctx.has_bias = bias is not None
         ctx.w_slot, ctx.b_slot = _slot(weight), _slot(bias)
-        ctx.save_for_backward(x, weight, w_scale, y if act not in (None, "none") else None)
+        # exact-training option: the backward of an exact layer is the plain bf16 one - the tile loaders would round the float32
+        # activation / gradient to bf16 anyway, and only bf16 operands reach the fast kernels (wgrad_s1 / wgrad_s2 / gconv_sp9 RFX;
+        # with float32 operands the residual-block weight gradient ran 317 us on the generic kernel against 88 us).  Saves the
+        # bf16 image of x instead of x.
+        ctx.bf16_bwd = bool(exact and _EXACT_TRAIN and x.dtype == torch.float32)
+        ctx.x_dtype = x.dtype
+        xs = cast(x, torch.bfloat16) if ctx.bf16_bwd else x
+        ctx.save_for_backward(xs, weight, w_scale, y if act not in (None, "none") else None)
         return y
 
     @staticmethod
@@ -749,13 +756,15 @@ class Conv2dFn(Function):
             slope = 0.0 if ctx.act == "relu" else 0.2
             call("hific_act_bwd", ptr(dy), ptr(y), ptr(dz), dy.numel(), slope, lib.dtype_code(dy), stream())
             dy = dz
+        if ctx.bf16_bwd and dy.dtype != torch.bfloat16:
+            dy = cast(dy, torch.bfloat16)
         dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
         dx = dw = db = None
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_grad
         side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
         ev = torch.cuda.current_stream(x.device).record_event() if side else None       # dy is ready here
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx = torch.empty(x.shape, dtype=ctx.x_dtype, device=x.device)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
             wc = _wcache(weight, 1, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, w_scale)
             call("hific_conv2d_bwd_data", ptr(dy), ptr(weight), ptr(w_scale), ptr(dx), N, C, H, W, K, R, S, stride,
@@ -831,7 +840,10 @@ class ConvTranspose2dFn(Function):
                  outpad, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
         ctx.geom, ctx.act, ctx.cd, ctx.has_bias = geom, act, cd, bias is not None
         ctx.w_slot, ctx.b_slot = _slot(weight), _slot(bias)
-        ctx.save_for_backward(x, weight, y if act not in (None, "none") else None)
+        ctx.bf16_bwd = bool(exact and _EXACT_TRAIN and x.dtype == torch.float32)        # see Conv2dFn
+        ctx.x_dtype = x.dtype
+        xs = cast(x, torch.bfloat16) if ctx.bf16_bwd else x
+        ctx.save_for_backward(xs, weight, y if act not in (None, "none") else None)
         return y
 
     @staticmethod
@@ -848,13 +860,15 @@ class ConvTranspose2dFn(Function):
             slope = 0.0 if ctx.act == "relu" else 0.2
             call("hific_act_bwd", ptr(dy), ptr(y), ptr(dz), dy.numel(), slope, lib.dtype_code(dy), stream())
             dy = dz
+        if ctx.bf16_bwd and dy.dtype != torch.bfloat16:
+            dy = cast(dy, torch.bfloat16)
         dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
         dx = dw = db = None
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_grad
         side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
         ev = torch.cuda.current_stream(x.device).record_event() if side else None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx = torch.empty(x.shape, dtype=ctx.x_dtype, device=x.device)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
             wc = _wcache(weight, 1, (N, Ci, H, W, Co, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
             call("hific_conv_transpose2d_bwd_data", ptr(dy), ptr(weight), ptr(dx), N, Ci, H, W, Co, R, S, stride, pad,
