@@ -214,7 +214,13 @@ void gconv_pl_kernel(const GcParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-    pl_u32x4_t aN[TG] = {};
+    // A operands are requested TWO tap groups ahead (one group of MFMAs is 0.3-0.6 us, an L2 round trip under load more than that:
+    // with one group of lead every group ended in a wait - timing ablation: the loop without any memory instruction 27 us, with
+    // the A path alone +12-20 us on 480 -> 960 @32x32).  Register sets rotate with a period that divides the groups per item, so
+    // every index stays a compile-time constant; the LDS ring keeps its two slots.
+    constexpr int NSET = (NG % 2 == 0) ? 2 : 3;
+    static_assert(NG % NSET == 0 && NG >= 2, "register sets per item");
+    pl_u32x4_t aN[NSET][TG] = {};
     pl_u32x4_t pva[PL_QI] = {}, pvb[PL_QI] = {};           // item j: channels 2 cp, 2 cp + 1 of unit (j & 1), cp = 2 wave + (j >> 1)
     unsigned pmask[2];                                     // per unit half: all ones / zero (row, image column range)
     bool pwr[2];
@@ -224,17 +230,17 @@ void gconv_pl_kernel(const GcParams p) {
     const unsigned char* wp_m = (const unsigned char*)p.wp + (size_t)mtile * nch * NT * PL_SLOT_TAP + (size_t)tid * 16;
 
     // A operands of tap group g of chunk c -> registers
-#define PL_ISSUE_A(c_, g_)                                                                                         \
+#define PL_ISSUE_A(set_, c_, g_)                                                                                   \
     do {                                                                                                           \
         const unsigned char* s_ = wp_m + ((size_t)(c_) * NT + (g_) * TG) * PL_SLOT_TAP;                            \
         if constexpr (!(PL_ABL & 2)) {                                                                             \
-        _Pragma("unroll") for (int j = 0; j < TG; ++j) aN[j] = *(const pl_u32x4_t*)(s_ + (size_t)j * PL_SLOT_TAP); } \
+        _Pragma("unroll") for (int j = 0; j < TG; ++j) aN[set_][j] = *(const pl_u32x4_t*)(s_ + (size_t)j * PL_SLOT_TAP); } \
     } while (0)
-#define PL_WRITE_A(slot_)                                                                                          \
+#define PL_WRITE_A(set_, slot_)                                                                                    \
     do {                                                                                                           \
         unsigned char* d_ = aring + (slot_) * SLOT + tid * 16;                                                     \
         if constexpr (!(PL_ABL & 32)) {                                                                            \
-        _Pragma("unroll") for (int j = 0; j < TG; ++j) *(pl_u32x4_t*)(d_ + j * PL_SLOT_TAP) = aN[j]; }             \
+        _Pragma("unroll") for (int j = 0; j < TG; ++j) *(pl_u32x4_t*)(d_ + j * PL_SLOT_TAP) = aN[set_][j]; }       \
     } while (0)
     // halo patch of (tile t_, chunk c_) -> registers: unconditional loads from clamped addresses, masks applied at the LDS write
 #define PL_P_ADDR(t_)                                                                                              \
@@ -361,11 +367,12 @@ void gconv_pl_kernel(const GcParams p) {
 
     // ---- prologue: item 0 staged synchronously -----------------------------------------------------------------------------
     int tile = t_lo, chunk = 0;
-    PL_ISSUE_A(0, 0);
+    PL_ISSUE_A(0, 0, 0);
     PL_P_ADDR(tile);
     PL_P_LOAD(0, 0); PL_P_LOAD(1, 0); PL_P_LOAD(2, 0); PL_P_LOAD(3, 0);
-    PL_WRITE_A(0);
+    PL_WRITE_A(0, 0);
     PL_P_WRITE(0, 0, 0); PL_P_WRITE(0, 0, 1);
+    PL_ISSUE_A(1 % NSET, 0, 1);                            // group 1 of item 0: in flight into the loop
     __syncthreads();
 
     unsigned gcnt = 0;                                     // tap groups done: ring slot of the current group = gcnt & 1
@@ -378,7 +385,8 @@ void gconv_pl_kernel(const GcParams p) {
         const int ptile = last ? tile : ntile, pchunk = last ? chunk : nchunk;     // last item: harmless re-load of itself
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) PL_ISSUE_A(chunk, g + 1); else PL_ISSUE_A(pchunk, 0);
+            // group g + 2 of the item stream -> register set (g + 2) % NSET (group g + 1's set was filled one group ago)
+            if (g + 2 < NG) PL_ISSUE_A((g + 2) % NSET, chunk, g + 2); else PL_ISSUE_A((g + 2) % NSET, pchunk, g + 2 - NG);
             if (g == 0) PL_P_ADDR(ptile);
             // keep the requests HERE: the scheduler otherwise sinks each load to just above its first use
             __builtin_amdgcn_sched_barrier(0);
@@ -405,7 +413,7 @@ void gconv_pl_kernel(const GcParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            PL_WRITE_A((gcnt + 1u) & 1u);
+            PL_WRITE_A((g + 1) % NSET, (gcnt + 1u) & 1u);
             __syncthreads();
             ++gcnt;
         }
