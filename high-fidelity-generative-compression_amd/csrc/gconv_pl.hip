@@ -31,6 +31,9 @@
 // timing ablations (WRONG RESULTS; tools/r05 only): 1 = no patch loads, 2 = no A loads, 4 = no patch LDS writes, 8 = no fragment
 // reads / MFMAs, 16 = no epilogue, 32 = no A LDS writes, 64 = epilogue without its global stores, 128 = epilogue stores of
 // a dummy register instead of the LDS-transposed data
+#ifndef PL_SPREAD
+#define PL_SPREAD 0        // patch requests spread over the first four taps of an item instead of its first two (A/B)
+#endif
 #ifndef PL_ABL
 #define PL_ABL 0
 #endif
@@ -404,10 +407,18 @@ void gconv_pl_kernel(const GcParams p) {
 #pragma unroll
             for (int tt = 0; tt < TG; ++tt) {
                 PL_TAP(aring + (gcnt & 1u) * SLOT, pbuf + pb * pbytes, tt, g * TG + tt);
+#if PL_SPREAD
+                // one lane-item (two loads) behind each of the item's first four taps
+                if (g * TG + tt < 4) {
+                    PL_P_LOAD(g * TG + tt, pchunk);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
                 if (g == 0 && tt < 2) {
                     PL_P_LOAD(2 * tt, pchunk); PL_P_LOAD(2 * tt + 1, pchunk);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
                 if (g == NG - 1 && tt < 2) {
                     PL_P_WRITE(pb ^ 1, pchunk, tt);
                     __builtin_amdgcn_sched_barrier(0);
