@@ -1,39 +1,41 @@
-// Pipelined, persistent forward-type kernel for the STRIDE-2 layers (gfx950): Encoder blocks 2-5 (plain and native split-bf16
-// form), the Discriminator's 4x4 convolutions, and the data gradients of the Generator's up-convolutions - every one of them a
-// one-phase tap-table contraction with input stride 2 (reference: src/network/encoder.py:64-93, src/network/discriminator.py:53-62,
-// src/network/generator.py:115-137 backward).
+// Pipelined, persistent, wave-specialised forward-type kernel for the STRIDE-2 layers (gfx950): Encoder blocks 2-5 (plain and
+// native split-bf16 form), the Discriminator's 4x4 convolutions, and the data gradients of the Generator's up-convolutions - every
+// one of them a one-phase tap-table contraction with input stride 2 (reference: src/network/encoder.py:64-93,
+// src/network/discriminator.py:53-62, src/network/generator.py:115-137 backward).
 //
 // Why a second kernel.  gconv_kernel runs stage -> barrier -> MFMA -> barrier per channel chunk with nothing in flight across a
 // barrier: on these layers (four input pixels per output pixel, 2000-4000 tiles) every workgroup starts its staging at the same
 // time, HBM is saturated for the staging phase and idle for the rest (counters: VALU 49 %, LDS 26 %, MFMA 13 %).  Here
 //   * a workgroup is PERSISTENT: it walks a contiguous range of pixel tiles of one 128-row tile and treats (tile, 32-channel
-//     chunk) pairs as one stream of items; the halo patch of item i+1 is requested (16-byte loads, global -> registers) at the
-//     start of item i, written to the OTHER patch buffer after item i's last MFMA group and first read after the barrier that
-//     ends item i - whether item i+1 is the next chunk of the same tile or the first chunk of the next tile; the epilogue of a
-//     tile is issued while the next tile's patch is already in flight;
-//   * the taps of an item run in groups of TG (one barrier per group); the packed weights of group g+1 (TG x 8 KB, MFMA
-//     A-fragment order: GcParams::afrag = 2) are requested at the start of group g and written to the other slot of a two-slot
-//     LDS ring after its MFMAs - both operands have their loads in flight during MFMAs, every load count is static (hipcc's
-//     vmcnt stays exact) and vector loads return in order, so the A request goes out first and the patch request second;
-//   * the patch image is PARITY-PLANAR: patch pixel (y, x) of a channel chunk lives in plane (y & 1, x & 1) at (y >> 1, x >> 1),
-//     64 bytes (32 channels) per pixel with the 16-byte granule XOR-swizzled by (pixel index >> 2) & 3, so that the B fragment
-//     of any tap - 32 pixels two patch pixels apart - is 32 CONSECUTIVE pixels of one plane: conflict-free ds_read_b128 where
-//     the [pixel][channel] image of gconv_kernel is 2-way conflicted at stride 2, and no padding bytes (39 KB per buffer);
-//   * 8 waves = 2 row halves x 4 pixel quarters (64 rows x 32 pixels each, 32 accumulator registers): no reduction split, no
-//     exchange, registers to spare for the two prefetch sets.
+//     chunk) pairs as one stream of items;
+//   * the 16 waves have two ROLES.  Waves 8-15 LOAD: the halo patch of item i+1 is requested (16-byte loads, global -> registers)
+//     at the start of item i and written to the OTHER patch buffer in the last tap group of item i; the packed weights
+//     (GcParams::afrag = 2: 8 KB per tap in MFMA A-fragment order) run in groups of TG taps through a two-slot LDS ring and are
+//     requested TWO groups ahead into rotating register sets.  Every load count is static (hipcc's vmcnt stays exact) and
+//     vector loads return in order, so the A request goes out first and the patch request second.  Waves 0-7 COMPUTE: 2 row
+//     halves x 4 pixel quarters (64 rows x 32 pixels each), fragment reads of tap t+1 under the MFMAs of tap t, and the epilogue
+//     of a tile (LDS-transposed 16-byte stores through a wave-private 2 KB region) in the first group of the NEXT tile, when
+//     the loaders' requests for that tile are already in flight.  Both role loops execute the same barrier sequence: one
+//     barrier per tap group;
+//   * a patch load instruction reads ONE channel (wave-uniform) for 64 (patch row, aligned 8-pixel group) units: neighbouring
+//     lanes read neighbouring 16 bytes (8-20 cache lines per instruction; with lane = channel pair it was 48-64 and the kernel
+//     ran at the texture addresser's line rate);
+//   * the patch image in LDS is PARITY-PLANAR in planes of 4 channels: patch pixel (y, x) lives at pixel index
+//     ((y & 1, x & 1), y >> 1, x >> 1) of each of the 8 planes, 8 bytes per pixel, so that the B fragment of any tap - 32 pixels
+//     two patch pixels apart - is 32 CONSECUTIVE pixels: conflict-free ds_read_b64 x 4 per tap and ds_write_b64 on the way
+//     in (v_perm interleaves the two channels of a pair), no padding bytes; the mirror column of a reflect boundary is written
+//     from the registers that already hold its source column.
 // SPLIT: operands in the pair layout of the exact-index chain (hific_split3 which = 2: slice 0 = hi, slice 1 = lo of the same
 // 16 real channels); a tap issues lo*hi + hi*lo + hi*hi per row block, as gconv_kernel<..., SPLIT> does.
+// Measured history (combined-role 512-thread form, transposed-tile form, spread requests, ...): docs/ENGINEERING_LOG.md round 5.
 #include "gconv.h"
 #include "gconv_dev.h"
 #include <stdio.h>
 #include <string.h>
 
-// timing ablations (WRONG RESULTS; tools/r05 only): 1 = no patch loads, 2 = no A loads, 4 = no patch LDS writes, 8 = no fragment
-// reads / MFMAs, 16 = no epilogue, 32 = no A LDS writes, 64 = epilogue without its global stores, 128 = epilogue stores of
-// a dummy register instead of the LDS-transposed data
-#ifndef PL_SPREAD
-#define PL_SPREAD 0        // patch requests spread over the first four taps of an item instead of its first two (A/B)
-#endif
+// timing ablations (WRONG RESULTS; tools/r05 only): 1 = no patch loads, 2 = no A loads, 4 = no patch LDS writes, 16 = no
+// epilogue, 32 = no A LDS writes, 64 = epilogue without its global stores, 128 = epilogue stores of a dummy register instead
+// of the LDS-transposed data
 #ifndef PL_ABL
 #define PL_ABL 0
 #endif
@@ -44,13 +46,12 @@ typedef unsigned int pl_u32x4_t __attribute__((ext_vector_type(4)));
 
 // Wide-store epilogue of one 32-row block (mi) of a wave's 64 x 32 tile: the accumulator fragment (lane = pixel, 16 rows per
 // lane) is transposed through a WAVE-PRIVATE LDS region and leaves as 16-byte pieces (8 bf16 / 4 f32 pixels of one row) - 4 (bf16)
-// or 8 (f32) store instructions per block instead of 16 two- / four-byte ones.  The region is this wave's own 1 KB chunks of the
-// A-ring slot that is free between the barrier that ends a tile and the wave's next write into that slot (PL_WRITE_A touches
-// exactly the same bytes), so no barrier is needed: chunk c of the wave = `wreg + c * PL_SLOT_TAP`.
+// or 8 (f32) store instructions per block instead of 16 two- / four-byte ones.  The region is two `cst`-byte chunks at `wreg`, private
+// to the wave (no barrier).
 template <bool F32O>
 __device__ __forceinline__ void pl_store_wide(const GcParams& p, const GcPhase& ph, const f32x16_t a, int mi, int m0, int mrel,
                                               int lane, int wn, int u0, int v0, int n, int tw_shift, unsigned char* wreg,
-                                              const float* bias_l, float osc, float slope) {
+                                              int cst, const float* bias_l, float osc, float slope) {
     const int l31 = lane & 31, lhi = lane >> 5;
     const int mbase = m0 + mrel;
     float v[16];
@@ -66,7 +67,7 @@ __device__ __forceinline__ void pl_store_wide(const GcParams& p, const GcPhase& 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ml = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            *(bf16_t*)(wreg + (ml >> 4) * PL_SLOT_TAP + (ml & 15) * 64 + l31 * 2) = f2bf(v[r]);
+            *(bf16_t*)(wreg + (ml >> 4) * cst + (ml & 15) * 64 + l31 * 2) = f2bf(v[r]);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): this wave's LDS writes have landed
 #pragma unroll
@@ -75,7 +76,7 @@ __device__ __forceinline__ void pl_store_wide(const GcParams& p, const GcPhase& 
             const int row = q >> 2, ptl = wn * 32 + (q & 3) * 8;
             const int ty = ptl >> tw_shift, tx = ptl & ((1 << tw_shift) - 1);
             const int m = mbase + mi * 32 + row;
-            pl_u32x4_t d = *(const pl_u32x4_t*)(wreg + (row >> 4) * PL_SLOT_TAP + (row & 15) * 64 + (q & 3) * 16);
+            pl_u32x4_t d = *(const pl_u32x4_t*)(wreg + (row >> 4) * cst + (row & 15) * 64 + (q & 3) * 16);
             if constexpr ((PL_ABL & 128) != 0) { d[0] = (unsigned)q; d[1] = d[2] = d[3] = 0u; }
             if (!(PL_ABL & 64) && m < p.K && u0 + ty < ph.OHt && v0 + tx < ph.OWt)
                 *(pl_u32x4_t*)((bf16_t*)p.out + ((size_t)n * p.K + m) * plane + (size_t)(u0 + ty) * p.OWf + (v0 + tx)) = d;
@@ -88,7 +89,7 @@ __device__ __forceinline__ void pl_store_wide(const GcParams& p, const GcPhase& 
             for (int r8 = 0; r8 < 8; ++r8) {
                 const int r = h * 8 + r8;
                 const int ml = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi;           // row inside the half
-                *(float*)(wreg + (ml >> 3) * PL_SLOT_TAP + (ml & 7) * 128 + l31 * 4) = v[r];
+                *(float*)(wreg + (ml >> 3) * cst + (ml & 7) * 128 + l31 * 4) = v[r];
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
@@ -97,7 +98,7 @@ __device__ __forceinline__ void pl_store_wide(const GcParams& p, const GcPhase& 
                 const int row = q >> 3, ptl = wn * 32 + (q & 7) * 4;
                 const int ty = ptl >> tw_shift, tx = ptl & ((1 << tw_shift) - 1);
                 const int m = mbase + mi * 32 + h * 16 + row;
-                const pl_u32x4_t d = *(const pl_u32x4_t*)(wreg + (row >> 3) * PL_SLOT_TAP + (row & 7) * 128 + (q & 7) * 16);
+                const pl_u32x4_t d = *(const pl_u32x4_t*)(wreg + (row >> 3) * cst + (row & 7) * 128 + (q & 7) * 16);
                 if (!(PL_ABL & 64) && m < p.K && u0 + ty < ph.OHt && v0 + tx < ph.OWt)
                     *(pl_u32x4_t*)((float*)p.out + ((size_t)n * p.K + m) * plane + (size_t)(u0 + ty) * p.OWf + (v0 + tx)) = d;
             }
@@ -107,14 +108,17 @@ __device__ __forceinline__ void pl_store_wide(const GcParams& p, const GcPhase& 
 }
 
 template <int NT, int TG, bool SPLIT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void gconv_pl_kernel(const GcParams p) {
     static_assert(NT % TG == 0, "taps per group");
     constexpr int NG = NT / TG;
     constexpr int SLOT = TG * PL_SLOT_TAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x;
+    // 16 waves: 0-7 compute (LDS fragment reads, MFMAs, epilogue), 8-15 load (global requests, LDS writes of both operands).
+    // Each role has its own loop with the SAME barrier sequence; `tid` / `wave` below are role-local (0..511 / 0..7).
+    const bool loader = threadIdx.x >= 512;
+    const int tid = threadIdx.x & 511;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -129,6 +133,7 @@ void gconv_pl_kernel(const GcParams p) {
     unsigned char* aring = smem;                           // 2 x SLOT
     unsigned char* pbuf = smem + 2 * SLOT;                 // 2 x pbytes
     float* bias_l = (float*)(pbuf + 2 * pbytes);           // 128 floats: bias of this workgroup's row tile
+    unsigned char* epi_l = (unsigned char*)(bias_l + 128); // 8 x 2 KB: the compute waves' store-transposition regions
 
     // ---- work of this workgroup: pixel tiles [t_lo, t_hi) of row tile `mtile` ------------------------------------------
     int mtile, t_lo, t_hi;
@@ -160,7 +165,7 @@ void gconv_pl_kernel(const GcParams p) {
     const bool refl = p.bmode == PAD_REFLECT;
     const int tiles_xy = ph.tiles_x * ph.tiles_y;
     const bool hb = p.bias != nullptr;
-    if (tid < 128) bias_l[tid] = (hb && m0 + tid < p.K) ? p.bias[m0 + tid] : 0.f;
+    if (!loader && tid < 128) bias_l[tid] = (hb && m0 + tid < p.K) ? p.bias[m0 + tid] : 0.f;
     const float osc = p.oscale ? *p.oscale : 1.f;
     const float slope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LEAKY ? 0.2f : 1.f);
 
@@ -314,33 +319,33 @@ void gconv_pl_kernel(const GcParams p) {
             }                                                                                                      \
         }                                                                                                          \
     } while (0)
-    // tap t_ (the tt-th of its group): A operands from ring slot `as_`, B fragments (2 x 8 bytes per slice: planes 4 s + 2 lhi + {0, 1}) from `pc_`
-#define PL_TAP(as_, pc_, tt, t_)                                                                                   \
+    // fragment reads of tap t_ (the tt-th of its group) into a register set: A operands from ring slot `as_`, B fragments
+    // (2 x 8 bytes per slice: planes 4 s + 2 lhi + {0, 1}) from patch buffer `pc_`; PL_MFMAS: that tap's MFMAs
+#define PL_FRAGS(FA, FB, as_, pc_, tt, t_)                                                                         \
     do {                                                                                                           \
-        if constexpr (!(PL_ABL & 8)) {                                                                             \
-            const unsigned char* bp_ = (pc_) + (unsigned)(lhi * 2) * plb + (bpix0 + toffs[t_]) * 8u;               \
-            const uint2 q00_ = *(const uint2*)(bp_), q01_ = *(const uint2*)(bp_ + plb);                            \
-            const uint2 q10_ = *(const uint2*)(bp_ + 4u * plb), q11_ = *(const uint2*)(bp_ + 5u * plb);            \
-            const pl_u32x4_t bq0_ = {q00_.x, q00_.y, q01_.x, q01_.y}, bq1_ = {q10_.x, q10_.y, q11_.x, q11_.y};     \
-            const bf16x8_t b0_ = __builtin_bit_cast(bf16x8_t, bq0_), b1_ = __builtin_bit_cast(bf16x8_t, bq1_);     \
-            const unsigned char* ab_ = (as_) + ((tt * 4 + wm * 2) * 2) * 1024 + lane * 16;                         \
-            const bf16x8_t a00_ = *(const bf16x8_t*)(ab_);                                                         \
-            const bf16x8_t a01_ = *(const bf16x8_t*)(ab_ + 1024);                                                  \
-            const bf16x8_t a10_ = *(const bf16x8_t*)(ab_ + 2048);                                                  \
-            const bf16x8_t a11_ = *(const bf16x8_t*)(ab_ + 3072);                                                  \
-            if constexpr (SPLIT) {                                                                                 \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01_, b0_, acc0, 0, 0, 0);                          \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11_, b0_, acc1, 0, 0, 0);                          \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00_, b1_, acc0, 0, 0, 0);                          \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10_, b1_, acc1, 0, 0, 0);                          \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00_, b0_, acc0, 0, 0, 0);                          \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10_, b0_, acc1, 0, 0, 0);                          \
-            } else {                                                                                               \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00_, b0_, acc0, 0, 0, 0);                          \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10_, b0_, acc1, 0, 0, 0);                          \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01_, b1_, acc0, 0, 0, 0);                          \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11_, b1_, acc1, 0, 0, 0);                          \
-            }                                                                                                      \
+        const unsigned char* bp_ = (pc_) + (unsigned)(lhi * 2) * plb + (bpix0 + toffs[t_]) * 8u;                   \
+        const uint2 q00_ = *(const uint2*)(bp_), q01_ = *(const uint2*)(bp_ + plb);                                \
+        const uint2 q10_ = *(const uint2*)(bp_ + 4u * plb), q11_ = *(const uint2*)(bp_ + 5u * plb);                \
+        const pl_u32x4_t bq0_ = {q00_.x, q00_.y, q01_.x, q01_.y}, bq1_ = {q10_.x, q10_.y, q11_.x, q11_.y};         \
+        FB[0] = __builtin_bit_cast(bf16x8_t, bq0_); FB[1] = __builtin_bit_cast(bf16x8_t, bq1_);                    \
+        const unsigned char* ab_ = (as_) + (((tt) * 4 + wm * 2) * 2) * 1024 + lane * 16;                           \
+        FA[0] = *(const bf16x8_t*)(ab_);        FA[1] = *(const bf16x8_t*)(ab_ + 1024);                            \
+        FA[2] = *(const bf16x8_t*)(ab_ + 2048); FA[3] = *(const bf16x8_t*)(ab_ + 3072);                            \
+    } while (0)
+#define PL_MFMAS(FA, FB)                                                                                           \
+    do {                                                                                                           \
+        if constexpr (SPLIT) {                                                                                     \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1], FB[0], acc0, 0, 0, 0);                           \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[3], FB[0], acc1, 0, 0, 0);                           \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0], FB[1], acc0, 0, 0, 0);                           \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2], FB[1], acc1, 0, 0, 0);                           \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0], FB[0], acc0, 0, 0, 0);                           \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2], FB[0], acc1, 0, 0, 0);                           \
+        } else {                                                                                                   \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0], FB[0], acc0, 0, 0, 0);                           \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2], FB[0], acc1, 0, 0, 0);                           \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1], FB[1], acc0, 0, 0, 0);                           \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[3], FB[1], acc1, 0, 0, 0);                           \
         }                                                                                                          \
     } while (0)
     // bias / activation / store of this wave's 64 rows x 32 pixels of tile `t_`; the accumulators are cleared for the next tile
@@ -354,77 +359,84 @@ void gconv_pl_kernel(const GcParams p) {
         asm volatile("" : "+v"(mrel_));                                                                            \
         if constexpr ((PL_ABL & 16) != 0) { if (acc0[0] == 12345.678f) ((float*)p.out)[0] = acc1[1]; }             \
         else {                                                                                                     \
-            /* (the ring slot the NEXT write goes to is free from the last barrier until this wave's own PL_WRITE_A) */ \
-            unsigned char* wreg_ = aring + ((gcnt + 1u) & 1u) * SLOT + wave * 1024;                                \
+            unsigned char* wreg_ = epi_l + wave * 2048;                                                            \
             const int tws_ = p.TW == 32 ? 5 : 4;                                                                   \
             if (p.out_f32) {                                                                                       \
-                pl_store_wide<true>(p, ph, acc0, 0, m0, mrel_, lane, wn, ty_ * p.TH, tx_ * p.TW, tn_, tws_, wreg_, bias_l, osc, slope); \
-                pl_store_wide<true>(p, ph, acc1, 1, m0, mrel_, lane, wn, ty_ * p.TH, tx_ * p.TW, tn_, tws_, wreg_, bias_l, osc, slope); \
+                pl_store_wide<true>(p, ph, acc0, 0, m0, mrel_, lane, wn, ty_ * p.TH, tx_ * p.TW, tn_, tws_, wreg_, 1024, bias_l, osc, slope); \
+                pl_store_wide<true>(p, ph, acc1, 1, m0, mrel_, lane, wn, ty_ * p.TH, tx_ * p.TW, tn_, tws_, wreg_, 1024, bias_l, osc, slope); \
             } else {                                                                                               \
-                pl_store_wide<false>(p, ph, acc0, 0, m0, mrel_, lane, wn, ty_ * p.TH, tx_ * p.TW, tn_, tws_, wreg_, bias_l, osc, slope); \
-                pl_store_wide<false>(p, ph, acc1, 1, m0, mrel_, lane, wn, ty_ * p.TH, tx_ * p.TW, tn_, tws_, wreg_, bias_l, osc, slope); \
+                pl_store_wide<false>(p, ph, acc0, 0, m0, mrel_, lane, wn, ty_ * p.TH, tx_ * p.TW, tn_, tws_, wreg_, 1024, bias_l, osc, slope); \
+                pl_store_wide<false>(p, ph, acc1, 1, m0, mrel_, lane, wn, ty_ * p.TH, tx_ * p.TW, tn_, tws_, wreg_, 1024, bias_l, osc, slope); \
             }                                                                                                      \
         }                                                                                                          \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }                           \
     } while (0)
 
-    // ---- prologue: item 0 staged synchronously -----------------------------------------------------------------------------
+    if (loader) {
+        // ================= loader role: both operands, one tap group / one item ahead of the compute waves =================
+        int tile = t_lo, chunk = 0;
+        PL_ISSUE_A(0, 0, 0);
+        PL_P_ADDR(tile);
+        PL_P_LOAD(0, 0); PL_P_LOAD(1, 0); PL_P_LOAD(2, 0); PL_P_LOAD(3, 0);
+        PL_WRITE_A(0, 0);
+        PL_P_WRITE(0, 0, 0); PL_P_WRITE(0, 0, 1);
+        PL_ISSUE_A(1 % NSET, 0, 1);
+        __syncthreads();
+        unsigned gcnt = 0;
+        int pb = 0;
+        for (;;) {
+            int ntile = tile, nchunk = chunk + 1;
+            if (nchunk == nch) { nchunk = 0; ntile = tile + 1; }
+            const bool last = ntile >= t_hi;
+            const int ptile = last ? tile : ntile, pchunk = last ? chunk : nchunk;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 2 < NG) PL_ISSUE_A((g + 2) % NSET, chunk, g + 2); else PL_ISSUE_A((g + 2) % NSET, pchunk, g + 2 - NG);
+                if (g == 0) {
+                    PL_P_ADDR(ptile);
+                    PL_P_LOAD(0, pchunk); PL_P_LOAD(1, pchunk); PL_P_LOAD(2, pchunk); PL_P_LOAD(3, pchunk);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                PL_WRITE_A((g + 1) % NSET, (gcnt + 1u) & 1u);
+                if (g == NG - 1) { PL_P_WRITE(pb ^ 1, pchunk, 0); PL_P_WRITE(pb ^ 1, pchunk, 1); }
+                __syncthreads();
+                ++gcnt;
+            }
+            pb ^= 1;
+            if (last) break;
+            tile = ntile; chunk = nchunk;
+        }
+        return;
+    }
+    // ===================== compute role: fragment reads + MFMAs, epilogue of the previous tile in the first group =====================
     int tile = t_lo, chunk = 0;
-    PL_ISSUE_A(0, 0, 0);
-    PL_P_ADDR(tile);
-    PL_P_LOAD(0, 0); PL_P_LOAD(1, 0); PL_P_LOAD(2, 0); PL_P_LOAD(3, 0);
-    PL_WRITE_A(0, 0);
-    PL_P_WRITE(0, 0, 0); PL_P_WRITE(0, 0, 1);
-    PL_ISSUE_A(1 % NSET, 0, 1);                            // group 1 of item 0: in flight into the loop
-    __syncthreads();
-
-    unsigned gcnt = 0;                                     // tap groups done: ring slot of the current group = gcnt & 1
-    int pb = 0;                                            // patch buffer of the current item
-    int epi_tile = -1;                                     // finished tile whose epilogue is still owed
+    __syncthreads();                                       // (the loader's prologue)
+    unsigned gcnt = 0;
+    int pb = 0;
+    int epi_tile = -1;
     for (;;) {
         int ntile = tile, nchunk = chunk + 1;
         if (nchunk == nch) { nchunk = 0; ntile = tile + 1; }
         const bool last = ntile >= t_hi;
-        const int ptile = last ? tile : ntile, pchunk = last ? chunk : nchunk;     // last item: harmless re-load of itself
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            // group g + 2 of the item stream -> register set (g + 2) % NSET (group g + 1's set was filled one group ago)
-            if (g + 2 < NG) PL_ISSUE_A((g + 2) % NSET, chunk, g + 2); else PL_ISSUE_A((g + 2) % NSET, pchunk, g + 2 - NG);
-            if (g == 0) PL_P_ADDR(ptile);
-            // keep the requests HERE: the scheduler otherwise sinks each load to just above its first use
-            __builtin_amdgcn_sched_barrier(0);
             if (g == 0 && epi_tile >= 0) {
-                // The previous tile's stores go out BEHIND this group's A requests: the wait for those (end of this group)
-                // leaves the stores in flight.  Issued ahead of the requests they sat in front of every load in the in-order
-                // return queue: 27 of 120 us on 60 -> 120 @256x256.
                 PL_EPILOGUE(epi_tile);
                 epi_tile = -1;
             }
-            // The patch requests of the next item go out BETWEEN the taps of the first group and its LDS writes between the
-            // taps of the last one: all eight waves leave a barrier together, and with the requests in one block ahead of the
-            // MFMAs the texture addresser, the matrix pipe and the LDS store path took turns (timing ablations: every part of the
-            // loop cost its full stand-alone time).
+            // fragments of tap tt + 1 are read while the MFMAs of tap tt run (two register sets): with the reads of a tap
+            // directly ahead of its MFMAs every tap began with an LDS round trip (37 % of the wave cycles parked in waits)
+            {
+                const unsigned char* as_ = aring + (gcnt & 1u) * SLOT;
+                const unsigned char* pc_ = pbuf + pb * pbytes;
+                bf16x8_t fa[2][4], fb[2][2];
+                PL_FRAGS(fa[0], fb[0], as_, pc_, 0, g * TG);
 #pragma unroll
-            for (int tt = 0; tt < TG; ++tt) {
-                PL_TAP(aring + (gcnt & 1u) * SLOT, pbuf + pb * pbytes, tt, g * TG + tt);
-#if PL_SPREAD
-                // one lane-item (two loads) behind each of the item's first four taps
-                if (g * TG + tt < 4) {
-                    PL_P_LOAD(g * TG + tt, pchunk);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#else
-                if (g == 0 && tt < 2) {
-                    PL_P_LOAD(2 * tt, pchunk); PL_P_LOAD(2 * tt + 1, pchunk);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#endif
-                if (g == NG - 1 && tt < 2) {
-                    PL_P_WRITE(pb ^ 1, pchunk, tt);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int tt = 0; tt < TG; ++tt) {
+                    if (tt + 1 < TG) PL_FRAGS(fa[(tt + 1) & 1], fb[(tt + 1) & 1], as_, pc_, tt + 1, g * TG + tt + 1);
+                    PL_MFMAS(fa[tt & 1], fb[tt & 1]);
                 }
             }
-            PL_WRITE_A((g + 1) % NSET, (gcnt + 1u) & 1u);
             __syncthreads();
             ++gcnt;
         }
@@ -434,8 +446,9 @@ void gconv_pl_kernel(const GcParams p) {
         tile = ntile; chunk = nchunk;
     }
     if (epi_tile >= 0) PL_EPILOGUE(epi_tile);
+#undef PL_MFMAS
+#undef PL_FRAGS
 #undef PL_EPILOGUE
-#undef PL_TAP
 #undef PL_P_WRITE
 #undef PL_P_LOAD
 #undef PL_P_ADDR
@@ -478,12 +491,13 @@ int launch_gconv_pl(GcParams& p, const float* w, const float* w_scale, long long
     const int NGR = (acol + PW + 7) / 8;
     if (PH * NGR > 128) return HIFIC_ERR_UNSUPPORTED;             // (patch row, aligned group) units: two per lane
     const size_t pbytes = (size_t)(4 * RH * RW + 1) * 64;         // 16 channel-pair planes of 4 RH RW + 1 dwords
+    // LDS: two ring slots + two patch buffers + bias + the eight compute waves' 2 KB store regions (160 KB per CU)
     int tg = nt == 9 ? 3 : (gc_env_int("HIFIC_PL_TG", 4) == 2 ? 2 : 4);
-    if (2 * (size_t)tg * PL_SLOT_TAP + 2 * pbytes + 512 > (size_t)150 * 1024) {
+    if (2 * (size_t)tg * PL_SLOT_TAP + 2 * pbytes + 512 + 16384 > (size_t)160 * 1024) {
         if (nt == 16) tg = 2;
-        if (2 * (size_t)tg * PL_SLOT_TAP + 2 * pbytes + 512 > (size_t)150 * 1024) return HIFIC_ERR_UNSUPPORTED;
+        if (2 * (size_t)tg * PL_SLOT_TAP + 2 * pbytes + 512 + 16384 > (size_t)160 * 1024) return HIFIC_ERR_UNSUPPORTED;
     }
-    const size_t lds = 2 * (size_t)tg * PL_SLOT_TAP + 2 * pbytes + 512;
+    const size_t lds = 2 * (size_t)tg * PL_SLOT_TAP + 2 * pbytes + 512 + 16384;
 
     p.TH = TH; p.TW = TW; p.NI = 1; p.tiles_n = p.N;
     p.Kpad = cdiv(p.K, 128) * 128;
@@ -520,7 +534,7 @@ int launch_gconv_pl(GcParams& p, const float* w, const float* w_scale, long long
 #define PL_LAUNCH(NT_, TG_, SP_)                                                                      \
     do {                                                                                              \
         gc_set_max_lds((const void*)gconv_pl_kernel<NT_, TG_, SP_>, (int)lds);                        \
-        hipLaunchKernelGGL((gconv_pl_kernel<NT_, TG_, SP_>), grid, dim3(512), lds, st, p);            \
+        hipLaunchKernelGGL((gconv_pl_kernel<NT_, TG_, SP_>), grid, dim3(1024), lds, st, p);           \
     } while (0)
     if (nt == 9) { if (p.split) PL_LAUNCH(9, 3, true); else PL_LAUNCH(9, 3, false); }
     else if (tg == 4) { if (p.split) PL_LAUNCH(16, 4, true); else PL_LAUNCH(16, 4, false); }
