@@ -1042,6 +1042,12 @@ static int launch_gconv_t(GcParams& p, const float* w, const float* w_scale, lon
     if constexpr (std::is_same<T, float>::value) {
         return launch_gconv_tb<float, 16>(p, w, w_scale, sm, sc, sr, ss, ws, st);
     } else {
+        {   // weight-resident persistent kernel for the few-channel layers on big planes (gconv_wr.hip)
+            const GcParams saved = p;
+            const int rcw = launch_gconv_wr(p, w, w_scale, sm, sc, sr, ss, ws, st);
+            if (rcw != HIFIC_ERR_UNSUPPORTED) return rcw;
+            p = saved;
+        }
         {   // pipelined persistent kernel for the stride-2 layers (gconv_pl.hip); it leaves the plan untouched when it declines
             const GcParams saved = p;
             const int rcp = launch_gconv_pl(p, w, w_scale, sm, sc, sr, ss, ws, st);
@@ -1147,8 +1153,7 @@ static int launch_gconv_fewc(GcParams& p, const float* w, const float* w_scale, 
 // ---------------------------------------------------------------------------------------------------
 template <typename TO>
 __global__ void vrow_shift_add_kernel(const float* __restrict__ P, const float* __restrict__ bias, TO* __restrict__ out,
-                                      unsigned N, int K, int OH, int OW, int nd, int act) {
-    const int PW = OW + nd - 1;
+                                      unsigned N, int K, int OH, int OW, int nd, int PW /* row pitch of P */, int act) {
     const unsigned total = N * (unsigned)(K * OH * OW);
     const float slope = act == ACT_RELU ? 0.f : (act == ACT_LEAKY ? 0.2f : 1.f);
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -1192,7 +1197,9 @@ static int launch_gconv_fewk(GcParams& p, const float* w, const float* w_scale, 
     for (int a = 0; a < nx; ++a) for (int b = a + 1; b < nx; ++b)
         if (dxv[b] < dxv[a]) { int t1 = dxv[a]; dxv[a] = dxv[b]; dxv[b] = t1; t1 = ss_[a]; ss_[a] = ss_[b]; ss_[b] = t1; }
     for (int j = 1; j < nx; ++j) if (dxv[j] - dxv[j - 1] != 1) return HIFIC_ERR_UNSUPPORTED;
-    const int PWd = p.OWf + nx - 1;
+    // (row pitch of P rounded up to 16 bytes: the weight-resident kernel then writes it with 16-byte stores; the extra columns
+    //  are computed like any other and never read)
+    const int PWd = (p.OWf + nx - 1 + 3) & ~3;
     const size_t pe = (size_t)p.N * p.K * nx * p.OHf * PWd;
     const size_t mark = ws.off;
     float* P = (float*)ws.take(pe * sizeof(float));
@@ -1216,9 +1223,9 @@ static int launch_gconv_fewk(GcParams& p, const float* w, const float* w_scale, 
     const size_t total = (size_t)p.N * p.K * p.OHf * p.OWf;
     int gx = (int)((total + 255) / 256); if (gx > 32768) gx = 32768;
     if (p.out_f32) hipLaunchKernelGGL(vrow_shift_add_kernel<float>, dim3(gx), dim3(256), 0, st, P, p.bias, (float*)p.out, (unsigned)p.N,
-                                      p.K, p.OHf, p.OWf, nx, p.act);
+                                      p.K, p.OHf, p.OWf, nx, PWd, p.act);
     else hipLaunchKernelGGL(vrow_shift_add_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, P, p.bias, (bf16_t*)p.out, (unsigned)p.N,
-                            p.K, p.OHf, p.OWf, nx, p.act);
+                            p.K, p.OHf, p.OWf, nx, PWd, p.act);
     return hific_launch_status();
 }
 

@@ -25,6 +25,9 @@ int gc_pack_weights_bf16(GcParams& p, long long wp_elems, const float* w, const 
 // Pipelined stride-2 forward-type kernel (gconv_pl.hip); HIFIC_ERR_UNSUPPORTED when the plan does not qualify
 int launch_gconv_pl(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc, long long sr, long long ss,
                     WsAlloc& ws, hipStream_t st);
+// Weight-resident persistent kernel for the few-channel layers on big planes (gconv_wr.hip); same contract
+int launch_gconv_wr(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc, long long sr, long long ss,
+                    WsAlloc& ws, hipStream_t st);
 
 // Source index of packed element (row m, reduction channel c, tap (r, s)).  With virtual channels (csplit) the packed
 // channel cc = c * csplit + j stands for channel c at kernel column vcol_s[j]; with virtual rows (msplit) the packed row

@@ -364,3 +364,74 @@ __device__ __forceinline__ void gc_epilogue_wide(const GcParams& p, const GcPhas
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wide-store epilogue of the persistent kernels (gconv_pl_kernel, gconv_wr_kernel)
+// ---------------------------------------------------------------------------------------------------
+#ifndef PL_ABL
+#define PL_ABL 0           // timing ablations of gconv_pl.hip (bits 64 / 128 act here)
+#endif
+typedef unsigned int pl_u32x4_t __attribute__((ext_vector_type(4)));
+
+// Wide-store epilogue of one 32-row block (mi) of a wave's 64 x 32 tile: the accumulator fragment (lane = pixel, 16 rows per
+// lane) is transposed through a WAVE-PRIVATE LDS region and leaves as 16-byte pieces (8 bf16 / 4 f32 pixels of one row) - 4 (bf16)
+// or 8 (f32) store instructions per block instead of 16 two- / four-byte ones.  The region is two `cst`-byte chunks at `wreg`, private
+// to the wave (no barrier).
+template <bool F32O>
+__device__ __forceinline__ void pl_store_wide(const GcParams& p, const GcPhase& ph, const f32x16_t a, int mi, int m0, int mrel,
+                                              int lane, int wn, int u0, int v0, int n, int tw_shift, unsigned char* wreg,
+                                              int cst, const float* bias_l, float osc, float slope) {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int mbase = m0 + mrel;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ml = mrel + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;     // row inside the 128-row tile: bias from LDS (no
+        const float x = a[r] * osc + bias_l[ml];                              // vector-memory load between the prefetch requests)
+        v[r] = x > 0.f ? x : x * slope;
+    }
+    const size_t plane = (size_t)p.OHf * p.OWf;
+    if constexpr (!F32O) {
+        // [32 rows][64 bytes] = 2 chunks of 16 rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            *(bf16_t*)(wreg + (ml >> 4) * cst + (ml & 15) * 64 + l31 * 2) = f2bf(v[r]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): this wave's LDS writes have landed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = lane + 64 * i;                    // piece: row q >> 2, pixels (q & 3) * 8 .. + 7 of the wave's 32
+            const int row = q >> 2, ptl = wn * 32 + (q & 3) * 8;
+            const int ty = ptl >> tw_shift, tx = ptl & ((1 << tw_shift) - 1);
+            const int m = mbase + mi * 32 + row;
+            pl_u32x4_t d = *(const pl_u32x4_t*)(wreg + (row >> 4) * cst + (row & 15) * 64 + (q & 3) * 16);
+            if constexpr ((PL_ABL & 128) != 0) { d[0] = (unsigned)q; d[1] = d[2] = d[3] = 0u; }
+            if (!(PL_ABL & 64) && m < p.K && u0 + ty < ph.OHt && v0 + tx < ph.OWt)
+                *(pl_u32x4_t*)((bf16_t*)p.out + ((size_t)n * p.K + m) * plane + (size_t)(u0 + ty) * p.OWf + (v0 + tx)) = d;
+        }
+    } else {
+        // two halves of 16 rows: [16 rows][128 bytes] = 2 chunks of 8 rows (accumulator registers 8h .. 8h+7 hold rows 16h .. 16h+15)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = h * 8 + r8;
+                const int ml = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi;           // row inside the half
+                *(float*)(wreg + (ml >> 3) * cst + (ml & 7) * 128 + l31 * 4) = v[r];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = lane + 64 * i;                // piece: row q >> 3 of the half, pixels (q & 7) * 4 .. + 3
+                const int row = q >> 3, ptl = wn * 32 + (q & 7) * 4;
+                const int ty = ptl >> tw_shift, tx = ptl & ((1 << tw_shift) - 1);
+                const int m = mbase + mi * 32 + h * 16 + row;
+                const pl_u32x4_t d = *(const pl_u32x4_t*)(wreg + (row >> 3) * cst + (row & 7) * 128 + (q & 7) * 16);
+                if (!(PL_ABL & 64) && m < p.K && u0 + ty < ph.OHt && v0 + tx < ph.OWt)
+                    *(pl_u32x4_t*)((float*)p.out + ((size_t)n * p.K + m) * plane + (size_t)(u0 + ty) * p.OWf + (v0 + tx)) = d;
+            }
+            if (h == 0) __builtin_amdgcn_s_waitcnt(0xc07f); // the reads of half 0 are done before half 1 overwrites the region
+        }
+    }
+}
+

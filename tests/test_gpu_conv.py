@@ -58,6 +58,14 @@ CONV_CASES = {
     "PL_4x4_wide_reflect":  (3, 40, 20, 64, 100, 4, 2, (1, 1, 1, 1), "reflect"),
     "PL_3x3_sym_reflect":   (1, 100, 24, 64, 130, 3, 2, (1, 1, 1, 1), "reflect"),
     "PL_3x3_zero_many":     (9, 64, 32, 64, 64, 3, 2, (1, 1, 0, 0), "zeros"),
+    # weight-resident persistent kernel of the few-channel layers on big planes (gconv_wr_kernel: <= 64 channels on both sides,
+    # >= 1024 tiles of 256 pixels): the first Encoder layer's split form (9 channels, 7x7) with partial tiles in both
+    # directions, the 60 -> 3 output layer (virtual-row form forward, virtual-channel form backward), the Discriminator's
+    # first layer (stride 2, 15 channels), a plain 3x3 with zero padding and channel / row tails
+    "WR_7x7_c9":            (4, 9, 250, 262, 60, 7, 1, (3, 3, 3, 3), "reflect"),
+    "WR_7x7_to3":           (4, 60, 256, 256, 3, 7, 1, (3, 3, 3, 3), "reflect"),
+    "WR_4x4s2_c15":         (5, 15, 520, 400, 64, 4, 2, (1, 1, 1, 1), "reflect"),
+    "WR_3x3_c24_zero":      (3, 24, 300, 310, 50, 3, 1, (1, 1, 1, 1), "zeros"),
     "S1_rect_reflect":      (2, 70, 12, 32, 100, 3, 1, (1, 1, 1, 1), "reflect"),
     "S1_wide_zero":         (1, 130, 20, 48, 40, 3, 1, (1, 1, 1, 1), "zeros"),
 }
@@ -335,6 +343,63 @@ def test_strided_weight_gradients_take_their_kernels(hific, dev):
     for name in ("I16_3x3s1_c12", "I16_4x4s2_c16_zero", "odd_s2"):
         assert "wgrad_im2col_kernel<bf16>" in conv_wgrad(name), name
     assert "wgrad_s2_kernel" not in conv_wgrad("odd_s2")
+    hific.set_compute_dtype(torch.float32)
+
+
+def test_few_channel_layers_take_the_weight_resident_kernel(hific, dev):
+    """Pins the dispatch of the few-channel big-plane layers to gconv_wr_kernel (forward and, where the transposed problem
+    qualifies too, the data gradient), checks what it must decline (small planes, many channels), and that it agrees with the
+    generic kernels (HIFIC_WR=0) to bf16 output rounding."""
+    import os
+    from hific_amd import ops, lib
+    hific.set_compute_dtype(torch.bfloat16)
+
+    def run(name, with_out=False, bwd=False):
+        N, C, H, W, K, R, stride, pads, mode = CONV_CASES[name]
+        x = _rnd((N, C, H, W), 1, torch.bfloat16).to(dev).bfloat16().requires_grad_(bwd)
+        w = (_rnd((K, C, R, R), 2, torch.bfloat16) * 0.05).to(dev)
+        b = _rnd((K,), 3, torch.float32).to(dev)
+        pm = lib.PAD_REFLECT if mode == "reflect" else lib.PAD_ZERO
+        out = {}
+        def go():
+            with torch.set_grad_enabled(bwd):
+                y = ops.conv2d(x, w, b, stride=stride, pads=pads, pad_mode=pm, act=None if bwd else "leaky_relu")
+            if bwd:
+                y.backward(torch.ones_like(y))
+                out["y"] = x.grad
+            else:
+                out["y"] = y
+            torch.cuda.synchronize()
+        kinds = _kinds_of(go)
+        return (kinds, out["y"]) if with_out else kinds
+
+    for name in ("WR_7x7_c9", "WR_7x7_to3", "WR_4x4s2_c15", "WR_3x3_c24_zero"):
+        kinds = run(name)
+        assert any(k.startswith("gconv_wr_kernel") for k in kinds), (name, kinds)
+    kinds = run("WR_3x3_c24_zero", bwd=True)                          # a data gradient that is a few-channel problem itself
+    assert any(k.startswith("gconv_wr_kernel") for k in kinds), kinds
+    for name in ("G9_7x7_to3", "D1_4x4s2", "E2_3x3s2_asym", "R_3x3_960"):
+        kinds = run(name)
+        assert not any(k.startswith("gconv_wr_kernel") for k in kinds), (name, kinds)
+    was = os.environ.get("HIFIC_WR")
+    try:
+        for name, bwd in (("WR_7x7_c9", False), ("WR_7x7_to3", False), ("WR_4x4s2_c15", False),
+                          ("WR_3x3_c24_zero", True)):
+            _, y1 = run(name, with_out=True, bwd=bwd)
+            os.environ["HIFIC_WR"] = "0"
+            lib.call("hific_env_refresh"); ops.pack_cache.clear()
+            kinds0, y0 = run(name, with_out=True, bwd=bwd)
+            assert not any(k.startswith("gconv_wr_kernel") for k in kinds0)
+            os.environ.pop("HIFIC_WR")
+            lib.call("hific_env_refresh"); ops.pack_cache.clear()
+            scale = y0.float().abs().max().item()
+            assert (y1.float() - y0.float()).abs().max().item() <= 2.0 ** -7 * scale, (name, bwd)
+    finally:
+        if was is None:
+            os.environ.pop("HIFIC_WR", None)
+        else:
+            os.environ["HIFIC_WR"] = was
+        lib.call("hific_env_refresh"); ops.pack_cache.clear()
     hific.set_compute_dtype(torch.float32)
 
 
