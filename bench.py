@@ -53,6 +53,8 @@ GFLOP_PER_IMAGE = {
 }
 GMAC_G_TURN, GMAC_D_TURN = 161.2, 62.8      # per image of the G-turn / D-turn batch (D weight-gradient quirk included)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = MFMA_PEAK_TFLOPS["bf16"]
+PEAK_HBM_GBPS = 8000.0                                  # HBM3E, same guide
 
 
 def parse():
@@ -277,7 +279,7 @@ def timed(step, steps, warmup, fence):
 def profile_kernels(step, nsteps):
     """HIP-event pairs around every GEMM-class launch of `nsteps` further steps -> per kernel function totals."""
     from hific_amd import lib, ops
-    MAXK = 32
+    MAXK = 48
     # Kernel durations are taken with everything on ONE stream: in the timed headline the weight gradients run on a side
     # stream (ops._SideLaunch) concurrently with the data-gradient chain, which would charge each kernel for the time it
     # shares the chip with another one; likewise the loss branch / Discriminator branch streams of model.py.  (Same setting in
@@ -294,6 +296,8 @@ def profile_kernels(step, nsteps):
         ops.set_branch_streams(branch_was)
     ms = (ctypes.c_double * MAXK)(); fl = (ctypes.c_double * MAXK)(); cnt = (ctypes.c_int * MAXK)()
     names = ctypes.create_string_buffer(MAXK * 64)
+    by = (ctypes.c_double * MAXK)()
+    lib.raw("hific_prof_bytes")(MAXK, by)
     nk = lib.raw("hific_prof_end")(MAXK, ms, fl, cnt, names)
     if nk < 0:
         raise RuntimeError(f"hific_prof_end failed ({nk})")
@@ -304,6 +308,14 @@ def profile_kernels(step, nsteps):
             out[nm] = {"launches_per_step": cnt[k] / nsteps, "ms_per_step": ms[k] / nsteps,
                        "avg_launch_us": ms[k] * 1e3 / cnt[k], "gflop_per_launch": fl[k] / cnt[k] / 1e9,
                        "tflops": fl[k] / (ms[k] * 1e-3) / 1e12 if ms[k] > 0 else 0.0}
+            # Kernel functions whose launches sit below the machine balance (2500 TFLOP/s / 8 TB/s = 312 FLOP per byte of
+            # operands read once + result written once) are priced against the HBM roofline: the few-channel layers on
+            # 256 x 256 planes, the first / last convolutions' weight gradients.
+            if by[k] > 0 and ms[k] > 0 and fl[k] / by[k] < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9):
+                gbps = by[k] / (ms[k] * 1e-3) / 1e9
+                out[nm]["hbm_bound"] = {"achieved_GBps": gbps, "peak_GBps": PEAK_HBM_GBPS, "frac": gbps / PEAK_HBM_GBPS,
+                                        "algorithmic_MB_per_launch": by[k] / cnt[k] / 1e6,
+                                        "flop_per_byte": fl[k] / by[k]}
     return out
 
 
@@ -848,7 +860,8 @@ def main():
             "frac": round(d["tflops"] / peak, 4), "avg_launch_us": round(d["avg_launch_us"], 2),
             "algorithmic_gflop_per_launch": round(d["gflop_per_launch"], 3),
             "launches_per_step": d["launches_per_step"], "traffic": None,
-            "per_kernel": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in
+            "per_kernel": {k: {kk: ({a: round(b, 3) for a, b in vv.items()} if isinstance(vv, dict) else round(vv, 3))
+                                   for kk, vv in v.items()} for k, v in
                            sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "gemm_class_ms_per_step": round(sum(v["ms_per_step"] for v in prof.values()), 3),
         }

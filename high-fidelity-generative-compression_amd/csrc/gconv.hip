@@ -468,7 +468,7 @@ __global__ void reflect_extend_rows_kernel(const bf16_t* __restrict__ dy, bf16_t
 // kernel kind, with the algorithmic FLOPs of each launch.  Used by bench.py for the live roofline figure.
 // ---------------------------------------------------------------------------------------------------
 #define PROF_MAX 16384
-#define PROF_MAXKINDS 32
+#define PROF_MAXKINDS 48
 #define PROF_NAMELEN 64
 // kinds are kernel functions, registered by name on first use (the table only grows while profiling is on)
 static bool g_prof_on = false;
@@ -479,6 +479,7 @@ static hipEvent_t g_prof_ev[PROF_MAX][2];
 static bool g_prof_ev_made[PROF_MAX];
 static int g_prof_kind[PROF_MAX];
 static double g_prof_flops[PROF_MAX];
+static double g_prof_bytes[PROF_MAX];    // algorithmic HBM bytes of the launch (operands read once + result written once); 0 = not given
 static char g_prof_tag[PROF_MAX][112];     // launch shape, printed per launch when HIFIC_PROF_DUMP=1
 
 static int prof_open(const char* kname, double flops, hipStream_t st, const char* tag = "") {
@@ -494,7 +495,7 @@ static int prof_open(const char* kname, double flops, hipStream_t st, const char
     if (!g_prof_ev_made[i]) {
         hipEventCreate(&g_prof_ev[i][0]); hipEventCreate(&g_prof_ev[i][1]); g_prof_ev_made[i] = true;
     }
-    g_prof_kind[i] = k; g_prof_flops[i] = flops;
+    g_prof_kind[i] = k; g_prof_flops[i] = flops; g_prof_bytes[i] = 0.0;
     strncpy(g_prof_tag[i], tag, sizeof(g_prof_tag[i]) - 1); g_prof_tag[i][sizeof(g_prof_tag[i]) - 1] = 0;
     hipEventRecord(g_prof_ev[i][0], st);
     return i;
@@ -502,6 +503,20 @@ static int prof_open(const char* kname, double flops, hipStream_t st, const char
 static void prof_close(int i, hipStream_t st) { if (i >= 0) hipEventRecord(g_prof_ev[i][1], st); }
 int gc_prof_open(const char* kname, double flops, hipStream_t st, const char* tag) { return prof_open(kname, flops, st, tag); }
 void gc_prof_close(int slot, hipStream_t st) { prof_close(slot, st); }
+void gc_prof_bytes(int slot, double bytes) { if (slot >= 0) g_prof_bytes[slot] = bytes; }
+double gc_algo_bytes(const GcParams& p) {
+    int nt = 0;
+    for (int i = 0; i < p.nphase; ++i) nt += p.ph[i].ntaps;
+    return (double)p.N * p.C * p.IH * p.IW * (p.in_f32 ? 4.0 : 2.0) + (double)p.N * p.K * p.OHf * p.OWf * (p.out_f32 ? 4.0 : 2.0) +
+           (double)p.K * p.C * nt * 2.0;
+}
+// Algorithmic bytes per kernel function of the profile in progress (same order as hific_prof_end, which must be called AFTER this)
+extern "C" int hific_prof_bytes(int max_kinds, double* bytes) {
+    const int nk = g_prof_nk < max_kinds ? g_prof_nk : max_kinds;
+    for (int k = 0; k < nk; ++k) bytes[k] = 0;
+    for (int i = 0; i < g_prof_n; ++i) if (g_prof_kind[i] < nk) bytes[g_prof_kind[i]] += g_prof_bytes[i];
+    return nk;
+}
 
 extern "C" int hific_prof_begin(void) { g_prof_on = true; g_prof_n = 0; g_prof_nk = 0; return HIFIC_OK; }
 // Synchronises the recorded events.  Fills, for up to max_kinds kernel functions: total ms, total algorithmic FLOPs,
@@ -977,6 +992,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     else snprintf(kname, sizeof(kname), "gconv_kernel<%s,%d,%s>", std::is_same<T, float>::value ? "f32" : "bf16", BC,
                   bm == 128 ? "2,2,2,2" : (bm == 64 ? "2,2,1,2" : "1,4,1,1"));
     const int pslot = prof_open(kname, aflops, st, ptag);
+    gc_prof_bytes(pslot, gc_algo_bytes(p));
 #define GC_LAUNCH(WGM, WGN, WM, WN)                                                                      \
     do {                                                                                                 \
         void (*kfn)(const GcParams) = gconv_kernel<T, BC, WGM, WGN, WM, WN, 1, 1>;                       \

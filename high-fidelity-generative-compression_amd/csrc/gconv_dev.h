@@ -18,6 +18,8 @@ int gc_pack_weights_f32(GcParams& p, long long wp_elems, const float* w, const f
 void gc_set_max_lds(const void* fn, int bytes);             // dynamic-LDS opt-in per (device, kernel function), raised monotonically
 int gc_prof_open(const char* kname, double flops, hipStream_t st, const char* tag);
 void gc_prof_close(int slot, hipStream_t st);
+void gc_prof_bytes(int slot, double bytes);                 // algorithmic HBM bytes of the launch in `slot`
+double gc_algo_bytes(const GcParams& p);                    // input + output + weights of a forward-type launch, each once
 // Packs the weights for plan `p` (layout = gc_wp_index) into the caller's cache / the workspace as WsAlloc says, or - plan-only
 // call (ws.plan_out) - fills the pack job and sets *plan_only.  Sets p.wp.
 int gc_pack_weights_bf16(GcParams& p, long long wp_elems, const float* w, const float* w_scale, long long sm, long long sc,

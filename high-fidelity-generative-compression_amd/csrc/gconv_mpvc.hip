@@ -548,6 +548,7 @@ int gc_launch_vc(GcParams& p, const float* w, const float* w_scale, long long sm
     snprintf(ptag, sizeof(ptag), "gconv_vc K%d C%d N%d in%dx%d out%dx%d taps%d ist%d tile%dx%dx%d J%d grid%d", p.K, p.C, p.N, p.IH,
              p.IW, p.OHf, p.OWf, T, p.ist, p.NI, p.TH, p.TW, J, (int)grid.x);
     const int pslot = gc_prof_open("gconv_vc_kernel", p.aflops, st, ptag);
+    gc_prof_bytes(pslot, gc_algo_bytes(p));
     if (p.in_f32) {
         if (lds > 48 * 1024) gc_set_max_lds((const void*)gconv_vc_kernel<true>, (int)lds);
         hipLaunchKernelGGL(gconv_vc_kernel<true>, grid, dim3(256), lds, st, p);

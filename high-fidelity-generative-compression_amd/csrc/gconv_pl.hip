@@ -466,6 +466,7 @@ int launch_gconv_pl(GcParams& p, const float* w, const float* w_scale, long long
              p.IH, p.IW, p.OHf, p.OWf, nt, tg, TH, TW, p.pl_tpw, npg * mtiles, p.split ? " split" : "");
     snprintf(kname, sizeof(kname), "gconv_pl_kernel<%d,%d%s>", nt, tg, p.split ? ",split" : "");
     const int pslot = gc_prof_open(kname, p.aflops, st, ptag);
+    gc_prof_bytes(pslot, gc_algo_bytes(p));
     const dim3 grid(npg * mtiles);
 #define PL_LAUNCH(NT_, TG_, SP_)                                                                      \
     do {                                                                                              \

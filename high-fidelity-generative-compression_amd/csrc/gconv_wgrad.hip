@@ -943,6 +943,7 @@ static int launch_wgrad_t(WgParams& p, float* dw, long long sm, long long sc, lo
     }
     const int pslot = gc_prof_open(pipe ? "wgrad_pipe_kernel" : (std::is_same<T, float>::value ? "wgrad_kernel<f32>" : "wgrad_kernel<bf16>"),
                                 2.0 * p.M * p.C * p.ntaps * (double)p.N * p.AH * p.AW, st, ptag);
+    gc_prof_bytes(pslot, (double)p.N * p.M * p.AH * p.AW * (p.a_f32 ? 4.0 : 2.0) + (double)p.N * p.C * p.BH * p.BW * (p.b_f32 ? 4.0 : 2.0) + (double)p.M * p.C * p.ntaps * 4.0);
     if constexpr (std::is_same<T, bf16_t>::value) {
         int npatch_max = 0;
         for (int gi = 0; gi < p.ngroups; ++gi) {
@@ -1066,6 +1067,8 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     snprintf(ptag, sizeof(ptag), "wgrad_im2col K%d C%d N%d out%dx%d taps%d split%d", g.K, g.C, g.N, g.OH(), g.OW(), nt, p.nsplit);
     const int pslot = gc_prof_open(std::is_same<T, float>::value ? "wgrad_im2col_kernel<f32>" : "wgrad_im2col_kernel<bf16>",
                                 2.0 * g.K * g.C * nt * (double)g.N * g.OH() * g.OW(), st, ptag);
+    gc_prof_bytes(pslot, (double)g.N * g.K * g.OH() * g.OW() * (dy_f32 ? 4.0 : 2.0) + (double)g.N * g.C * g.H * g.W * (x_f32 ? 4.0 : 2.0) +
+                         (double)g.K * g.C * nt * 4.0);
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
     gc_prof_close(pslot, st);
     int rc = hific_launch_status();

@@ -654,6 +654,7 @@ int gc_launch_wgrad_s1(WgParams& p, float* dw, long long sm, long long sc, long 
     char ptag[112];
     snprintf(ptag, sizeof(ptag), "wgrad_s1 M%d C%d N%d a%dx%d split%d grid%d", p.M, p.C, p.N, p.AH, p.AW, p.nsplit, grid);
     const int pslot = gc_prof_open("wgrad_s1_kernel", 2.0 * p.M * p.C * 9 * (double)p.N * p.AH * p.AW, st, ptag);
+    gc_prof_bytes(pslot, (double)p.N * p.M * p.AH * p.AW * (p.a_f32 ? 4.0 : 2.0) + (double)p.N * p.C * p.BH * p.BW * (p.b_f32 ? 4.0 : 2.0) + (double)p.M * p.C * 9 * 4.0);
     size_t lds = 2 * (size_t)64 * 272 + 2 * (size_t)64 * (10 * 32 + 16) + 2 * (size_t)10 * 64 * 4;
     const size_t epi = (size_t)4 * 16 * (32 * 9 + 1) * sizeof(float);
     if (lds < epi) lds = epi;
@@ -718,6 +719,7 @@ int gc_launch_wgrad_s2(WgParams& p, float* dw, long long sm, long long sc, long 
     char ptag[112];
     snprintf(ptag, sizeof(ptag), "wgrad_s2 M%d C%d N%d a%dx%d taps%d split%d grid%d", p.M, p.C, p.N, p.AH, p.AW, p.ntaps, p.nsplit, grid);
     const int pslot = gc_prof_open("wgrad_s2_kernel", 2.0 * p.M * p.C * p.ntaps * (double)p.N * p.AH * p.AW, st, ptag);
+    gc_prof_bytes(pslot, (double)p.N * p.M * p.AH * p.AW * (p.a_f32 ? 4.0 : 2.0) + (double)p.N * p.C * p.BH * p.BW * (p.b_f32 ? 4.0 : 2.0) + (double)p.M * p.C * p.ntaps * 4.0);
 #define WGS2_LAUNCH(R_, S_, PT_, PL_)                                                                          \
     do {                                                                                                       \
         const size_t lds = 2 * (size_t)64 * 144 + 2 * (size_t)64 * S2Cfg<R_, S_, PT_, PL_>::cp();              \

@@ -308,6 +308,7 @@ int launch_gconv_wr(GcParams& p, const float* w, const float* w_scale, long long
              p.epi_wide ? " wstore" : "");
     snprintf(kname, sizeof(kname), "gconv_wr_kernel<%d,%d%s>", BC, WM, nlw == 8 ? ",lw8" : "");
     const int pslot = gc_prof_open(kname, p.aflops, st, ptag);
+    gc_prof_bytes(pslot, gc_algo_bytes(p));
 #define WR_LAUNCH(BC_, WM_, NLW_)                                                                     \
     do {                                                                                              \
         gc_set_max_lds((const void*)gconv_wr_kernel<BC_, WM_, NLW_>, (int)lds);                       \

@@ -92,6 +92,7 @@ SIGNATURES = {
     "hific_prof_begin": (I, []),
     "hific_env_refresh": (I, []),
     "hific_prof_end": (I, [I, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int), c_char_p]),
+    "hific_prof_bytes": (I, [I, POINTER(ctypes.c_double)]),
 }
 
 

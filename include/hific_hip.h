@@ -286,6 +286,9 @@ int hific_augment_crop(const void* imgs, const int* xb, const int* xk, const int
  * Return value: number of kernel functions seen (>= 0) or a negative error code. */
 int hific_prof_begin(void);
 int hific_prof_end(int max_kinds, double* ms, double* flops, int* count, char* names);
+/* Algorithmic HBM bytes (operands read once + result written once) per kernel function of the profile in progress, same order
+ * as hific_prof_end; call it BEFORE hific_prof_end (which resets the profile).  0 for launches that do not report bytes. */
+int hific_prof_bytes(int max_kinds, double* bytes);
 
 /* The planner's HIFIC_* environment knobs (A/B switches of the conv engine; the reference has no counterpart - its knobs are
  * cuDNN's) are read once per process and cached.  A caller that changes one inside a running process (tests, tools) calls this

@@ -9,7 +9,7 @@ up to a handful of rounding ties), and EVERY parameter gradient is compared elem
 
     e = max |g_bf16 - g_f32| / max |g_f32|          per tensor
 
-against a per-tensor bound = 3 x the value measured when the table was made (tests/golden/bf16_grad_bounds.json, written by
+against a per-tensor bound = 1.5 x the value measured when the table was made (round 5: regenerated with the round-5 kernels) (tests/golden/bf16_grad_bounds.json, written by
 this very test under HIFIC_WRITE_BOUNDS=1 on the GPU box and committed; the measured values are printed on every run).
 bf16 runs are bit-reproducible, so the measured values are properties of the arithmetic, not of the box.  No tensor may have
 a bound above 0.25: a flipped sign or a dropped term gives e ~ 1-2.
@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 BOUNDS = os.path.join(HERE, "golden", "bf16_grad_bounds.json")
-FLOOR, CAP, FACTOR = 2e-3, 0.25, 3.0
+FLOOR, CAP, FACTOR = 2e-3, 0.25, 1.5
 
 
 def _cycle(hific, dev, dt, B, S, regime):

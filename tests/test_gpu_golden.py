@@ -139,7 +139,8 @@ def test_reference_golden_replay_bf16(hific, dev, case):
     assert _rel(float(inter.n_bpp), g["n_bpp"]) < 3e-3 and _rel(float(inter.q_bpp), g["q_bpp"]) < 3e-3
     assert _rel(float(losses["compression"]), g["compression"]) < 5e-3
     assert abs(float(rec.mean()) - g["recon_mean"]) < 1e-2 * g["recon_std"] and _rel(float(rec.std()), g["recon_std"]) < 1e-2
-    assert worst_g < (0.25 if not g["train_generator"] else 8e-2)
+    # 2x the values measured on the round-5 build (G-turns 1.33e-2 / 1.23e-2, D-turn 3.7e-4; bf16 runs are bit-reproducible)
+    assert worst_g < (1e-3 if not g["train_generator"] else 2.7e-2)
     if g["gan"]:
         assert _rel(float(losses["disc"]), g["disc"]) < 3e-2
 
@@ -234,8 +235,9 @@ def test_fullsize_bf16_exact_index_against_oracle(hific, dev, fullsize_oracle):
     assert _rel(float(inter.q_bpp), float(hi.total_qbpp)) < 3e-3
     assert _rel(float(losses["compression"]), float(out["compression"])) < 5e-3
     # 24 bf16 convolutions + 25 bf16 ChannelNorms deep: the reconstruction carries the bf16 rounding of the Generator's
-    # activations (2^-9 per element per layer; measured max-rel 1.3e-2, rms-rel 1.0e-2 of a low-contrast random-init output)
-    assert err_rec < 3e-2 and rms_rec < 3e-2
+    # activations (2^-9 per element per layer; measured max-rel 1.33e-2, rms-rel 1.01e-2 of a low-contrast random-init output)
+    # (bounds = 2x the measured values)
+    assert err_rec < 2.7e-2 and rms_rec < 2.1e-2
 
 
 def test_fullsize_bf16_exact_reconstruction_option(hific, dev, fullsize_oracle):
