@@ -748,6 +748,224 @@ __global__ void split_pair_kernel(const float* __restrict__ src, TO* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Gradient of the Discriminator's context maps THROUGH its first convolution, without the data gradient of that convolution
+// (src/network/discriminator.py:75-78: x = cat(x, upsample16(context)); conv1 = 4x4, stride 2, reflect pad 1).
+// d ctx[m][c][Y][X] = sum over the f x f block of the input plane of dx[i][Ci + c] for the images i in {2m, 2m+1} (model.py:
+// 176-179: repeat_interleave pairs them), and dx = conv1^T dz.  Both are linear and the block sum commutes with the taps:
+//   d ctx = (1/sigma) sum_i sum_k sum_{r,s} w[k][Ci+c][r][s] * sum_{q in Q_r(Y)} sum_{q' in Q_s(X)} dz[i][k][q][q']
+// where Q_r(b) = {q : P0(b) <= 2q + r <= P1(b)} and [P0, P1] is the block's range of PADDED rows, the first / last block taking
+// the mirror row with it (reflect pad 1: padded row 0 is input row 1, padded row H+1 is input row H-2).  One pass over dz (67 MB
+// at the benchmark shape) instead of a 15-channel data gradient on the 258 x 258 padded plane + its block-sum kernel.
+// Two launches.  d1_ctx_win_kernel, grid (H / f) x B x column segments, 512 threads: a workgroup walks the K output channels of
+// its two images four at a time; thread (channel, column) sums its column over each tap row's window (rows requested one step
+// ahead, registers) -> LDS -> thread (channel, tap row, tap column, block) forms the column window (one base window + edge
+// corrections), adds the pair's two images and writes T[(m, Y, X)][(k, r, s)] (float32, 16 MB at the benchmark shape).
+// d1_ctx_dot_kernel: d ctx[(m, Y, X)][c] = (1/sigma) sum_j T[.][j] w[j][c], the weights in LDS.
+// ---------------------------------------------------------------------------------------------------
+#define D1C_MAXW 128      // columns of dz per workgroup (blockIdx.z = column segment)
+#define D1C_NK 8          // output channels per step: loading thread = (channel, column pair)
+// NR = rows a block's taps can draw from (f / 2 + 2); HALO: the plane is wider than one segment (the segment's edge threads also
+// carry the column outside it).  Every load is unconditional from a clamped address and masked afterwards (loads under a
+// condition make hipcc wait for each one); a thread loads two neighbouring columns per instruction.
+template <typename TI> struct D1Pair;
+template <> struct D1Pair<bf16_t> {
+    typedef unsigned type;
+    __device__ static __forceinline__ float lo(unsigned v) { return __uint_as_float(v << 16); }
+    __device__ static __forceinline__ float hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+};
+template <> struct D1Pair<float> {
+    typedef float2 type;
+    __device__ static __forceinline__ float lo(float2 v) { return v.x; }
+    __device__ static __forceinline__ float hi(float2 v) { return v.y; }
+};
+template <typename TI, int NR, bool HALO>
+__global__ __launch_bounds__(512) void d1_ctx_win_kernel(const TI* __restrict__ dz, float* __restrict__ T, int B, int K, int OH,
+                                                         int OW, int f) {
+    // vertical window sums of the channels in flight, per tap row: index 0 = the column left of the segment, 1 .. 128 = the
+    // segment, 129 = the column right of it (a block's outermost tap windows reach one column past its own)
+    __shared__ float V[D1C_NK][4][D1C_MAXW + 2];
+    typedef typename D1Pair<TI>::type PT;
+    const int tid = threadIdx.x;
+    const int Y = blockIdx.x, m = blockIdx.y;
+    const int H = OH * 2, NB = H / f, NBX = (OW * 2) / f;
+    const int bps = D1C_MAXW / (f / 2);                   // blocks per column segment (16)
+    const int X0 = blockIdx.z * bps, c0 = X0 * (f / 2);   // first block / first column of this segment
+    const int nbx = NBX - X0 < bps ? NBX - X0 : bps;
+    // padded row range of block Y and the output rows each tap row draws from
+    const int P0 = Y == 0 ? 0 : f * Y + 1, P1 = Y == NB - 1 ? H + 1 : f * Y + f;
+    int qlo[4], qhi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lo = (P0 - r + 1) >> 1, hi = (P1 - r) >> 1;   // ceil((P0 - r) / 2), floor((P1 - r) / 2)  (arithmetic shifts)
+        qlo[r] = lo < 0 ? 0 : lo; qhi[r] = hi > OH - 1 ? OH - 1 : hi;
+    }
+    const int row0 = qlo[3], row1 = qhi[0];               // tap row 3 starts lowest, tap row 0 ends highest
+    // window threads: value u = tid + 512 e (e < 4) of the 16 x 128 values of a step -> block column (tid >> 7) + 4 e of the
+    // segment, j = tid & 127 = (channel of the step, tap row, tap column).  Column windows as indices into V (column - c0 + 1):
+    // the window of tap columns 1 and 2 is exactly f / 2 = NR - 2 columns for every block; tap columns 0 and 3 differ from it by
+    // at most one column per end: `ia` / `ib` = index added at the low / high end (or -1), `sl` / `sh` = the base window's first /
+    // last column is subtracted
+    int wlo[4], ia[4], ib[4];
+    bool sl[4], sh[4], wok[4];
+    const int jj = tid & 127, jk = jj >> 4, jr = (jj >> 2) & 3, js = jj & 3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int xl = (tid >> 7) + 4 * e;                 // block column inside the segment
+        wok[e] = xl < nbx;
+        const int cX = X0 + (wok[e] ? xl : 0);
+        const int W2 = OW * 2;
+        const int PX0 = cX == 0 ? 0 : f * cX + 1, PX1 = cX == NBX - 1 ? W2 + 1 : f * cX + f;
+        int slo[4], shi[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int lo = (PX0 - s2 + 1) >> 1, hi = (PX1 - s2) >> 1;
+            slo[s2] = (lo < 0 ? 0 : lo) - c0 + 1; shi[s2] = (hi > OW - 1 ? OW - 1 : hi) - c0 + 1;
+        }
+        wlo[e] = slo[1];
+        ia[e] = slo[js] < slo[1] ? slo[js] : -1; sl[e] = slo[js] > slo[1];
+        ib[e] = shi[js] > shi[1] ? shi[js] : -1; sh[e] = shi[js] < shi[1];
+    }
+    const int kk = tid >> 6, lp = tid & 63;               // loading threads: channel of the step, column pair of the segment
+    const int col = c0 + 2 * lp;                          // (OW is even: a pair is inside or outside as a whole)
+    // the segment's first / last pair thread also carries the column outside it (-1: none)
+    const int hcol = lp == 0 ? (c0 > 0 ? c0 - 1 : -1) : (lp == 63 ? (c0 + D1C_MAXW < OW ? c0 + D1C_MAXW : -1) : -1);
+    const int hidx = lp == 0 ? 0 : D1C_MAXW + 1;
+    const size_t plane = (size_t)OH * OW;
+    const int nstep = 2 * ((K + D1C_NK - 1) / D1C_NK);    // (channel group, image) steps
+    // row weights of the four tap rows (1 inside the tap row's window, 0 outside: uniform over the workgroup) and this thread's
+    // clamped element offsets inside a channel plane
+    unsigned roff[NR], hoff[NR];
+    float mk[NR][4];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int q = row0 + j, qc = q <= row1 ? q : row1;
+        roff[j] = (unsigned)(qc * OW + (col < OW ? col : OW - 2));
+        hoff[j] = (unsigned)(qc * OW + (hcol >= 0 ? hcol : 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mk[j][r] = (q <= row1 && q >= qlo[r] && q <= qhi[r]) ? 1.f : 0.f;
+    }
+    const bool cok = col < OW, hok = hcol >= 0;
+    PT xr[NR];
+    typename std::conditional<std::is_same<TI, float>::value, float, unsigned short>::type xh[NR];
+    // rows of step st_ -> xr / xh
+#define D1C_LOAD(st_)                                                                                   \
+    do {                                                                                                \
+        const int img_ = (st_) & 1, k_ = ((st_) >> 1) * D1C_NK + kk;                                    \
+        const TI* zk_ = dz + ((size_t)(2 * m + img_) * K + (k_ < K ? k_ : K - 1)) * plane;              \
+        _Pragma("unroll") for (int j = 0; j < NR; ++j) {                                                \
+            xr[j] = *(const PT*)(zk_ + roff[j]);                                                        \
+            if constexpr (HALO) xh[j] = zk_[hoff[j]];                                                   \
+        }                                                                                               \
+    } while (0)
+    D1C_LOAD(0);
+    float tacc[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t J = (size_t)K * 16;
+    float* Trow = T + (((size_t)m * NB + Y) * NBX + X0) * J;
+    for (int st = 0; st < nstep; ++st) {
+        float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f}, vh[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool kok = (st >> 1) * D1C_NK + kk < K;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const float x0 = D1Pair<TI>::lo(xr[j]), x1 = D1Pair<TI>::hi(xr[j]);
+            float xhv = 0.f;
+            if constexpr (HALO) xhv = DT<TI>::ld((const TI*)&xh[j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v0[r] += mk[j][r] * x0; v1[r] += mk[j][r] * x1;
+                if constexpr (HALO) vh[r] += mk[j][r] * xhv;
+            }
+        }
+        __syncthreads();                                   // the previous step's V has been consumed
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            V[kk][r][2 * lp + 1] = (cok && kok) ? v0[r] : 0.f;
+            V[kk][r][2 * lp + 2] = (cok && kok) ? v1[r] : 0.f;
+        }
+        if (HALO && (lp == 0 || lp == 63)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) V[kk][r][hidx] = (hok && kok) ? vh[r] : 0.f;
+        }
+        if (st + 1 < nstep) D1C_LOAD(st + 1);              // in flight under the window sums below
+        __syncthreads();
+        const float* vr = V[jk][jr];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float wv[NR - 2];
+#pragma unroll
+            for (int q = 0; q < NR - 2; ++q) wv[q] = vr[wlo[e] + q];
+            const float ea = vr[ia[e] >= 0 ? ia[e] : 0], eb = vr[ib[e] >= 0 ? ib[e] : 0];
+            float base = 0.f;
+#pragma unroll
+            for (int q = 0; q < NR - 2; ++q) base += wv[q];
+            tacc[e] += base + (ia[e] >= 0 ? ea : 0.f) - (sl[e] ? wv[0] : 0.f) + (ib[e] >= 0 ? eb : 0.f) - (sh[e] ? wv[NR - 3] : 0.f);
+        }
+        if (st & 1) {                                      // both images of the pair are in: T[(m, Y, X)][(k, r, s)]
+            const int kq = (st >> 1) * D1C_NK;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (wok[e] && kq + jk < K) Trow[(size_t)((tid >> 7) + 4 * e) * J + (size_t)kq * 16 + jj] = tacc[e];
+                tacc[e] = 0.f;
+            }
+        }
+    }
+#undef D1C_LOAD
+}
+
+// d ctx[(m, Y, X)][c] = sc * sum_j T[(m, Y, X)][j] * w[(j >> 4) * Ct + Ci + c][j & 15].  16 rows per workgroup of 256 threads;
+// thread = (row, one of 16 slices of 64 j): its 64 T values in flight as 16 float4 loads, the weights of its slice from LDS
+// ([slice][64 j][CC] + 4 floats of padding per slice: the 16 slices of a wave sit in different banks, the rows broadcast),
+// slice sums by lane shuffles.  J = 1024, CC = 12 instantiated.
+template <typename TO, int CC>
+__global__ __launch_bounds__(256) void d1_ctx_dot_kernel(const float* __restrict__ T, const float* __restrict__ w,
+                                                         const float* __restrict__ inv_sigma, TO* __restrict__ dctx, int rows,
+                                                         int Ci, int NBNBX) {
+    constexpr int JS = 64, NS = 16, J = JS * NS, SST = JS * CC + 4;
+    static_assert(CC % 4 == 0, "16-byte weight reads");
+    __shared__ __attribute__((aligned(16))) float wl[NS * SST];
+    const int tid = threadIdx.x;
+    const int Ct = Ci + CC;
+    for (int i = tid; i < J * CC; i += 256) {
+        const int j = i / CC, c = i - j * CC;
+        wl[(j >> 6) * SST + (j & 63) * CC + c] = w[((size_t)(j >> 4) * Ct + Ci + c) * 16 + (j & 15)];
+    }
+    const int sl = tid & 15, rl = tid >> 4;
+    const int row = blockIdx.x * 16 + rl;
+    const float* tr = T + (size_t)(row < rows ? row : rows - 1) * J + sl * JS;
+    float4 t[JS / 4];
+#pragma unroll
+    for (int q = 0; q < JS / 4; ++q) t[q] = *(const float4*)(tr + 4 * q);
+    __syncthreads();
+    float acc[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+    const float* ws_ = wl + sl * SST;
+#pragma unroll
+    for (int q = 0; q < JS / 4; ++q) {
+        const float tv[4] = {t[q].x, t[q].y, t[q].z, t[q].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int c4 = 0; c4 < CC / 4; ++c4) {
+                const float4 wv = *(const float4*)(ws_ + (4 * q + u) * CC + 4 * c4);
+                acc[4 * c4 + 0] += tv[u] * wv.x; acc[4 * c4 + 1] += tv[u] * wv.y;
+                acc[4 * c4 + 2] += tv[u] * wv.z; acc[4 * c4 + 3] += tv[u] * wv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 16);
+    }
+    if (sl == 0 && row < rows) {
+        const float sc = inv_sigma ? *inv_sigma : 1.f;
+        const int mm = row / NBNBX, yx = row - mm * NBNBX;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) DT<TO>::st(dctx + ((size_t)mm * CC + c) * NBNBX + yx, acc[c] * sc);
+    }
+}
+
 extern "C" {
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
@@ -1021,6 +1239,34 @@ int hific_upcat_pair_bwd(const void* dout, void* dgen, void* dctx, int B, int Ci
             hipLaunchKernelGGL(upcat_pair_bwd_ctx_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)dout, (float*)dctx, B, Ci, Cc, H, W, f),
             hipLaunchKernelGGL(upcat_pair_bwd_ctx_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dctx, B, Ci, Cc, H, W, f));
     }
+    return hific_launch_status();
+}
+
+// dz [2B, K, H/2, W/2] (gradient at conv1's pre-activation), w [K, Ci+Cc, 4, 4] float32 (weight_orig), inv_sigma: device scalar
+// or null, dctx [B, Cc, H/f, W/f].  Geometry fixed by the reference: 4x4 window, stride 2, reflect pad 1; f even, W/2 <= 128.
+int hific_d1_ctx_grad(const void* dz, const float* w, const float* inv_sigma, void* dctx, int B, int K, int Ci, int Cc, int H,
+                      int W, int f, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!dz || !w || !dctx || B <= 0 || K <= 0 || Cc <= 0 || f < 4 || (f & 1) || H % f || W % f || (H & 1) || (W & 1))
+        return HIFIC_ERR_ARG;
+    const int OH = H / 2, OW = W / 2;
+    if (f != 16 || 16 * Cc > 256 || H / f < 2 || W / f < 2) return HIFIC_ERR_UNSUPPORTED;     // instantiated: NR = f / 2 + 2 = 10
+    const size_t J = (size_t)K * 16, rows = (size_t)B * (H / f) * (W / f);
+    if (K != 64 || Cc != 12) return HIFIC_ERR_UNSUPPORTED;    // d1_ctx_dot_kernel is instantiated for the reference's layer
+    if (!ws || ws_bytes < rows * J * sizeof(float)) return HIFIC_ERR_WS;
+    float* T = (float*)ws;
+    const dim3 grid(H / f, B, cdiv(OW, D1C_MAXW));
+    const bool halo = OW > D1C_MAXW;
+#define D1C_GO(TI_, NR_, HALO_)                                                                                             \
+    hipLaunchKernelGGL((d1_ctx_win_kernel<TI_, NR_, HALO_>), grid, dim3(512), 0, st, (const TI_*)dz, T, B, K, OH, OW, f)
+#define D1C_PICK(TI_)                                                                                                       \
+    do { if (halo) D1C_GO(TI_, 10, true); else D1C_GO(TI_, 10, false); } while (0)
+    DISPATCH_T(dtype, D1C_PICK(float), D1C_PICK(bf16_t));
+#undef D1C_PICK
+#undef D1C_GO
+    const int nb = (int)((rows + 15) / 16);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((d1_ctx_dot_kernel<float, 12>), dim3(nb), dim3(256), 0, st, T, w, inv_sigma, (float*)dctx, (int)rows, Ci, (H / f) * (W / f)),
+        hipLaunchKernelGGL((d1_ctx_dot_kernel<bf16_t, 12>), dim3(nb), dim3(256), 0, st, T, w, inv_sigma, (bf16_t*)dctx, (int)rows, Ci, (H / f) * (W / f)));
     return hific_launch_status();
 }
 

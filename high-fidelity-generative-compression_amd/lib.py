@@ -60,6 +60,7 @@ SIGNATURES = {
     "hific_upcat_bwd": (I, [P, P, I, I, P, I, I, I, I, I, I, I, P]),
     "hific_upcat_pair_fwd": (I, [P, P, P, P] + [I] * 7 + [P]),
     "hific_upcat_pair_bwd": (I, [P, P, P] + [I] * 7 + [P]),
+    "hific_d1_ctx_grad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P, Z, P]),
     "hific_spectral_norm_fwd": (I, [P, P, P, P, I, I, I, F, P, Z, P]),
     "hific_spectral_norm_fwd_batch": (I, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                           POINTER(c_int), POINTER(c_int), I, I, F, P, Z, P]),

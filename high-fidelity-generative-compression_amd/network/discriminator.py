@@ -81,16 +81,29 @@ class Discriminator(nn.Module):
             x_gen = ops.cast_grad(x_gen, y.dtype)
         if x_real.dtype != y.dtype:
             x_real = ops.cast(x_real.contiguous(), y.dtype)
+        if ops.d1_stage_on():
+            # input gather + first convolution as one autograd node: its backward never forms the 15-channel data gradient
+            # (ops.D1StageFn)
+            convs = (self.conv1, self.conv2, self.conv3, self.conv4)
+            with torch.no_grad():
+                sigs = ops.spectral_norm_power_iteration_batch([(c.weight_orig, c.weight_u, c.weight_v) for c in convs],
+                                                               do_iter=self.training, eps=convs[0].eps)
+            c1 = self.conv1
+            geom = (c1.stride, c1.pad, c1.pad, c1.pad, c1.pad, lib.PAD_REFLECT)
+            x = ops.D1StageFn.apply(x_real.contiguous(), x_gen.contiguous(), y.contiguous(), self.upsample_factor,
+                                    c1.weight_orig, c1.bias, c1.weight_u, c1.weight_v, sigs[0], geom, c1.act)
+            return self._trunk(x, sigs=sigs, first=1)
         x = ops.UpsamplePairConcatFn.apply(x_real.contiguous(), x_gen.contiguous(), y, self.upsample_factor)
         return self._trunk(x)
 
-    def _trunk(self, x):
+    def _trunk(self, x, sigs=None, first=0):
         # one power iteration per spectral-norm layer and forward (torch.nn.utils.spectral_norm), the four layers per launch
         convs = (self.conv1, self.conv2, self.conv3, self.conv4)
-        with torch.no_grad():
-            sigs = ops.spectral_norm_power_iteration_batch([(c.weight_orig, c.weight_u, c.weight_v) for c in convs],
-                                                           do_iter=self.training, eps=convs[0].eps)
-        for c, sg in zip(convs, sigs):
+        if sigs is None:
+            with torch.no_grad():
+                sigs = ops.spectral_norm_power_iteration_batch([(c.weight_orig, c.weight_u, c.weight_v) for c in convs],
+                                                               do_iter=self.training, eps=convs[0].eps)
+        for c, sg in list(zip(convs, sigs))[first:]:
             x = c(x, sig=sg)
         out_logits = self.conv_out(x).view(-1, 1)
         out = ops.sigmoid(out_logits.detach())

@@ -1605,6 +1605,117 @@ class SNConv2dFn(Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+_D1_FUSED = os.environ.get("HIFIC_D1_FUSED", "1") not in ("0", "")
+
+
+def d1_stage_on():
+    """The Discriminator's input gather + first convolution as ONE autograd node (D1StageFn); HIFIC_D1_FUSED=0: the two nodes."""
+    return _D1_FUSED
+
+
+def set_d1_stage(on):
+    global _D1_FUSED
+    _D1_FUSED = bool(on)
+
+
+class D1StageFn(Function):
+    """UpsamplePairConcatFn + SNConv2dFn of the Discriminator's first layer (src/model.py:176-179, src/network/discriminator.py:
+    36,53,75-78) as one node.  Forward: the same two kernels.  Backward: the 15-channel data gradient of the convolution on the
+    258 x 258 padded plane is never formed - its consumers are (a) the generated images' 3 channels of the second half of the
+    batch, computed by a data gradient restricted to those (G-turn only: the D-turn detaches them), and (b) the block sums over
+    the 16 x 16 upsampling cells of the 12 context channels, which commute with the convolution's taps and come from window
+    sums of the output gradient (hific_d1_ctx_grad).  Parameter gradients as in SNConv2dFn."""
+
+    @staticmethod
+    def forward(ctx, real, gen, ctxt, f, weight_orig, bias, u, v, sig, geom, act):
+        require_gpu(real, gen, ctxt, weight_orig, bias, u, v, sig)
+        B, Ci, H, W = real.shape
+        assert gen.shape == real.shape and gen.dtype == real.dtype == ctxt.dtype and ctxt.shape[0] == B
+        Cc = ctxt.shape[1]
+        stride, pt, pl, pb, pr, pad_mode = geom
+        K, C, R, S = weight_orig.shape
+        assert C == Ci + Cc and (R, S, stride, pt, pl, pb, pr) == (4, 4, 2, 1, 1, 1, 1) and pad_mode == lib.PAD_REFLECT
+        x = torch.empty((2 * B, C, H, W), dtype=real.dtype, device=real.device)
+        call("hific_upcat_pair_fwd", ptr(real), ptr(gen), ptr(ctxt), ptr(x), B, Ci, Cc, H, W, int(f), lib.dtype_code(real),
+             stream())
+        cd = _cd()
+        N = 2 * B
+        OH, OW = (H + 2 - 4) // 2 + 1, (W + 2 - 4) // 2 + 1
+        ydt = torch.float32 if cd == HIFIC_F32 else torch.bfloat16
+        y = torch.empty((N, K, OH, OW), dtype=ydt, device=x.device)
+        flags = (_is_f32(x) | (_is_f32(y) << 1)) if cd == HIFIC_BF16 else 0
+        flags |= _SN_EPI_SCALE
+        wsp, wsb = _ws(x)
+        wc = _wcache(weight_orig, 0, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None) \
+            if _SN_EPI_SCALE else (None, 0, 0)
+        call("hific_conv2d_fwd", ptr(x), ptr(weight_orig), ptr(sig[1:]), ptr(bias), None, ptr(y),
+             N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
+        ctx.geom, ctx.act, ctx.cd, ctx.dims = geom, act, cd, (B, Ci, Cc, H, W, int(f))
+        ctx.w_slot, ctx.b_slot = _slot(weight_orig), _slot(bias)
+        ctx.save_for_backward(x, weight_orig, u.clone(), v.clone(), sig, y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight_orig, u, v, sig, y = ctx.saved_tensors
+        stride, pt, pl, pb, pr, pad_mode = ctx.geom
+        cd = ctx.cd
+        B, Ci, Cc, H, W, f = ctx.dims
+        N, C = 2 * B, Ci + Cc
+        K, _, R, S = weight_orig.shape
+        dy = dy.contiguous()
+        if y is not None:
+            dz = torch.empty_like(dy)
+            slope = 0.0 if ctx.act == "relu" else 0.2
+            call("hific_act_bwd", ptr(dy), ptr(y), ptr(dz), dy.numel(), slope, lib.dtype_code(dy), stream())
+            dy = dz
+        dy_f32 = _is_f32(dy) if cd == HIFIC_BF16 else 0
+        inv_sigma = sig[1:]
+        dgen = dctx = dw = db = None
+        want_w, want_b = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
+        side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
+        ev = torch.cuda.current_stream(x.device).record_event() if side else None
+        if ctx.needs_input_grad[1]:
+            # generated images: data gradient of the second half of the batch for the image channels only
+            wsp, wsb = _ws(x)
+            w_gen = weight_orig[:, :Ci].contiguous()
+            dgen = torch.empty((B, Ci, H, W), dtype=x.dtype, device=x.device)
+            flags = dy_f32 | ((_is_f32(dgen) << 1) if cd == HIFIC_BF16 else 0) | _SN_EPI_SCALE
+            call("hific_conv2d_bwd_data", ptr(dy[B:]), ptr(w_gen), ptr(inv_sigma), ptr(dgen), B, Ci, H, W, K, R, S,
+                 stride, pt, pl, pb, pr, pad_mode, cd, flags, wsp, wsb, None, 0, 0, stream())
+        if ctx.needs_input_grad[2]:
+            dctx = torch.empty((B, Cc, H // f, W // f), dtype=dy.dtype, device=x.device)
+            wsp, wsb = _ws(x)
+            call("hific_d1_ctx_grad", ptr(dy), ptr(weight_orig), ptr(inv_sigma), ptr(dctx), B, K, Ci, Cc, H, W, f,
+                 lib.dtype_code(dy), wsp, wsb, stream())
+            if dctx.dtype != x.dtype:
+                dctx = dctx.to(x.dtype)
+
+        def param_grads():
+            nonlocal dw, db
+            wsp_, wsb_ = _ws(x)
+            if want_w:
+                dws = torch.empty_like(weight_orig)       # gradient w.r.t. the normalised weight (stream-local scratch)
+                flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dy_f32 << 1)
+                call("hific_conv2d_bwd_weight", ptr(x), ptr(dy), ptr(dws), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                     pad_mode, 0, cd, flags, wsp_, wsb_, stream())
+                dwt, acc, dw = _grad_target(ctx.w_slot, weight_orig)
+                M = weight_orig.numel() // K
+                call("hific_spectral_norm_bwd", ptr(dws), ptr(weight_orig), ptr(u), ptr(v), ptr(sig), ptr(dwt), K, M,
+                     acc, wsp_, wsb_, stream())
+            if want_b:
+                dbt, acc, db = _grad_target(ctx.b_slot, weight_orig.new_empty(K))
+                call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
+                     wsp_, wsb_, stream())
+        if side:
+            with _SideLaunch(ev, x, dy, u, v, sig):
+                param_grads()
+        else:
+            param_grads()
+        _written(ctx.w_slot if want_w else None, ctx.b_slot if want_b else None)
+        return None, dgen, dctx, None, dw, db, None, None, None, None, None
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     require_gpu(p, g, m, v)
     call("hific_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2),

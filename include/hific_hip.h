@@ -176,6 +176,15 @@ int hific_upcat_pair_fwd(const void* real, const void* gen, const void* ctx, voi
                          int f, int dtype, hipStream_t stream);
 int hific_upcat_pair_bwd(const void* dout, void* dgen, void* dctx, int B, int Ci, int Cc, int H, int W, int f, int dtype,
                          hipStream_t stream);
+/* Gradient of the per-latent context maps through the Discriminator's first convolution (4x4, stride 2, reflect pad 1 on
+ * cat(image, upsample_f(context)); src/network/discriminator.py:53,75-78) straight from dz = the gradient at that convolution's
+ * pre-activation [2B, K, H/2, W/2]: dctx[m][c][Y][X] = (1/sigma) sum_{i in 2m,2m+1} sum_k sum_{r,s} w[k][Ci+c][r][s] * (window sum
+ * of dz[i][k] over the output pixels whose tap (r, s) reads the f x f block (Y, X), mirror row / column included).  Replaces the
+ * 15-channel data gradient on the padded plane + hific_upcat_pair_bwd's block sums by one pass over dz and a small contraction.
+ * w = weight_orig [K, Ci+Cc, 4, 4] float32, inv_sigma: device scalar or null; ws: B * (H/f) * (W/f) * K * 16 floats.
+ * HIFIC_ERR_UNSUPPORTED: anything but the reference's layer (f = 16, K = 64, Cc = 12). */
+int hific_d1_ctx_grad(const void* dz, const float* w, const float* inv_sigma, void* dctx, int B, int K, int Ci, int Cc, int H,
+                      int W, int f, int dtype, void* ws, size_t ws_bytes, hipStream_t stream);
 /* The same power iteration for n <= 8 layers in one call (src/network/discriminator.py:53-62: the four spectral-norm convs of
  * the Discriminator; their iterations depend only on the weights): per layer bit-identical to hific_spectral_norm_fwd, 6
  * launches for the whole set instead of 6 per layer.  ws >= sum_i (M_i + K_i + ceil(K_i / 16) M_i) floats. */

@@ -196,29 +196,72 @@ def test_discriminator_pair_input_equals_cat_and_repeat_interleave(hific, dev, s
     lat = (O.make_noise(10, (B, 220, 8, 8)) * 4).to(dev)
     g = None
     res = {}
-    for mode in ("cat", "pair"):
+    from hific_amd import ops
+    for mode in ("cat", "pair", "stage"):
         D.zero_grad()
         gen = gen0.clone().requires_grad_(True)
         if mode == "cat":
             out, logits = D(torch.cat([real, gen], dim=0), torch.repeat_interleave(lat, 2, dim=0))
         else:
-            out, logits = D.forward_pairs(real, gen, lat)
+            # "stage": input gather + first convolution as one node whose backward never forms the 15-channel data gradient
+            ops.set_d1_stage(mode == "stage")
+            try:
+                out, logits = D.forward_pairs(real, gen, lat)
+            finally:
+                ops.set_d1_stage(True)
         if g is None:
             g = O.make_noise(11, tuple(logits.shape)).to(dev)
         logits.backward(g)
         torch.cuda.synchronize()
         res[mode] = (out.clone(), logits.detach().clone(), gen.grad.clone(),
                      {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None})
-    assert torch.equal(res["cat"][0], res["pair"][0]) and torch.equal(res["cat"][1], res["pair"][1])
-    assert torch.equal(res["cat"][2], res["pair"][2])
-    for k, gc in res["cat"][3].items():
-        gp = res["pair"][3][k]
-        tol = 1e-5 if dt == torch.float32 else 2e-2
-        if not k.startswith("context_conv."):
-            assert torch.equal(gc, gp), k
-        else:
-            assert _relerr(gp.float().cpu(), gc.float().cpu()) < tol, k
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    for mode in ("pair", "stage"):
+        assert torch.equal(res["cat"][0], res[mode][0]) and torch.equal(res["cat"][1], res[mode][1]), mode
+        if mode == "pair":
+            assert torch.equal(res["cat"][2], res[mode][2])
+        else:       # the restricted data gradient runs the same contraction on a 3-row problem: equal up to its tiling
+            assert _relerr(res[mode][2].float().cpu(), res["cat"][2].float().cpu()) < tol
+        for k, gc in res["cat"][3].items():
+            gp = res[mode][3][k]
+            if not k.startswith("context_conv."):
+                assert torch.equal(gc, gp), (mode, k)
+            else:
+                assert _relerr(gp.float().cpu(), gc.float().cpu()) < tol, (mode, k)
     hific.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 32, 512), (1, 256, 256)], ids=["64x64", "32x512_segments", "256x256"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_context_gradient_through_first_discriminator_conv(hific, dev, shape, dt):
+    """hific_d1_ctx_grad against autograd through cat(image, upsample16(context)) -> reflect pad 1 -> 4x4 stride-2 convolution
+    (src/network/discriminator.py:36,53,75-78) with the reference's latent pairing (image i reads context i >> 1,
+    src/model.py:176-179): first / last block rows and columns (mirror lines), several column segments, both dtypes."""
+    import torch.nn.functional as F
+    from hific_amd import lib
+    B, H, W = shape
+    Ci, Cc, K, f = 3, 12, 64, 16
+    g = torch.Generator().manual_seed(5)
+    w = (torch.rand((K, Ci + Cc, 4, 4), generator=g) - 0.5) * 0.2
+    dz = (torch.rand((2 * B, K, H // 2, W // 2), generator=g) - 0.5)
+    if dt == torch.bfloat16:
+        dz = dz.bfloat16().float()
+    inv_sigma = torch.tensor([0.7])
+    ctx = torch.zeros((B, Cc, H // f, W // f), requires_grad=True)
+    img = torch.zeros((2 * B, Ci, H, W))
+    up = F.interpolate(torch.repeat_interleave(ctx, 2, dim=0), scale_factor=f, mode="nearest")
+    y = F.conv2d(F.pad(torch.cat([img, up], 1), (1, 1, 1, 1), mode="reflect"), w * inv_sigma, stride=2)
+    (y * dz).sum().backward()
+    out = torch.empty((B, Cc, H // f, W // f), dtype=dt, device=dev)
+    dzd = dz.to(dev).to(dt).contiguous()
+    wd, sd_ = w.to(dev).contiguous(), inv_sigma.to(dev)
+    ws = lib.workspace(dev)
+    lib.call("hific_d1_ctx_grad", dzd.data_ptr(), wd.data_ptr(), sd_.data_ptr(), out.data_ptr(), B, K, Ci, Cc, H, W, f,
+             lib.dtype_code(dzd), ws.data_ptr(), ws.numel(), lib.stream())
+    torch.cuda.synchronize()
+    err = _relerr(out.float().cpu(), ctx.grad)
+    print(f"context gradient {shape} {dt}: max-rel {err:.2e}")
+    assert err < (2e-5 if dt == torch.float32 else 6e-3)      # bf16: the output rounding only (sums in float32)
 
 
 @pytest.mark.parametrize("gan", [False, True], ids=["compression", "compression_gan"])
