@@ -773,7 +773,7 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
     }
     if (!phs && !mp && choose_tile(p.N, OHt, OWt, p.ist, span_y, span_x, PITCH, wbytes, tile_budget, p.TH, p.TW, p.NI, maxtaps)) {
         const long long g = (long long)cdiv(OHt, p.TH) * cdiv(OWt, p.TW) * cdiv(p.N, p.NI) * (p.Kpad / bm) * p.nphase;
-        tiled = g >= env_int("HIFIC_GC_BIGTILE_MIN_GRID", 256);
+        tiled = g >= env_int("HIFIC_GC_BIGTILE_MIN_GRID", 64);     // (round 5: 256 -> 64, the hyperprior 5x5 layers: 127 -> 94, 77 -> 71 us)
     }
     // Layers whose 64-channel halo patch only fits as a whole-LDS tile (stride-2 convs: four input pixels per output
     // pixel) run ONE workgroup per CU, and its weight-load / staging / MFMA / bias / store-drain latencies are all
@@ -945,7 +945,10 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
         if (g0 <= gmax && nch >= 4 &&
             chain_us >= (use_sp9 ? env_int("HIFIC_KSPLIT_MIN_US_SP", 60) : env_int("HIFIC_KSPLIT_MIN_US", 20)) &&
             !p.fold_h && !p.resid && !p.msplit && !p.csplit && !p.oscale && env_int("HIFIC_KSPLIT", 1)) {
-            int ks = (int)cdivl(env_int("HIFIC_KSPLIT_TARGET", 800), g0);
+            // 128-row software-pipelined tiles run one workgroup per CU: one full wave of 256 workgroups (measured, round 5:
+            // 220 <- 2880 @16x16 100.6 -> 81.0 us, 220 <- 960 57.0 -> 41.1 us against the 800-slot target of the co-resident kernels)
+            const int target = (use_sp9 && bm == 128) ? env_int("HIFIC_KSPLIT_TARGET_SP128", 256) : env_int("HIFIC_KSPLIT_TARGET", 800);
+            int ks = (use_sp9 && bm == 128) ? (int)(target / g0) : (int)cdivl(target, g0);       // (one wave: round down)
             if (ks > nch / 2) ks = nch / 2;
             if (ks > 16) ks = 16;
             if (ks >= 2) {
