@@ -63,6 +63,7 @@ CONV_CASES = {
     # directions, the 60 -> 3 output layer (virtual-row form forward, virtual-channel form backward), the Discriminator's
     # first layer (stride 2, 15 channels), a plain 3x3 with zero padding and channel / row tails
     "WR_7x7_c9":            (4, 9, 250, 262, 60, 7, 1, (3, 3, 3, 3), "reflect"),
+    "WR_7x7_c3":            (4, 3, 256, 248, 60, 7, 1, (3, 3, 3, 3), "reflect"),      # 3 channels: virtual-channel form (21 x 7 taps)
     "WR_7x7_to3":           (4, 60, 256, 256, 3, 7, 1, (3, 3, 3, 3), "reflect"),
     "WR_4x4s2_c15":         (5, 15, 520, 400, 64, 4, 2, (1, 1, 1, 1), "reflect"),
     "WR_3x3_c24_zero":      (3, 24, 300, 310, 50, 3, 1, (1, 1, 1, 1), "zeros"),
@@ -373,7 +374,7 @@ def test_few_channel_layers_take_the_weight_resident_kernel(hific, dev):
         kinds = _kinds_of(go)
         return (kinds, out["y"]) if with_out else kinds
 
-    for name in ("WR_7x7_c9", "WR_7x7_to3", "WR_4x4s2_c15", "WR_3x3_c24_zero"):
+    for name in ("WR_7x7_c9", "WR_7x7_c3", "WR_7x7_to3", "WR_4x4s2_c15", "WR_3x3_c24_zero"):
         kinds = run(name)
         assert any(k.startswith("gconv_wr_kernel") for k in kinds), (name, kinds)
     kinds = run("WR_3x3_c24_zero", bwd=True)                          # a data gradient that is a few-channel problem itself
@@ -383,7 +384,7 @@ def test_few_channel_layers_take_the_weight_resident_kernel(hific, dev):
         assert not any(k.startswith("gconv_wr_kernel") for k in kinds), (name, kinds)
     was = os.environ.get("HIFIC_WR")
     try:
-        for name, bwd in (("WR_7x7_c9", False), ("WR_7x7_to3", False), ("WR_4x4s2_c15", False),
+        for name, bwd in (("WR_7x7_c9", False), ("WR_7x7_c3", False), ("WR_7x7_to3", False), ("WR_4x4s2_c15", False),
                           ("WR_3x3_c24_zero", True)):
             _, y1 = run(name, with_out=True, bwd=bwd)
             os.environ["HIFIC_WR"] = "0"
