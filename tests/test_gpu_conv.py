@@ -67,6 +67,12 @@ CONV_CASES = {
     "WR_7x7_to3":           (4, 60, 256, 256, 3, 7, 1, (3, 3, 3, 3), "reflect"),
     "WR_4x4s2_c15":         (5, 15, 520, 400, 64, 4, 2, (1, 1, 1, 1), "reflect"),
     "WR_3x3_c24_zero":      (3, 24, 300, 310, 50, 3, 1, (1, 1, 1, 1), "zeros"),
+    # merged-phase kernel (gconv_mp_kernel) through the DATA GRADIENTS of stride-2 convolutions on big planes (the small cases
+    # above take the per-phase grid): 4x4 reflect pad 1 (element stores into the fold), 3x3 asymmetric reflect pad (pair stores
+    # into the fold), zero padding (plain pair stores), channel tails and partial tiles
+    "PM_4x4_reflect":       (12, 64, 128, 128, 128, 4, 2, (1, 1, 1, 1), "reflect"),
+    "PM_3x3_asym_reflect":  (6, 60, 256, 256, 120, 3, 2, (1, 0, 0, 1), "reflect"),
+    "PM_3x3_zero_tail":     (5, 40, 200, 272, 72, 3, 2, (1, 1, 1, 1), "zeros"),
     "S1_rect_reflect":      (2, 70, 12, 32, 100, 3, 1, (1, 1, 1, 1), "reflect"),
     "S1_wide_zero":         (1, 130, 20, 48, 40, 3, 1, (1, 1, 1, 1), "zeros"),
 }
@@ -80,6 +86,9 @@ CONVT_CASES = {
     "odd":         (1, 7, 5, 6, 9, 3, 2, 1, 1),
     "S2T_rect":    (2, 70, 6, 16, 40, 3, 2, 1, 1),        # wgrad_s2_kernel, conv-transpose form (zero outside), partial tile rows
     "S2T_wide":    (1, 20, 9, 48, 130, 3, 2, 1, 1),
+    # merged-phase kernel forward on big planes: the Generator's last up-convolution shape, and odd sizes with a channel tail
+    "PM_U4":       (4, 120, 128, 128, 60, 3, 2, 1, 1),
+    "PM_T_odd":    (5, 70, 100, 136, 40, 3, 2, 1, 1),
 }
 DTYPES = [torch.float32, torch.bfloat16]
 TOL = {torch.float32: 2e-4, torch.bfloat16: 2e-2}
