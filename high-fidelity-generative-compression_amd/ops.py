@@ -533,8 +533,13 @@ def _written(*slots):
 # which would read it on the main stream).  Joined (main waits for side) by an autograd-engine callback at the end of
 # every backward pass and by `join_side_stream()` (the DDP reducer calls it before a bucket's all-reduce).
 _SIDE_ON = os.environ.get("HIFIC_SIDE_WGRAD", "1") not in ("0", "")
-_side_streams = {}
-_side_state = {"pending": False, "cb": False}
+# HIFIC_SIDE_STREAMS side streams per device, one per gradient slot (hashed), each with its own workspace.  Default 1: with one,
+# the weight gradients of the Discriminator's layers and their reduce / finalize / spectral-norm chains queue behind each other
+# for ~0.2 ms after the main stream has finished the D-turn's data-gradient chain (tools/r05/tail.py), but two or three streams
+# measured the same cycle time within noise (1572 / 1570 / 1574 images/s, three runs each: round 5)
+_N_SIDE = max(1, int(os.environ.get("HIFIC_SIDE_STREAMS", "1")))
+_side_streams = {}            # device index -> [streams]
+_side_state = {"pending": False, "cb": False, "rr": 0}
 
 
 def set_side_stream(on):
@@ -556,10 +561,11 @@ def _may_wait(cur, other):
 def join_side_stream():
     """Make the current stream wait for every weight-gradient kernel launched on the side stream so far."""
     if _side_state["pending"] or _branch_streams:
-        for dev_index, side in _side_streams.items():
+        for dev_index, sides in _side_streams.items():
             cur = torch.cuda.current_stream(dev_index)
-            if _may_wait(cur, side):
-                cur.wait_stream(side)
+            for side in sides:
+                if _may_wait(cur, side):
+                    cur.wait_stream(side)
         # kernels of ops whose forward ran on the branch stream write parameter gradients (arena slots) from that stream in
         # backward; autograd's own end-of-backward synchronisation only covers gradients it accumulates itself
         for dev_index, br in _branch_streams.items():
@@ -593,8 +599,8 @@ def producer_streams(device):
     """Every stream gradient kernels may have been enqueued on: the current one, the model's main stream, side, branch."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     out = [torch.cuda.current_stream(idx)]
-    for table in (_home_streams, _side_streams, _branch_streams):
-        st = table.get(idx)
+    cands = [_home_streams.get(idx)] + list(_side_streams.get(idx, ())) + [_branch_streams.get(idx)]
+    for st in cands:
         if st is not None and all(st.cuda_stream != o.cuda_stream for o in out):
             out.append(st)
     return out
@@ -608,11 +614,18 @@ def _join_callback():
 class _SideLaunch:
     """`with _SideLaunch(ev, x, dy):` - launches inside run on the side stream after event `ev` of the main stream."""
 
-    def __init__(self, ev, *tensors):
+    def __init__(self, ev, *tensors, key=None):
+        """`key`: the gradient slot the launches write (its arena index picks the side stream, so that two uses of one
+        parameter in a backward pass - overwrite, then accumulate - stay ordered); None: round-robin."""
         dev = tensors[0].device
-        side = _side_streams.get(dev.index)
-        if side is None:
-            side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+        sides = _side_streams.get(dev.index)
+        if sides is None:
+            sides = _side_streams[dev.index] = [torch.cuda.Stream(device=dev) for _ in range(_N_SIDE)]
+        if key is not None:
+            side = sides[((int(key.index) * 2654435761) >> 16) % len(sides)]      # (weights sit at every other index)
+        else:
+            side = sides[_side_state["rr"] % len(sides)]
+            _side_state["rr"] += 1
         side.wait_event(ev)
         for t in tensors:
             if t is not None:
@@ -783,7 +796,7 @@ class Conv2dFn(Function):
                 call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
                      wsp_, wsb_, stream())
         if side:
-            with _SideLaunch(ev, x, dy):
+            with _SideLaunch(ev, x, dy, key=ctx.w_slot if ctx.w_slot is not None else ctx.b_slot):
                 param_grads()
         else:
             param_grads()
@@ -887,7 +900,7 @@ class ConvTranspose2dFn(Function):
                 call("hific_channel_sum", ptr(dy), ptr(dbt), N, Co, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
                      wsp_, wsb_, stream())
         if side:
-            with _SideLaunch(ev, x, dy):
+            with _SideLaunch(ev, x, dy, key=ctx.w_slot if ctx.w_slot is not None else ctx.b_slot):
                 param_grads()
         else:
             param_grads()
@@ -1048,7 +1061,7 @@ class ExactConvNormFn(Function):
                  acc, cd, _is_f32(x), wsp_, wsb_, stream())
         if want_w:
             if side:
-                with _SideLaunch(ev, x, dz):
+                with _SideLaunch(ev, x, dz, key=ctx.w_slot):
                     wgrad()
             else:
                 wgrad()
@@ -1597,7 +1610,7 @@ class SNConv2dFn(Function):
                 call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
                      wsp_, wsb_, stream())
         if side:
-            with _SideLaunch(ev, x, dy, u, v, sig):
+            with _SideLaunch(ev, x, dy, u, v, sig, key=ctx.w_slot if ctx.w_slot is not None else ctx.b_slot):
                 param_grads()
         else:
             param_grads()
@@ -1708,7 +1721,7 @@ class D1StageFn(Function):
                 call("hific_channel_sum", ptr(dy), ptr(dbt), N, K, dy.shape[2] * dy.shape[3], acc, lib.dtype_code(dy),
                      wsp_, wsb_, stream())
         if side:
-            with _SideLaunch(ev, x, dy, u, v, sig):
+            with _SideLaunch(ev, x, dy, u, v, sig, key=ctx.w_slot if ctx.w_slot is not None else ctx.b_slot):
                 param_grads()
         else:
             param_grads()
