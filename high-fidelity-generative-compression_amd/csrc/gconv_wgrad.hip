@@ -517,6 +517,9 @@ void wgrad_pipe_kernel(const WgParams p) {
 //   swapped : D[c][(t,m)]  = sum_pix' A'[c][pix'] * B'[m][pix' - tap_t]    (A' = padded x over the padded domain,
 //             B' = dY zero outside) -- used when dY is the small operand
 // ---------------------------------------------------------------------------------------------------
+#ifndef IM2COL_QB
+#define IM2COL_QB 2
+#endif
 template <typename T, bool BF32>
 __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
     using Cfg = WgCfg<T>;
@@ -581,8 +584,9 @@ __global__ __launch_bounds__(256) void wgrad_im2col_kernel(const WgParams p) {
         __syncthreads();
         // A^T: the tile itself, sampled at (u + a_y0, v + a_x0) of the source tensor [N, M, a_h, a_w].  Pixels of
         // the tile that lie outside the (padded) domain must contribute nothing: they are zeroed via the B image.
-        stage_T<T, DWR, PITCH>(at, p.a, p.a_f32, p.N, p.M, p.a_h, p.a_w, p.a_bmode, n0, p.NI, u0 + p.a_y0,
-                               v0 + p.a_x0, 0, p.TH, p.TW, m0, tid, 256);
+        // (both 64-pixel rounds of the tile in flight at once: IM2COL_QB, A/B in tools/r05)
+        stage_T<T, DWR, PITCH, IM2COL_QB>(at, p.a, p.a_f32, p.N, p.M, p.a_h, p.a_w, p.a_bmode, n0, p.NI, u0 + p.a_y0,
+                                          v0 + p.a_x0, 0, p.TH, p.TW, m0, tid, 256);
         // the small operand's halo patch: rows y0 .. y0 + PHh - 1, columns x0 .. x0 + PWw - 1 of B (padding rule applied here,
         // so the gather below needs no bounds tests); consecutive threads take consecutive columns
         {
