@@ -1049,7 +1049,9 @@ static int launch_wgrad_im2col_t(const ConvGeom& g, const void* x, const void* d
     p.ntiles = p.tiles_n * p.tiles_y * p.tiles_x;
     if (p.Cpad / 64 > 4) return HIFIC_ERR_UNSUPPORTED;             // one workgroup covers all (<= 256) virtual columns
     const int base_blocks = p.Mpad / 64;
-    int nsplit = cdiv(env_int("HIFIC_IM2COL_TARGET", 512), base_blocks);       // two workgroups per CU: one full round
+    // three workgroups per CU co-reside (103 registers, ~48 KB of LDS): one full round of 768 (round 5: 512 -> 768: 194 -> 168 us
+    // on the first Encoder layer's weight gradient, 243 -> 207 us on the output layer's; 1024-2048 are slower again)
+    int nsplit = cdiv(env_int("HIFIC_IM2COL_TARGET", 768), base_blocks);
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     p.tiles_per_split = cdiv(p.ntiles, nsplit);
     p.nsplit = cdiv(p.ntiles, p.tiles_per_split);
