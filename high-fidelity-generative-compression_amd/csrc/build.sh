@@ -7,7 +7,7 @@ OUT=${OUT:-../libhific_hip.so}
 OBJDIR=${OBJDIR:-.}
 mkdir -p $OBJDIR
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value $EXTRA"
-SRCS="gconv gconv_mpvc gconv_sp9 gconv_pack gconv_wgrad gconv_wgrad_nat gconv_pl gconv_wr elementwise norm entropy lpips augment capi"
+SRCS="gconv gconv_mpvc gconv_sp9 gconv_pack gconv_wgrad gconv_wgrad_nat gconv_wgrad_c3 gconv_pl gconv_wr elementwise norm entropy lpips augment capi"
 OBJS=""
 PIDS=""
 NAMES=""

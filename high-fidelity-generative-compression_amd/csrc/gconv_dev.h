@@ -136,6 +136,10 @@ int gc_launch_wgrad_s1(WgParams& p, float* dw, long long sm, long long sc, long 
 int gc_launch_wgrad_s2(WgParams& p, float* dw, long long sm, long long sc, long long sr, long long ss, int accumulate, WsAlloc& ws,
                        hipStream_t st);
 
+// gconv_wgrad_c3.hip: stride-1 weight gradient with <= 4 input channels on big planes, operands in natural order
+int gc_launch_wgrad_c3(const ConvGeom& g, const void* x, const void* dy, float* dw, int accumulate, int x_f32, int dy_f32,
+                       WsAlloc& ws, hipStream_t st);
+
 // gconv_mpvc.hip
 void gc_launch_mp(const GcParams& p, dim3 grid, size_t lds, hipStream_t st);
 int gc_launch_vc(GcParams& p, const float* w, const float* w_scale, long long sm, long long sc, long long sr, long long ss,

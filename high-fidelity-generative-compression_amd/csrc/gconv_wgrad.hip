@@ -1121,6 +1121,11 @@ int gc_conv_bwd_weight(const ConvGeom& g, const void* x, const void* dy, float* 
         const int rc = gc_launch_wgrad_s2(q, dw, (long long)g.C * RSq, RSq, g.S, 1, accumulate, ws, st);
         if (rc != HIFIC_ERR_UNSUPPORTED) return rc;
     }
+    if (im2col4 && g.C <= 4 && dtype == HIFIC_BF16) {
+        // few INPUT channels on a big plane (the first Encoder layer): natural-order kernel (gconv_wgrad_c3.hip)
+        const int rc = gc_launch_wgrad_c3(g, x, dy, dw, accumulate, x_f32, dy_f32, ws, st);
+        if (rc != HIFIC_ERR_UNSUPPORTED) return rc;
+    }
     if ((im2col4 || im2col16) && !env_int("HIFIC_NO_IM2COL", 0)) {
         int rc = HIFIC_ERR_ARG;
         if (dtype == HIFIC_F32) rc = launch_wgrad_im2col_t<float>(g, x, dy, dw, accumulate, 1, 1, ws, st);

@@ -73,6 +73,10 @@ CONV_CASES = {
     "PM_4x4_reflect":       (12, 64, 128, 128, 128, 4, 2, (1, 1, 1, 1), "reflect"),
     "PM_3x3_asym_reflect":  (6, 60, 256, 256, 120, 3, 2, (1, 0, 0, 1), "reflect"),
     "PM_3x3_zero_tail":     (5, 40, 200, 272, 72, 3, 2, (1, 1, 1, 1), "zeros"),
+    # natural-order weight gradient for <= 4 input channels on big planes (wgrad_c3_kernel): the first Encoder layer's shape, and
+    # 4 channels / 5x5 / zero padding / a row count that does not divide the workgroups
+    "WC3_7x7":              (4, 3, 256, 256, 60, 7, 1, (3, 3, 3, 3), "reflect"),
+    "WC3_5x5_c4_zero":      (5, 4, 208, 240, 40, 5, 1, (2, 2, 2, 2), "zeros"),
     "S1_rect_reflect":      (2, 70, 12, 32, 100, 3, 1, (1, 1, 1, 1), "reflect"),
     "S1_wide_zero":         (1, 130, 20, 48, 40, 3, 1, (1, 1, 1, 1), "zeros"),
 }
@@ -353,6 +357,9 @@ def test_strided_weight_gradients_take_their_kernels(hific, dev):
     for name in ("I16_3x3s1_c12", "I16_4x4s2_c16_zero", "odd_s2"):
         assert "wgrad_im2col_kernel<bf16>" in conv_wgrad(name), name
     assert "wgrad_s2_kernel" not in conv_wgrad("odd_s2")
+    for name in ("WC3_7x7", "WC3_5x5_c4_zero"):
+        assert "wgrad_c3_kernel" in conv_wgrad(name), name
+    assert "wgrad_c3_kernel" not in conv_wgrad("WR_7x7_c3")          # plane width not a multiple of 16: im2col kernel
     hific.set_compute_dtype(torch.float32)
 
 
