@@ -966,6 +966,38 @@ __global__ __launch_bounds__(256) void d1_ctx_dot_kernel(const float* __restrict
     }
 }
 
+// Exact Generator chain: the sum of two float32-accurate activations that exist only as split-bf16 images (the head skip
+// `x + head` after the residual trunk, generator.py:161).  a3 / b3: (hi, lo, ..) images in layout la / lb (0 = 3C planes,
+// 2 = pair groups); writes the nominal bf16 sum y [N,C,HW] and its split image y3 in layout lo.
+__device__ __forceinline__ void split_offs(unsigned c, unsigned hw, unsigned C, unsigned C16, unsigned HW, int lay,
+                                           unsigned& oh, unsigned& ol, unsigned& per_n) {
+    if (lay == 2) { oh = (32u * (c >> 4) + (c & 15u)) * HW + hw; ol = oh + 16u * HW; per_n = 2u * C16 * HW; }
+    else { oh = c * HW + hw; ol = oh + C * HW; per_n = 3u * C * HW; }
+}
+__global__ __launch_bounds__(256) void add_split_kernel(const bf16_t* __restrict__ a3, const bf16_t* __restrict__ b3,
+                                                        bf16_t* __restrict__ y, bf16_t* __restrict__ y3, long long total,
+                                                        unsigned C, unsigned C16, unsigned HW, int la, int lb, int lo) {
+    const unsigned chw = C16 * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / chw;
+        const unsigned rem = (unsigned)(i - n * chw), c = rem / HW, hw = rem - c * HW;
+        unsigned oh, ol, pn;
+        if (c >= C) {                                   // zero padding channels of the pair layout's last 16-group
+            if (lo == 2) { split_offs(c, hw, C, C16, HW, 2, oh, ol, pn); y3[n * pn + oh] = 0; y3[n * pn + ol] = 0; }
+            continue;
+        }
+        split_offs(c, hw, C, C16, HW, la, oh, ol, pn);
+        float v = bf2f(a3[n * pn + oh]) + bf2f(a3[n * pn + ol]);
+        split_offs(c, hw, C, C16, HW, lb, oh, ol, pn);
+        v += bf2f(b3[n * pn + oh]) + bf2f(b3[n * pn + ol]);
+        const bf16_t h = f2bf(v), l = f2bf(v - bf2f(h));
+        y[(n * C + c) * HW + hw] = h;
+        split_offs(c, hw, C, C16, HW, lo, oh, ol, pn);
+        y3[n * pn + oh] = h; y3[n * pn + ol] = l;
+        if (lo != 2) y3[n * pn + oh + 2u * C * HW] = h;
+    }
+}
+
 extern "C" {
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
@@ -1058,6 +1090,18 @@ int hific_split3(const float* src, void* dst, long long outer, int C, long long 
         if (which == 0) hipLaunchKernelGGL((split3_kernel<float, 0>), EW_GRID(total), dim3(256), 0, st, src, (float*)dst, total, (unsigned)C, (unsigned)inner);
         else hipLaunchKernelGGL((split3_kernel<float, 1>), EW_GRID(total), dim3(256), 0, st, src, (float*)dst, total, (unsigned)C, (unsigned)inner);
     } else return HIFIC_ERR_ARG;
+    return hific_launch_status();
+}
+
+int hific_add_split(const void* a3, int la, const void* b3, int lb, void* y, void* y3, int lo, int N, int C, int HW,
+                    hipStream_t st) {
+    if (!a3 || !b3 || !y || !y3 || N <= 0 || C <= 0 || HW <= 0) return HIFIC_ERR_ARG;
+    if ((la != 0 && la != 2) || (lb != 0 && lb != 2) || (lo != 0 && lo != 2)) return HIFIC_ERR_ARG;
+    const long long C16 = ((long long)C + 15) / 16 * 16;
+    if ((long long)3 * C * HW >= (1ll << 31) || 2 * C16 * HW >= (1ll << 31)) return HIFIC_ERR_UNSUPPORTED;
+    const long long tot = (long long)N * C16 * HW;
+    hipLaunchKernelGGL(add_split_kernel, EW_GRID(tot), dim3(256), 0, st, (const bf16_t*)a3, (const bf16_t*)b3, (bf16_t*)y,
+                       (bf16_t*)y3, tot, (unsigned)C, (unsigned)C16, (unsigned)HW, la, lb, lo);
     return hific_launch_status();
 }
 

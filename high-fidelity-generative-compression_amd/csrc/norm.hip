@@ -285,12 +285,16 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_reg_kernel(const T* __restrict
 //   zb  bf16 [N,C,HW]   - bf16(z), saved for this norm's own backward (cn_bwd_reg_kernel<bf16>),
 // so the autograd graph of the chain is the plain bf16 one and no float32 activation is kept or re-read
 // (float32 norm + separate split pass: 18 bytes per element and a float32 backward; this: 14 and a bf16 backward).
-template <int PXB, int NW, int CPT>
+// RES (exact Generator chain, ResidualBlock generator.py:44 and nothing else): y = norm(z) + (rh + rl), the residual being read
+// from the (hi, lo, ..) split image r3 of the block's input (layout rpair: 0 = 3C planes, 1 = pair groups), so the float32-accurate
+// trunk value never exists as a float32 tensor.
+template <int PXB, int NW, int CPT, bool RES = false>
 __global__ __launch_bounds__(NW * 64) void cn_fwd_exact_kernel(const float* __restrict__ z, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, bf16_t* __restrict__ zb,
                                                                bf16_t* __restrict__ y, bf16_t* __restrict__ x3,
                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                               int C, int HW, float eps, int relu, int remap, int pair) {
+                                                               int C, int HW, float eps, int relu, int remap, int pair,
+                                                               const bf16_t* __restrict__ r3 = nullptr, int rpair = 0) {
     constexpr int SUBS = 64 / PXB, G = NW * SUBS;
     __shared__ float red[2][NW][PXB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -305,12 +309,19 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_exact_kernel(const float* __re
     bf16_t* yb = y + (size_t)n * C * HW;
     const int C16 = (C + 15) & ~15;
     bf16_t* x3b = x3 + (size_t)n * (pair ? 2 * C16 : 3 * C) * HW;
-    float v[CPT], gm[CPT], bt[CPT];
+    float v[CPT], gm[CPT], bt[CPT], rs[RES ? CPT : 1];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int c = g + G * k; const int ci = c < C ? c : C - 1;
         v[k] = xb[(unsigned)ci * (unsigned)HW + (unsigned)hw];
         gm[k] = gamma[ci]; bt[k] = beta[ci];
+        if constexpr (RES) {
+            const bf16_t* rb = r3 + (size_t)n * (rpair ? 2 * C16 : 3 * C) * HW;
+            const unsigned oh = rpair ? (unsigned)(32 * (ci >> 4) + (ci & 15)) * (unsigned)HW + (unsigned)hw
+                                      : (unsigned)ci * (unsigned)HW + (unsigned)hw;
+            const unsigned ol = oh + (rpair ? 16u * (unsigned)HW : (unsigned)C * (unsigned)HW);
+            rs[k] = bf2f(rb[oh]) + bf2f(rb[ol]);
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -340,6 +351,7 @@ __global__ __launch_bounds__(NW * 64) void cn_fwd_exact_kernel(const float* __re
         if (ok && c < C) {
             float o = gm[k] * ((v[k] - mu) * r) + bt[k];
             if (relu) o = o > 0.f ? o : 0.f;
+            if constexpr (RES) o += rs[k];
             const unsigned off = (unsigned)c * (unsigned)HW + (unsigned)hw;
             const bf16_t h = f2bf(o);
             const bf16_t l = f2bf(o - bf2f(h));
@@ -701,18 +713,26 @@ int hific_channelnorm_fwd(const void* x, const float* gamma, const float* beta, 
 // split_layout 0: x3 = (hi, lo, hi) over 3C channels; 2: the pair layout [N, 2 * C16, HW] of the native split kernels.
 // HIFIC_ERR_UNSUPPORTED when the shape has no register-resident configuration (the caller then runs the float32 norm and
 // hific_split3 instead).
-int hific_channelnorm_fwd_exact(const float* z, const float* gamma, const float* beta, void* zb, void* y, void* x3,
-                                float* mean, float* rstd, int N, int C, int HW, float eps, int relu, int split_layout,
-                                hipStream_t st) {
+static int cn_fwd_exact_launch(const float* z, const float* gamma, const float* beta, void* zb, void* y, void* x3,
+                               float* mean, float* rstd, int N, int C, int HW, float eps, int relu, int split_layout,
+                               const void* resid3, int resid_layout, hipStream_t st) {
     if (C < 2 || N <= 0 || HW <= 0 || !z || !zb || !y || !x3 || (split_layout != 0 && split_layout != 2)) return HIFIC_ERR_ARG;
+    if (resid3 && resid_layout != 0 && resid_layout != 2) return HIFIC_ERR_ARG;
     if ((long long)3 * C * HW >= (1ll << 31)) return HIFIC_ERR_UNSUPPORTED;
-    const int pair = split_layout == 2;
+    const int pair = split_layout == 2, rpair = resid_layout == 2;
     if (pair && (long long)2 * ((C + 15) / 16 * 16) * HW >= (1ll << 31)) return HIFIC_ERR_UNSUPPORTED;
     CnCfg cfg;
     if (!cn_pick(N, C, HW, cfg)) return HIFIC_ERR_UNSUPPORTED;
     dim3 rgrid(cdiv(HW, cfg.pxb), N);
-#define CN_FWD_X(PXB, NWV, CPT) hipLaunchKernelGGL((cn_fwd_exact_kernel<PXB, NWV, CPT>), rgrid, dim3(NWV * 64), 0, st, z, gamma, \
-                                       beta, (bf16_t*)zb, (bf16_t*)y, (bf16_t*)x3, mean, rstd, C, HW, eps, relu, cn_remap_flag(1), pair)
+#define CN_FWD_X(PXB, NWV, CPT)                                                                                                   \
+    do {                                                                                                                          \
+        if (resid3) hipLaunchKernelGGL((cn_fwd_exact_kernel<PXB, NWV, CPT, true>), rgrid, dim3(NWV * 64), 0, st, z, gamma, beta,   \
+                                       (bf16_t*)zb, (bf16_t*)y, (bf16_t*)x3, mean, rstd, C, HW, eps, relu, cn_remap_flag(1), pair, \
+                                       (const bf16_t*)resid3, rpair);                                                             \
+        else hipLaunchKernelGGL((cn_fwd_exact_kernel<PXB, NWV, CPT, false>), rgrid, dim3(NWV * 64), 0, st, z, gamma, beta,         \
+                                (bf16_t*)zb, (bf16_t*)y, (bf16_t*)x3, mean, rstd, C, HW, eps, relu, cn_remap_flag(1), pair,        \
+                                (const bf16_t*)nullptr, 0);                                                                       \
+    } while (0)
 #define CN_FWD_XC(CPT)                                                                    \
     do {                                                                                  \
         if (cfg.pxb == 64 && cfg.nw == 4) CN_FWD_X(64, 4, CPT);                           \
@@ -725,6 +745,21 @@ int hific_channelnorm_fwd_exact(const float* z, const float* gamma, const float*
 #undef CN_FWD_XC
 #undef CN_FWD_X
     return hific_launch_status();
+}
+
+int hific_channelnorm_fwd_exact(const float* z, const float* gamma, const float* beta, void* zb, void* y, void* x3,
+                                float* mean, float* rstd, int N, int C, int HW, float eps, int relu, int split_layout,
+                                hipStream_t st) {
+    return cn_fwd_exact_launch(z, gamma, beta, zb, y, x3, mean, rstd, N, C, HW, eps, relu, split_layout, nullptr, 0, st);
+}
+
+// The second norm of a ResidualBlock in the exact Generator chain: y = norm(z) + resid, resid given as the split image of the
+// block's input (resid_layout 0: (hi, lo, hi) over 3C channels, 2: pair layout); outputs as hific_channelnorm_fwd_exact.
+int hific_channelnorm_fwd_exact_res(const float* z, const float* gamma, const float* beta, const void* resid3, int resid_layout,
+                                    void* zb, void* y, void* x3, float* mean, float* rstd, int N, int C, int HW, float eps,
+                                    int relu, int split_layout, hipStream_t st) {
+    if (!resid3) return HIFIC_ERR_ARG;
+    return cn_fwd_exact_launch(z, gamma, beta, zb, y, x3, mean, rstd, N, C, HW, eps, relu, split_layout, resid3, resid_layout, st);
 }
 
 // ws: at least hific_channelnorm_bwd_ws_bytes(); dgamma/dbeta f32 [C]

@@ -34,6 +34,7 @@ SIGNATURES = {
     "hific_channelnorm_fwd": (I, [P, P, P, P, P, P, I, I, I, F, I, I, P]),
     "hific_channelnorm_fwd_res": (I, [P, P, P, P, P, P, P, I, I, I, F, I, I, P]),
     "hific_channelnorm_fwd_exact": (I, [P, P, P, P, P, P, P, P, I, I, I, F, I, I, P]),
+    "hific_channelnorm_fwd_exact_res": (I, [P, P, P, P, I, P, P, P, P, P, I, I, I, F, I, I, P]),
     "hific_channelnorm_bwd_ws_bytes": (Z, [I, I, I]),
     "hific_channelnorm_bwd": (I, [P] * 9 + [I, I, I, I, I, I, P, Z, P, I, P]),
     "hific_act_bwd": (I, [P, P, P, L, F, I, P]),
@@ -42,6 +43,7 @@ SIGNATURES = {
     "hific_scale_shift": (I, [P, P, L, F, F, I, P]),
     "hific_add": (I, [P, P, P, L, I, P]),
     "hific_cast": (I, [P, I, P, I, L, P]),
+    "hific_add_split": (I, [P, I, P, I, P, P, I, I, I, I, P]),
     "hific_split3": (I, [P, P, L, I, L, I, I, P]),
     "hific_axpby_f32": (I, [P, P, P, F, F, L, P]),
     "hific_channel_sum": (I, [P, P, I, I, I, I, I, P, Z, P]),

@@ -81,7 +81,7 @@ class Discriminator(nn.Module):
             x_gen = ops.cast_grad(x_gen, y.dtype)
         if x_real.dtype != y.dtype:
             x_real = ops.cast(x_real.contiguous(), y.dtype)
-        if ops.d1_stage_on():
+        if ops.d1_stage_on() and self._d1_stage_eligible(x_real, y):
             # input gather + first convolution as one autograd node: its backward never forms the 15-channel data gradient
             # (ops.D1StageFn)
             convs = (self.conv1, self.conv2, self.conv3, self.conv4)
@@ -95,6 +95,20 @@ class Discriminator(nn.Module):
             return self._trunk(x, sigs=sigs, first=1)
         x = ops.UpsamplePairConcatFn.apply(x_real.contiguous(), x_gen.contiguous(), y, self.upsample_factor)
         return self._trunk(x)
+
+    def _d1_stage_eligible(self, x_real, ctxt):
+        """ops.D1StageFn's backward (hific_d1_ctx_grad) exists for the reference's shape only: x16 upsampling, 64 output
+        channels, 12 context channels, at least two 16 x 16 cells per side (a 1-row latent is valid in the reference), a plane
+        that is a multiple of the cell and a workspace of 4 KiB per cell.  Everything else takes the two-node path
+        (UpsamplePairConcatFn + SNConv2d), whose backward handles any shape (the fused node used to be chosen
+        unconditionally and then failed in the middle of backward)."""
+        B, _, H, W = x_real.shape
+        f = self.upsample_factor
+        if not (f == 16 and self.conv1.weight_orig.shape[0] == 64 and ctxt.shape[1] == 12 and H % f == 0 and W % f == 0):
+            return False
+        if H // f < 2 or W // f < 2 or tuple(ctxt.shape[2:]) != (H // f, W // f):
+            return False
+        return lib.workspace(x_real.device).numel() >= B * (H // f) * (W // f) * 4096
 
     def _trunk(self, x, sigs=None, first=0):
         # one power iteration per spectral-norm layer and forward (torch.nn.utils.spectral_norm), the four layers per launch

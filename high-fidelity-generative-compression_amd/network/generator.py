@@ -88,7 +88,66 @@ class Generator(nn.Module):
     def _draw_noise(self, shape):
         return torch.randn(shape)
 
+    # ---- exact chain (round 6): float32-accurate forward values on a plain-bf16 autograd graph ---------------------------
+    def _exact_chain_ok(self, x):
+        """bf16 mode, ChannelNorm variant, no noise concat, and the exact-training option on - or the exact-reconstruction
+        option in a no-grad forward (Model.decompress / EVALUATION)."""
+        if not (x.is_cuda and ops.get_compute_dtype() == torch.bfloat16 and self.sample_noise is not True):
+            return False
+        if not (isinstance(self.conv_block_init[3], channel.ChannelNorm2D) and self.conv_block_out[1].exact_recon):
+            return False
+        if not ops.exact_generator_fused_on():
+            return False
+        on = ops.exact_training_on() or (ops.exact_reconstruction_on() and not torch.is_grad_enabled())
+        if not on:
+            return False
+        N, C, H, W = x.shape
+        planes = [(960, H, W), (480, 2 * H, 2 * W), (240, 4 * H, 4 * W), (120, 8 * H, 8 * W), (60, 16 * H, 16 * W)]
+        return ops.exact_chain_fits(planes)
+
+    def _forward_exact_chain(self, x):
+        """Every conv -> ChannelNorm block as ONE op (ops.ExactConvNormFn, as in the Encoder's exact-index chain): the
+        contraction reads the split-bf16 image of its input (x*w ~ xh*wh + xl*wh + xh*wl, float32 accumulate), the norm kernel
+        emits the nominal bf16 activation (what autograd stores and the backward pass reads), the next block's split image and
+        bf16(z) for its own backward; the residual stream and the head skip are added from the split images (hi + lo).  The
+        autograd graph - and so the whole backward pass - is the plain bf16 one; only the forward VALUES are float32-accurate
+        (reconstruction within north_star's 1e-3 of the reference Generator, generator.py:145-168)."""
+        S3, SP = ops.SPLIT_3C, ops.SPLIT_PAIR
+
+        def up_layout(conv):
+            return SP if (ops.exact_pair_on() and conv.in_channels >= 32) else S3
+        ups = [getattr(self, f'upconv_block{i + 1}') for i in range(4)]
+        up_lay = [up_layout(u[0]) for u in ups]
+        n0, conv0, norm0 = self.conv_block_init[0], self.conv_block_init[2], self.conv_block_init[3]
+        h = n0(x)                                               # float32 norm of the (float32) decoded latents
+        if h.dtype != torch.float32:
+            h = ops.cast_grad(h, torch.float32)
+        h3 = ops.split3_act(h, S3)
+        head, head3 = ops.exact_conv_norm(h, h3, conv0.weight, conv0.bias, 1, conv0.pads, conv0.hip_pad_mode, norm0.gamma,
+                                          norm0.beta, norm0.eps, norm0.fuse_relu, S3, S3)
+        head_res, head_skip = ops.fork(head)
+        h, h3 = head_res, head3
+        for m in range(self.n_residual_blocks):
+            blk = getattr(self, f'resblock_{m}')
+            c1, c2, n1, n2 = blk.conv1, blk.conv2, blk.norm1, blk.norm2
+            h_conv, h_id = ops.fork(h)
+            r, r3 = ops.exact_conv_norm(h_conv, h3, c1.weight, c1.bias, 1, c1.pads, c1.hip_pad_mode, n1.gamma, n1.beta, n1.eps,
+                                        n1.fuse_relu, S3, S3)
+            h, h3 = ops.exact_conv_norm(r, r3, c2.weight, c2.bias, 1, c2.pads, c2.hip_pad_mode, n2.gamma, n2.beta, n2.eps,
+                                        n2.fuse_relu, S3, S3, resid=h_id, resid3=h3, lay_res=S3)
+        h, h3 = ops.add_split(h, h3, S3, head_skip, head3, S3, up_lay[0])
+        for i, u in enumerate(ups):
+            ct, nm = u[0], u[1]
+            lay_next = up_lay[i + 1] if i + 1 < 4 else S3
+            h, h3 = ops.exact_conv_transpose_norm(h, h3, ct.weight, ct.bias, ct.stride[0], ct.padding[0], ct.output_padding[0],
+                                                  nm.gamma, nm.beta, nm.eps, nm.fuse_relu, up_lay[i], lay_next)
+        out = self.conv_block_out[1]
+        return ops.conv2d(h, out.weight, out.bias, stride=1, pads=out.pads, pad_mode=out.hip_pad_mode, out_f32=True,
+                          exact=True, x3=h3)
+
     def forward(self, x):
+        if self._exact_chain_ok(x):
+            return self._forward_exact_chain(x)
         head = self.conv_block_init(x)
         if self.sample_noise is True:
             # same draw as the reference: host RNG, then moved to the head's device / dtype (generator.py:149-152)

@@ -81,17 +81,17 @@ class WeightPackCache:
 
     def pin_all(self):
         """Pins every current entry on behalf of ONE graph (reference-counted: several captured graphs may share entries) and
-        returns (pins_broken, the pinned keys); the graph hands the keys back to unpin() when it is closed or collected."""
-        keys = list(self.entries.keys())
-        for k in keys:
-            e = self.entries[k]
+        returns (pins_broken, [(key, entry)]); the graph hands the pairs back to unpin() when it is closed or collected.
+        The pairs carry the entry OBJECTS: after clear() / a dead-entry sweep / an alias drop the same key can hold a fresh
+        entry that a newer graph pinned - an old graph's unpin must not release that one."""
+        pairs = list(self.entries.items())
+        for _, e in pairs:
             e.pinned = int(e.pinned) + 1
-        return self.pins_broken, keys
+        return self.pins_broken, pairs
 
-    def unpin(self, keys):
-        for k in keys:
-            e = self.entries.get(k)
-            if e is not None and e.pinned:
+    def unpin(self, pairs):
+        for k, e in pairs:
+            if self.entries.get(k) is e and e.pinned:
                 e.pinned = int(e.pinned) - 1
 
     def _drop(self, key):
@@ -349,6 +349,21 @@ def set_exact_training(on):
 
 def exact_training_on():
     return _EXACT_TRAIN
+
+
+# The Generator under the exact-training / exact-reconstruction options as ONE chain of fused conv -> norm blocks
+# (network/generator.py::_forward_exact_chain; round 6): float32-accurate forward values, bf16 stored activations, the plain
+# bf16 backward pass.  HIFIC_EXACT_GEN_FUSED=0: the round-5 form (float32 activations between separate conv / norm ops).
+_EXACT_GEN_FUSED = os.environ.get("HIFIC_EXACT_GEN_FUSED", "1") not in ("0", "")
+
+
+def exact_generator_fused_on():
+    return _EXACT_GEN_FUSED
+
+
+def set_exact_generator_fused(on):
+    global _EXACT_GEN_FUSED
+    _EXACT_GEN_FUSED = bool(on)
 
 
 class exact_index_suspended:
@@ -972,41 +987,67 @@ class ChannelNormFn(Function):
 
 
 class ExactConvNormFn(Function):
-    """One Encoder block of the exact-index chain with a plain-bf16 autograd graph:
-        (y, x3_next) = ChannelNorm[+ReLU]( conv_exact(x3; W) + b ).
-    `x` is the block's NOMINAL input (bf16 NCHW activation, or the float32 image) - saved for the weight gradient only;
-    `x3` is its split-bf16 image (hi, lo, hi) that the forward contraction really reads (hific_split3 layout, produced by
-    the previous block's norm kernel).  The convolution writes float32 z to a temporary; hific_channelnorm_fwd_exact turns
-    it into the nominal bf16 output y, the next block's x3 and bf16(z) for the norm's backward.  Backward = exactly what the
-    plain bf16 mode runs (ChannelNorm backward with the conv's bias gradient fused, data gradient, weight gradient on the
-    side stream): no float32 activation is stored, re-read or back-propagated."""
+    """One conv -> ChannelNorm[+ReLU][+residual] block of an exact chain with a plain-bf16 autograd graph:
+        (y, x3_next) = ChannelNorm[+ReLU]( conv_exact(x3; W) + b ) [+ resid].
+    `x` is the block's NOMINAL input (bf16 NCHW activation, or a float32 tensor) - saved for the weight gradient only;
+    `x3` is its split-bf16 image (hi, lo, hi) / pair layout that the forward contraction really reads (hific_split3 layout,
+    produced by the previous block's norm kernel).  The convolution writes float32 z to a temporary;
+    hific_channelnorm_fwd_exact turns it into the nominal bf16 output y, the next block's x3 and bf16(z) for the norm's
+    backward.  Backward = exactly what the plain bf16 mode runs (ChannelNorm backward with the conv's bias gradient fused,
+    data gradient, weight gradient on the side stream): no float32 activation is stored, re-read or back-propagated.
+    Used by the Encoder (exact-index chain, encoder.py:56-93) and, round 6, by the Generator under
+    ops.set_exact_training / set_exact_reconstruction (generator.py:9-44,115-137):
+      * geom of 3 entries (stride, pad, outpad): the convolution is an nn.ConvTranspose2d (weight [Cin, Cout, R, S]);
+      * resid / resid3: the residual of a ResidualBlock's second norm - `resid` the nominal tensor (autograd edge: its
+        gradient is dy), `resid3` its split image in layout `lay_res`, which the norm kernel adds as hi + lo."""
 
     @staticmethod
-    def forward(ctx, x, x3, weight, bias, geom, gamma, beta, eps, relu, lay_in=SPLIT_3C, lay_out=SPLIT_3C):
-        require_gpu(x, x3, weight, bias, gamma, beta)
-        stride, pt, pl, pb, pr, pad_mode = geom
+    def forward(ctx, x, x3, weight, bias, geom, gamma, beta, eps, relu, lay_in=SPLIT_3C, lay_out=SPLIT_3C, resid=None,
+                resid3=None, lay_res=SPLIT_3C):
+        require_gpu(x, x3, weight, bias, gamma, beta, resid, resid3)
+        transposed = len(geom) == 3
         N, C, H, W = x.shape
-        K, Cw, R, S = weight.shape
         Cx = pair_channels(C) if lay_in == SPLIT_PAIR else 3 * C
-        assert Cw == C and tuple(x3.shape) == (N, Cx, H, W) and x3.dtype == torch.bfloat16
-        OH = (H + pt + pb - R) // stride + 1
-        OW = (W + pl + pr - S) // stride + 1
-        z = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
-        w3 = split_weights.get(weight, transposed=False, layout=lay_in)
+        assert tuple(x3.shape) == (N, Cx, H, W) and x3.dtype == torch.bfloat16
         flags = _exact_flags(lay_in, C)
         wsp, wsb = _ws(x)
-        wc = _wcache(w3, 0, (N, Cx, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), HIFIC_BF16, flags & 0xff, None)
-        call("hific_conv2d_fwd", ptr(x3), ptr(w3), None, ptr(bias), None, ptr(z), N, Cx, H, W, K, R, S, stride, pt, pl, pb,
-             pr, pad_mode, lib.ACT_NONE, HIFIC_BF16, flags, wsp, wsb, *wc, stream())
+        w3 = split_weights.get(weight, transposed=transposed, layout=lay_in)
+        if transposed:
+            stride, pad, outpad = geom
+            Cw, K, R, S = weight.shape
+            assert Cw == C
+            OH = (H - 1) * stride - 2 * pad + R + outpad
+            OW = (W - 1) * stride - 2 * pad + S + outpad
+            z = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
+            wc = _wcache(w3, 0, (N, Cx, H, W, K, R, S, stride, pad, outpad), HIFIC_BF16, flags & 0xff, None, transposed=True)
+            call("hific_conv_transpose2d_fwd", ptr(x3), ptr(w3), ptr(bias), ptr(z), N, Cx, H, W, K, R, S, stride, pad,
+                 outpad, lib.ACT_NONE, HIFIC_BF16, flags, wsp, wsb, *wc, stream())
+        else:
+            stride, pt, pl, pb, pr, pad_mode = geom
+            K, Cw, R, S = weight.shape
+            assert Cw == C
+            OH = (H + pt + pb - R) // stride + 1
+            OW = (W + pl + pr - S) // stride + 1
+            z = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
+            wc = _wcache(w3, 0, (N, Cx, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), HIFIC_BF16, flags & 0xff, None)
+            call("hific_conv2d_fwd", ptr(x3), ptr(w3), None, ptr(bias), None, ptr(z), N, Cx, H, W, K, R, S, stride, pt, pl, pb,
+                 pr, pad_mode, lib.ACT_NONE, HIFIC_BF16, flags, wsp, wsb, *wc, stream())
         zb = torch.empty((N, K, OH, OW), dtype=torch.bfloat16, device=x.device)
         y = torch.empty_like(zb)
         Kx = pair_channels(K) if lay_out == SPLIT_PAIR else 3 * K
         x3n = torch.empty((N, Kx, OH, OW), dtype=torch.bfloat16, device=x.device)
         mean = torch.empty((N, OH * OW), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        call("hific_channelnorm_fwd_exact", ptr(z), ptr(gamma), ptr(beta), ptr(zb), ptr(y), ptr(x3n), ptr(mean), ptr(rstd),
-             N, K, OH * OW, float(eps), int(relu), lay_out, stream())
-        ctx.geom, ctx.relu, ctx.has_bias = geom, int(relu), bias is not None
+        if resid3 is not None:
+            Kr = pair_channels(K) if lay_res == SPLIT_PAIR else 3 * K
+            assert tuple(resid3.shape) == (N, Kr, OH, OW) and resid3.dtype == torch.bfloat16
+            call("hific_channelnorm_fwd_exact_res", ptr(z), ptr(gamma), ptr(beta), ptr(resid3), lay_res, ptr(zb), ptr(y),
+                 ptr(x3n), ptr(mean), ptr(rstd), N, K, OH * OW, float(eps), int(relu), lay_out, stream())
+        else:
+            call("hific_channelnorm_fwd_exact", ptr(z), ptr(gamma), ptr(beta), ptr(zb), ptr(y), ptr(x3n), ptr(mean), ptr(rstd),
+                 N, K, OH * OW, float(eps), int(relu), lay_out, stream())
+        ctx.geom, ctx.relu, ctx.has_bias, ctx.transposed = geom, int(relu), bias is not None, transposed
+        ctx.has_resid = resid is not None
         ctx.w_slot, ctx.b_slot, ctx.g_slot, ctx.be_slot = _slot(weight), _slot(bias), _slot(gamma), _slot(beta)
         ctx.save_for_backward(x, weight, zb, gamma, beta, mean, rstd)
         ctx.mark_non_differentiable(x3n)
@@ -1018,11 +1059,15 @@ class ExactConvNormFn(Function):
     @staticmethod
     def backward(ctx, dy, _unused):
         if dy is None:
-            return (None,) * 11
+            return (None,) * 14
         x, weight, zb, gamma, beta, mean, rstd = ctx.saved_tensors
-        stride, pt, pl, pb, pr, pad_mode = ctx.geom
         N, C, H, W = x.shape
-        K, _, R, S = weight.shape
+        if ctx.transposed:
+            stride, pad, outpad = ctx.geom
+            _, K, R, S = weight.shape
+        else:
+            stride, pt, pl, pb, pr, pad_mode = ctx.geom
+            K, _, R, S = weight.shape
         OH, OW = zb.shape[2], zb.shape[3]
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
@@ -1049,16 +1094,25 @@ class ExactConvNormFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             flags = (_is_f32(dx) << 1)
-            wc = _wcache(weight, 1, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None)
-            call("hific_conv2d_bwd_data", ptr(dz), ptr(weight), None, ptr(dx), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
-                 pad_mode, cd, flags, wsp, wsb, *wc, stream())
+            if ctx.transposed:
+                wc = _wcache(weight, 1, (N, C, H, W, K, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
+                call("hific_conv_transpose2d_bwd_data", ptr(dz), ptr(weight), ptr(dx), N, C, H, W, K, R, S, stride, pad,
+                     outpad, cd, flags, wsp, wsb, *wc, stream())
+            else:
+                wc = _wcache(weight, 1, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None)
+                call("hific_conv2d_bwd_data", ptr(dz), ptr(weight), None, ptr(dx), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                     pad_mode, cd, flags, wsp, wsb, *wc, stream())
 
         def wgrad():
             nonlocal dw
             wsp_, wsb_ = _ws(x)
             dwt, acc, dw = _grad_target(ctx.w_slot, weight)
-            call("hific_conv2d_bwd_weight", ptr(x), ptr(dz), ptr(dwt), N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode,
-                 acc, cd, _is_f32(x), wsp_, wsb_, stream())
+            if ctx.transposed:
+                call("hific_conv_transpose2d_bwd_weight", ptr(x), ptr(dz), ptr(dwt), N, C, H, W, K, R, S, stride, pad, outpad,
+                     acc, cd, _is_f32(x), wsp_, wsb_, stream())
+            else:
+                call("hific_conv2d_bwd_weight", ptr(x), ptr(dz), ptr(dwt), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                     pad_mode, acc, cd, _is_f32(x), wsp_, wsb_, stream())
         if want_w:
             if side:
                 with _SideLaunch(ev, x, dz, key=ctx.w_slot):
@@ -1066,13 +1120,52 @@ class ExactConvNormFn(Function):
             else:
                 wgrad()
         _written(ctx.w_slot if want_w else None)
-        return dx, None, dw, db, None, dg, dbe, None, None, None, None
+        return dx, None, dw, db, None, dg, dbe, None, None, None, None, (dy if ctx.has_resid else None), None, None
 
 
-def exact_conv_norm(x, x3, weight, bias, stride, pads, pad_mode, gamma, beta, eps, relu, lay_in=SPLIT_3C, lay_out=SPLIT_3C):
+def exact_conv_norm(x, x3, weight, bias, stride, pads, pad_mode, gamma, beta, eps, relu, lay_in=SPLIT_3C, lay_out=SPLIT_3C,
+                    resid=None, resid3=None, lay_res=SPLIT_3C):
     pt, pl, pb, pr = pads
     return ExactConvNormFn.apply(x.contiguous(), x3, weight, bias, (stride, pt, pl, pb, pr, pad_mode), gamma, beta, eps, relu,
-                                 lay_in, lay_out)
+                                 lay_in, lay_out, resid, resid3, lay_res)
+
+
+def exact_conv_transpose_norm(x, x3, weight, bias, stride, pad, outpad, gamma, beta, eps, relu, lay_in=SPLIT_3C,
+                              lay_out=SPLIT_3C):
+    """The up-convolution blocks of the exact Generator chain (generator.py:115-137): nn.ConvTranspose2d -> ChannelNorm -> ReLU."""
+    return ExactConvNormFn.apply(x.contiguous(), x3, weight, bias, (stride, pad, outpad), gamma, beta, eps, relu, lay_in,
+                                 lay_out, None, None, SPLIT_3C)
+
+
+class AddSplitFn(Function):
+    """(y, y3) = a + b for two activations of an exact chain: the sum is formed from the split images (hi + lo each), so it is
+    float32-accurate; `a` / `b` are the nominal tensors (autograd edges only: both receive dy)."""
+
+    @staticmethod
+    def forward(ctx, a, a3, la, b, b3, lb, lo):
+        require_gpu(a, a3, b, b3)
+        N, C, H, W = a.shape
+        assert a.shape == b.shape
+        y = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=a.device)
+        Cy = pair_channels(C) if lo == SPLIT_PAIR else 3 * C
+        y3 = torch.empty((N, Cy, H, W), dtype=torch.bfloat16, device=a.device)
+        call("hific_add_split", ptr(a3), la, ptr(b3), lb, ptr(y), ptr(y3), lo, N, C, H * W, stream())
+        ctx.dts = (a.dtype, b.dtype)
+        ctx.mark_non_differentiable(y3)
+        ctx.set_materialize_grads(False)
+        return y, y3
+
+    @staticmethod
+    def backward(ctx, g, _unused):
+        if g is None:
+            return (None,) * 7
+        ga = g if g.dtype == ctx.dts[0] else cast(g, ctx.dts[0])
+        gb = g if g.dtype == ctx.dts[1] else cast(g, ctx.dts[1])
+        return ga, None, None, gb, None, None, None
+
+
+def add_split(a, a3, la, b, b3, lb, lo):
+    return AddSplitFn.apply(a, a3, la, b, b3, lb, lo)
 
 
 def split3_act(x, layout=SPLIT_3C):

@@ -101,6 +101,13 @@ int hific_channelnorm_fwd_res(const void* x, const float* gamma, const float* be
 int hific_channelnorm_fwd_exact(const float* z, const float* gamma, const float* beta, void* zb, void* y, void* x3,
                                 float* mean, float* rstd, int N, int C, int HW, float eps, int relu, int split_layout,
                                 hipStream_t stream);
+/* The second norm of a ResidualBlock inside the exact Generator chain (src/network/generator.py:37-44 in bf16 mode with
+ * ops.set_exact_training / set_exact_reconstruction): y = norm(z) + resid, the residual read as hi + lo from the split image
+ * resid3 of the block's input (resid_layout 0: (hi, lo, hi) over 3C channels, 2: pair layout) so that the float32-accurate
+ * trunk value never exists as a float32 tensor; outputs and return codes as hific_channelnorm_fwd_exact. */
+int hific_channelnorm_fwd_exact_res(const float* z, const float* gamma, const float* beta, const void* resid3, int resid_layout,
+                                    void* zb, void* y, void* x3, float* mean, float* rstd, int N, int C, int HW, float eps,
+                                    int relu, int split_layout, hipStream_t stream);
 size_t hific_channelnorm_bwd_ws_bytes(int N, int C, int HW);
 /* dprev_bias (nullable, f32 [C]): additionally (=|+= by accumulate_prev) sum_{n,hw} dx, i.e. the bias gradient of the
  * convolution whose output is x when this norm is its only consumer (encoder.py:56-93, generator.py:28-42,115-137): saves
@@ -130,6 +137,11 @@ int hific_cast(const void* a, int src_dtype, void* o, int dst_dtype, long long n
  * source channel 16 g + j -> channels 32 g + j (hi) and 32 g + 16 + j (lo), padding channels zero; activations and weights
  * alike.  A convolution whose flags carry bit 3 reads both operands in this layout and issues hi*hi + hi*lo + lo*hi per
  * 16-channel slice pair itself: 2C instead of 3C staged channels for the same three MFMAs. */
+/* Sum of two activations held as split-bf16 images (the head skip of the exact Generator chain, src/network/generator.py:161):
+ * y3 (layout lo) and the nominal bf16 y [N,C,HW] of (a_hi + a_lo) + (b_hi + b_lo); layouts 0 = (hi, lo, hi) over 3C channels,
+ * 2 = pair layout. */
+int hific_add_split(const void* a3, int la, const void* b3, int lb, void* y, void* y3, int lo, int N, int C, int HW,
+                    hipStream_t stream);
 int hific_split3(const float* src, void* dst, long long outer, int C, long long inner, int which, int dst_dtype,
                  hipStream_t stream);
 int hific_axpby_f32(const float* a, const float* b, float* o, float alpha, float beta, long long n,

@@ -231,6 +231,32 @@ def test_discriminator_pair_input_equals_cat_and_repeat_interleave(hific, dev, s
     hific.set_compute_dtype(torch.float32)
 
 
+def test_discriminator_pair_input_on_a_one_row_latent_takes_the_two_node_path(hific, dev, sd):
+    """16 x N crops (a 1-row latent) are valid in the reference; hific_d1_ctx_grad has no kernel for them, so
+    forward_pairs must not choose the fused input stage there - forward AND backward run, equal to the cat / repeat path."""
+    from hific_amd.network.discriminator import Discriminator
+    hific.set_compute_dtype(torch.float32)
+    D = _load(Discriminator((3, 16, 64), (220, 1, 4), C=220), sd, "Discriminator.").to(dev).eval()
+    B = 2
+    real = O.make_image(9, B, 16, 64).to(dev)
+    gen0 = O.make_image(12, B, 16, 64).to(dev)
+    lat = (O.make_noise(10, (B, 220, 1, 4)) * 4).to(dev)
+    assert not D._d1_stage_eligible(real, torch.empty(B, 12, 1, 4, device=dev))
+    assert D._d1_stage_eligible(torch.empty(B, 3, 64, 64, device=dev), torch.empty(B, 12, 4, 4, device=dev))
+    res = []
+    for mode in ("cat", "pair"):
+        D.zero_grad()
+        gen = gen0.clone().requires_grad_(True)
+        if mode == "cat":
+            out, logits = D(torch.cat([real, gen], dim=0), torch.repeat_interleave(lat, 2, dim=0))
+        else:
+            out, logits = D.forward_pairs(real, gen, lat)
+        logits.sum().backward()
+        torch.cuda.synchronize()
+        res.append((logits.detach().clone(), gen.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 64), (3, 32, 512), (1, 256, 256)], ids=["64x64", "32x512_segments", "256x256"])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_context_gradient_through_first_discriminator_conv(hific, dev, shape, dt):

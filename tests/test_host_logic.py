@@ -265,3 +265,33 @@ def test_arena_slots_written_by_autograd_are_tracked(hific):
         assert torch.allclose(arena.slots[0].grad, gw, atol=1e-4)
         arena.zero_grad()
         assert all(s.fresh for s in arena.slots)
+
+
+def test_pack_cache_unpin_releases_only_the_entries_that_graph_pinned(hific):
+    """graph A pins the cache, the cache is cleared (A is invalidated), the same keys are re-created and
+    pinned by graph B; closing / collecting A must not release B's pins (it used to identify entries by key)."""
+    from hific_amd import ops
+
+    def entry():
+        e = ops._PackEntry()
+        e.pinned, e.last_use = False, 0
+        return e
+    pc = ops.WeightPackCache()
+    pc.entries = {("k", i): entry() for i in range(3)}
+    broken_a, pins_a = pc.pin_all()                       # graph A
+    assert all(e.pinned == 1 for e in pc.entries.values())
+    pc.clear()                                            # what makes the user re-capture
+    assert pc.pins_broken == broken_a + 1
+    pc.entries = {("k", i): entry() for i in range(3)}    # same keys, fresh entries
+    broken_b, pins_b = pc.pin_all()                       # graph B
+    pc.unpin(pins_a)                                      # `del A` -> GraphedStep.close()
+    assert all(e.pinned == 1 for e in pc.entries.values()), "graph A's unpin released graph B's entries"
+    assert pc.pins_broken == broken_b                     # B stays replayable
+    pc.unpin(pins_b)
+    assert all(e.pinned == 0 for e in pc.entries.values())
+    # two graphs sharing live entries: reference-counted
+    _, p1 = pc.pin_all(); _, p2 = pc.pin_all()
+    pc.unpin(p1)
+    assert all(e.pinned == 1 for e in pc.entries.values())
+    pc.unpin(p2)
+    assert not any(e.pinned for e in pc.entries.values())
