@@ -2,9 +2,49 @@
 #include "gconv.h"
 #include <string.h>
 
+#include <mutex>
+#include <stdlib.h>
+
+// ---- ticket buffers (common.h "tickets"): stream -> caller-owned zeroed counters ---------------------------------------------
+namespace {
+struct TicketSlot { hipStream_t st; unsigned* buf; int n; };
+TicketSlot g_tickets[64];
+int g_ntickets = 0;
+std::mutex g_ticket_mu;
+int g_tickets_on = -1;
+}
+unsigned* hific_tickets(hipStream_t st, int need) {
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    if (g_tickets_on < 0) { const char* e = getenv("HIFIC_TICKETS"); g_tickets_on = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_tickets_on) return nullptr;
+    for (int i = 0; i < g_ntickets; ++i)
+        if (g_tickets[i].st == st) return g_tickets[i].n >= need ? g_tickets[i].buf : nullptr;
+    return nullptr;
+}
+
 extern "C" {
 
 int hific_version(void) { return 100; }
+
+// Registers (buf != NULL) or removes (buf == NULL) the ticket counters of `stream`: `bytes` / 4 unsigned counters in device
+// memory, ZERO when registered, owned by the caller and valid until removed.  See include/hific_hip.h.
+int hific_set_ticket_buffer(hipStream_t stream, void* buf, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    g_tickets_on = -1;                                   // re-read HIFIC_TICKETS (tests flip it)
+    int at = -1;
+    for (int i = 0; i < g_ntickets; ++i) if (g_tickets[i].st == stream) at = i;
+    if (!buf) {
+        if (at >= 0) g_tickets[at] = g_tickets[--g_ntickets];
+        return HIFIC_OK;
+    }
+    if (((size_t)buf & 3) != 0 || bytes < 4) return HIFIC_ERR_ARG;
+    if (at < 0) {
+        if (g_ntickets >= 64) return HIFIC_ERR_UNSUPPORTED;
+        at = g_ntickets++;
+    }
+    g_tickets[at] = TicketSlot{stream, (unsigned*)buf, (int)(bytes / 4)};
+    return HIFIC_OK;
+}
 
 // Returns 0 and fills (name[<=63], CU count, LDS bytes/CU) for the given device; never throws.
 int hific_device_info(int device, char* name, int* cus, int* lds_per_cu) {

@@ -64,6 +64,45 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- tickets: the last-arriving workgroup of a launch finishes a two-stage reduction inside the same launch ----------------
+// A two-stage reduction (partials per workgroup -> one tiny reduce launch) costs a second launch of 4-7 us for a few KB of
+// work: ~120 such launches per training cycle.  With a ticket - an unsigned counter in device memory, zero between launches -
+// every workgroup publishes its partials, takes a ticket, and the workgroup that draws the last one performs the second
+// stage (same summation order as the separate kernel where noted: bit-identical results).
+// Memory model on gfx950 (8 XCDs, one L2 each, not coherent with each other for ordinary accesses): an agent-scope
+// release / acquire FENCE (`__threadfence()`) is `buffer_wbl2` / `buffer_inv` - a write-back / invalidate of the XCD's WHOLE L2;
+// issued once per workgroup next to kernels that stream hundreds of MB it cost the training cycle +9 ms (measured, round 6).
+// So no fences: the PARTIALS travel by agent-scope atomic stores and loads (hific_st_agent / hific_ld_agent: write-through /
+// read-through at the device coherence point, nothing else is flushed), each wave waits for its stores' acknowledgements
+// (s_waitcnt vmcnt(0)) before the barrier, and only then does thread 0 take the ticket (agent-scope atomic).  Nothing else crosses workgroups inside the launch; the results the last workgroup writes become visible at the end
+// of the kernel like any other output.
+// Counters live in a caller-owned, zero-initialised buffer registered per stream (hific_set_ticket_buffer): kernels of one
+// stream run one after another, so one buffer per stream suffices; without a registered buffer every entry point keeps its
+// two-launch form.  A kernel resets the counters it used (the last workgroup stores 0) - the buffer stays zero between launches.
+__device__ __forceinline__ float hific_ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hific_st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool hific_last_block(unsigned* ticket, unsigned nblocks) {
+    __shared__ unsigned hific_tk_last;
+    // this wave's partial stores are acknowledged by the coherence point before anyone takes the ticket: a workgroup-scope
+    // release fence emits no vmcnt wait on gfx950 (checked in the ISA), so the wait is explicit: vmcnt(0), other counters free
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = (t + 1u == nblocks) ? 1u : 0u;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hific_tk_last = last;
+    }
+    __syncthreads();
+    return hific_tk_last != 0u;
+}
+// host side (capi.hip): the ticket counters registered for `st`, or nullptr (then: two launches); `need` counters
+unsigned* hific_tickets(hipStream_t st, int need);
+
 static inline int hific_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? HIFIC_OK : HIFIC_ERR_LAUNCH;

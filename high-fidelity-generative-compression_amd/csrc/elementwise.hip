@@ -21,6 +21,24 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     return r;
 }
 
+// second stage of a scalar reduction, run by the last-arriving workgroup of the partial kernel (common.h "tickets"): the same
+// summation order as final_sum_kernel
+__device__ __forceinline__ void final_sum_tail(const float* part, int n, float mul, float* out, float* sh) {
+    float s = 0.f;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {            // independent loads (n <= 1024: one batch)
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = hific_ld_agent(part + (i0 + 256 * j < n ? i0 + 256 * j : 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += i0 + 256 * j < n ? v[j] : 0.f;
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) *out = s * mul;
+}
+#define TICKET_TAIL_ARGS unsigned* ticket, float tk_mul, float* tk_out
+#define TICKET_TAIL(part, sh) \
+    do { if (ticket && hific_last_block(ticket, gridDim.x)) final_sum_tail(part, (int)gridDim.x, tk_mul, tk_out, sh); } while (0)
+
 template <typename T>
 __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long long n,
                                float slope) {
@@ -79,7 +97,7 @@ __global__ void axpby_kernel(const float* __restrict__ a, const float* __restric
 // part[split][c] = sum over a slice of (n, hw) of x[n][c][hw]
 template <typename T>
 __global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, float* __restrict__ part, int N, int C,
-                                                       int HW, int nsplit) {
+                                                       int HW, int nsplit, unsigned* ticket, float* out, int accumulate) {
     // block (c, split): the split owns a contiguous slice of the HW axis of every image (no per-element division)
     __shared__ float sh[4];
     const int c = blockIdx.x, split = blockIdx.y;
@@ -102,7 +120,22 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, 
         }
     }
     s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) part[(size_t)split * C + c] = s;
+    if (threadIdx.x == 0) hific_st_agent(part + (size_t)split * C + c, s);
+    if (ticket && hific_last_block(ticket, gridDim.x * gridDim.y)) {
+        // second stage (chan_sum_reduce_kernel's sums, same order) by the last-arriving workgroup
+        // (loads in independent batches of 8: a dependent chain of agent-scope loads costs a memory round trip each)
+        for (int cc = threadIdx.x; cc < C; cc += 256) {
+            float t = 0.f;
+            for (int sp0 = 0; sp0 < nsplit; sp0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = hific_ld_agent(part + (size_t)(sp0 + j < nsplit ? sp0 + j : 0) * C + cc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t += sp0 + j < nsplit ? v[j] : 0.f;
+            }
+            if (accumulate) out[cc] += t; else out[cc] = t;
+        }
+    }
 }
 __global__ void chan_sum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nsplit,
                                        int accumulate) {
@@ -210,12 +243,13 @@ __global__ void scale_shift_kernel(const T* __restrict__ x, T* __restrict__ y, l
 // ---- squared-error sum: part[b] = sum (s*a - s*b)^2 ; final = sum(part) -----------------------------
 template <typename TA>
 __global__ __launch_bounds__(256) void sqdiff_partial_kernel(const TA* __restrict__ a, const float* __restrict__ b,
-                                                             float* __restrict__ part, long long n, float scale) {
+                                                             float* __restrict__ part, long long n, float scale, TICKET_TAIL_ARGS) {
     __shared__ float sh[4];
     float s = 0.f;
     EW_LOOP(i, n) { const float d = scale * DT<TA>::ld(a + i) - scale * b[i]; s += d * d; }
     s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (threadIdx.x == 0) hific_st_agent(part + blockIdx.x, s);
+    TICKET_TAIL(part, sh);
 }
 __global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ part, int n, float mul,
                                                         float* __restrict__ out) {
@@ -235,7 +269,7 @@ __global__ void sqdiff_bwd_kernel(const TA* __restrict__ a, const float* __restr
 
 // ---- BCE with logits against a constant target, mean over n ----------------------------------------
 __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ z, float target,
-                                                          float* __restrict__ part, long long n) {
+                                                          float* __restrict__ part, long long n, TICKET_TAIL_ARGS) {
     __shared__ float sh[4];
     float s = 0.f;
     EW_LOOP(i, n) {
@@ -243,7 +277,8 @@ __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restric
         s += fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
     }
     s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (threadIdx.x == 0) hific_st_agent(part + blockIdx.x, s);
+    TICKET_TAIL(part, sh);
 }
 // dz (=|+=) g * (sigmoid(z) - target)/n
 __global__ void bce_bwd_kernel(const float* __restrict__ z, float target, const float* __restrict__ g,
@@ -256,12 +291,13 @@ __global__ void bce_bwd_kernel(const float* __restrict__ z, float target, const 
 }
 // ---- least-squares GAN term on the sigmoid output: mean over n of (sigmoid(z) - target)^2 ----------
 __global__ __launch_bounds__(256) void lsq_partial_kernel(const float* __restrict__ z, float target,
-                                                          float* __restrict__ part, long long n) {
+                                                          float* __restrict__ part, long long n, TICKET_TAIL_ARGS) {
     __shared__ float sh[4];
     float s = 0.f;
     EW_LOOP(i, n) { const float d = 1.f / (1.f + expf(-z[i])) - target; s += d * d; }
     s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (threadIdx.x == 0) hific_st_agent(part + blockIdx.x, s);
+    TICKET_TAIL(part, sh);
 }
 // dz (=|+=) g * 2 (s - target) s (1 - s) / n,  s = sigmoid(z)
 __global__ void lsq_bwd_kernel(const float* __restrict__ z, float target, const float* __restrict__ g,
@@ -547,22 +583,29 @@ __global__ __launch_bounds__(256) void sn_wv_batch_kernel(const SnJobs J) {
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) q.tmpK[k] = s;
 }
-__global__ __launch_bounds__(256) void sn_sigma_batch_kernel(const SnJobs J) {
+__global__ __launch_bounds__(256) void sn_sigma_batch_kernel(const SnJobs J, int snap) {
     const SnJob& q = J.j[blockIdx.x];
     __shared__ float sh[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < q.K; i += 256) s += q.u[i] * q.tmpK[i];
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) { q.sig[0] = s; q.sig[1] = 1.f / s; }
+    if (snap) {
+        // the post-iteration (u, v) this forward's backward needs, behind sigma: the next forward iterates u, v in place
+        // (torch's spectral_norm clones them for the same reason); 8 small device copies per Discriminator forward otherwise
+        for (int i = threadIdx.x; i < q.K; i += 256) q.sig[2 + i] = q.u[i];
+        for (int i = threadIdx.x; i < q.M; i += 256) q.sig[2 + q.K + i] = q.v[i];
+    }
 }
 // backward: dWorig = (dW - (sum dW*Worig)/sigma * u v^T) / sigma
 __global__ __launch_bounds__(256) void sn_dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                             float* __restrict__ part, long long n) {
+                                                             float* __restrict__ part, long long n, TICKET_TAIL_ARGS) {
     __shared__ float sh[4];
     float s = 0.f;
     EW_LOOP(i, n) s += a[i] * b[i];
     s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (threadIdx.x == 0) hific_st_agent(part + blockIdx.x, s);
+    TICKET_TAIL(part, sh);
 }
 __global__ void sn_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ u, const float* __restrict__ v,
                               const float* __restrict__ sigma, const float* __restrict__ dot,
@@ -998,6 +1041,37 @@ __global__ __launch_bounds__(256) void add_split_kernel(const bf16_t* __restrict
     }
 }
 
+// ---- the scalar loss composition of one training forward as ONE launch (src/model.py:211-220 + :373-376, src/loss/losses.py:8-28)
+//   perceptual = mean_b lp[b];  penalty = q > target ? lambda_A : lambda_B
+//   total = ((penalty * nbpp + k_M * mse) + k_P * perceptual) [+ beta * g_loss]          (the reference's order of additions)
+// aux[0..3] = perceptual, penalty, penalty * nbpp, k_M * mse (logging + backward).  ~12 zero-dimensional ATen launches
+// (mean, mul, add, gt, where, full_like) and as many autograd nodes per forward otherwise.
+__global__ void loss_combine_fwd_kernel(const float* __restrict__ mse, const float* __restrict__ lp, int B,
+                                        const float* __restrict__ nbpp, const float* __restrict__ q,
+                                        const float* __restrict__ g_loss, float kM, float kP, float lamA, float lamB,
+                                        float target, float beta, float* __restrict__ total, float* __restrict__ aux) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sp = 0.f;
+    for (int b = 0; b < B; ++b) sp += lp[b];
+    const float perc = sp / (float)B;
+    const float pen = *q > target ? lamA : lamB;
+    const float wr = pen * *nbpp, wd = kM * *mse;
+    float t = (wr + wd) + kP * perc;
+    if (g_loss) t = t + beta * *g_loss;
+    *total = t;
+    aux[0] = perc; aux[1] = pen; aux[2] = wr; aux[3] = wd;
+}
+// grads[0] = d total / d mse * g, [1] = .. / d nbpp, [2] = .. / d g_loss, [3 + b] = .. / d lp[b]
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ g, const float* __restrict__ aux, int B, float kM, float kP,
+                                        float beta, float* __restrict__ grads) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float gg = *g;
+    if (i == 0) grads[0] = kM * gg;
+    else if (i == 1) grads[1] = aux[1] * gg;
+    else if (i == 2) grads[2] = beta * gg;
+    else if (i < 3 + B) grads[i] = kP * gg / (float)B;
+}
+
 extern "C" {
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
@@ -1105,6 +1179,21 @@ int hific_add_split(const void* a3, int la, const void* b3, int lb, void* y, voi
     return hific_launch_status();
 }
 
+int hific_loss_combine_fwd(const float* mse, const float* lp, int B, const float* nbpp, const float* q, const float* g_loss,
+                           float kM, float kP, float lamA, float lamB, float target, float beta, float* total, float* aux,
+                           hipStream_t st) {
+    if (!mse || !lp || B <= 0 || !nbpp || !q || !total || !aux) return HIFIC_ERR_ARG;
+    hipLaunchKernelGGL(loss_combine_fwd_kernel, dim3(1), dim3(64), 0, st, mse, lp, B, nbpp, q, g_loss, kM, kP, lamA, lamB, target,
+                       beta, total, aux);
+    return hific_launch_status();
+}
+int hific_loss_combine_bwd(const float* g, const float* aux, int B, float kM, float kP, float beta, float* grads,
+                           hipStream_t st) {
+    if (!g || !aux || B <= 0 || !grads) return HIFIC_ERR_ARG;
+    hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(cdiv(3 + B, 64)), dim3(64), 0, st, g, aux, B, kM, kP, beta, grads);
+    return hific_launch_status();
+}
+
 int hific_axpby_f32(const float* a, const float* b, float* o, float alpha, float beta, long long n, hipStream_t st) {
     hipLaunchKernelGGL(axpby_kernel, EW_GRID(n), dim3(256), 0, st, a, b, o, alpha, beta, n);
     return hific_launch_status();
@@ -1118,10 +1207,11 @@ int hific_channel_sum(const void* x, float* out, int N, int C, int HW, int accum
     if (nsplit < 1) nsplit = 1;
     if ((size_t)nsplit * C * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
     float* part = (float*)ws;
+    unsigned* tk = hific_tickets(st, 1);
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(chan_sum_kernel<float>, dim3(C, nsplit), dim3(256), 0, st, (const float*)x, part, N, C, HW, nsplit),
-        hipLaunchKernelGGL(chan_sum_kernel<bf16_t>, dim3(C, nsplit), dim3(256), 0, st, (const bf16_t*)x, part, N, C, HW, nsplit));
-    hipLaunchKernelGGL(chan_sum_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, out, C, nsplit, accumulate);
+        hipLaunchKernelGGL(chan_sum_kernel<float>, dim3(C, nsplit), dim3(256), 0, st, (const float*)x, part, N, C, HW, nsplit, tk, out, accumulate),
+        hipLaunchKernelGGL(chan_sum_kernel<bf16_t>, dim3(C, nsplit), dim3(256), 0, st, (const bf16_t*)x, part, N, C, HW, nsplit, tk, out, accumulate));
+    if (!tk) hipLaunchKernelGGL(chan_sum_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, out, C, nsplit, accumulate);
     return hific_launch_status();
 }
 
@@ -1168,10 +1258,12 @@ int hific_mse_fwd(const void* a, const float* b, float* out, long long n, float 
     const int nb = 1024;
     if (ws_bytes < nb * sizeof(float)) return HIFIC_ERR_WS;
     float* part = (float*)ws;
+    unsigned* tk = hific_tickets(st, 1);
+    const float mul = 1.f / (float)n;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(sqdiff_partial_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a, b, part, n, scale),
-        hipLaunchKernelGGL(sqdiff_partial_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a, b, part, n, scale));
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f / (float)n, out);
+        hipLaunchKernelGGL(sqdiff_partial_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a, b, part, n, scale, tk, mul, out),
+        hipLaunchKernelGGL(sqdiff_partial_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a, b, part, n, scale, tk, mul, out));
+    if (!tk) hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, mul, out);
     return hific_launch_status();
 }
 // da = (*g) * 2*scale^2*(a-b)/n
@@ -1189,8 +1281,9 @@ int hific_bce_fwd(const float* z, float target, float* out, long long n, void* w
     const int nb = 256;
     if (ws_bytes < nb * sizeof(float)) return HIFIC_ERR_WS;
     float* part = (float*)ws;
-    hipLaunchKernelGGL(bce_partial_kernel, dim3(nb), dim3(256), 0, st, z, target, part, n);
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f / (float)n, out);
+    unsigned* tk = hific_tickets(st, 1);
+    hipLaunchKernelGGL(bce_partial_kernel, dim3(nb), dim3(256), 0, st, z, target, part, n, tk, 1.f / (float)n, out);
+    if (!tk) hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f / (float)n, out);
     return hific_launch_status();
 }
 int hific_bce_bwd(const float* z, float target, const float* g, float* dz, long long n, int accumulate,
@@ -1204,8 +1297,9 @@ int hific_lsq_sigmoid_fwd(const float* z, float target, float* out, long long n,
     const int nb = 256;
     if (ws_bytes < nb * sizeof(float)) return HIFIC_ERR_WS;
     float* part = (float*)ws;
-    hipLaunchKernelGGL(lsq_partial_kernel, dim3(nb), dim3(256), 0, st, z, target, part, n);
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f / (float)n, out);
+    unsigned* tk = hific_tickets(st, 1);
+    hipLaunchKernelGGL(lsq_partial_kernel, dim3(nb), dim3(256), 0, st, z, target, part, n, tk, 1.f / (float)n, out);
+    if (!tk) hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f / (float)n, out);
     return hific_launch_status();
 }
 int hific_lsq_sigmoid_bwd(const float* z, float target, const float* g, float* dz, long long n, int accumulate,
@@ -1314,7 +1408,8 @@ int hific_d1_ctx_grad(const void* dz, const float* w, const float* inv_sigma, vo
     return hific_launch_status();
 }
 
-// n <= 8 layers per call: W[i] f32 [K[i], M[i]], u[i] [K[i]], v[i] [M[i]] updated in place (do_iter), sig[i] = [sigma, 1/sigma].
+// n <= 8 layers per call: W[i] f32 [K[i], M[i]], u[i] [K[i]], v[i] [M[i]] updated in place (do_iter bit 0), sig[i] = [sigma, 1/sigma].
+// do_iter bit 1: sig[i] has 2 + K[i] + M[i] floats and also receives copies of the post-iteration u[i], v[i].
 // Same arithmetic per layer as hific_spectral_norm_fwd (bit-identical), 6 launches for the whole set.
 int hific_spectral_norm_fwd_batch(const float* const* W, float* const* u, float* const* v, float* const* sig, const int* K,
                                   const int* M, int n, int do_iter, float eps, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -1335,6 +1430,8 @@ int hific_spectral_norm_fwd_batch(const float* const* W, float* const* u, float*
         if (M[i] > maxM) maxM = M[i];
     }
     for (int i = n; i < SN_MAXJOBS; ++i) J.j[i] = J.j[0];
+    const int snap = (do_iter >> 1) & 1;
+    do_iter &= 1;
     if (do_iter) {
         hipLaunchKernelGGL(sn_wtu_batch_kernel, dim3(cdiv(maxM, 256), cdiv(maxK, SN_ROWS), n), dim3(256), 0, st, J);
         hipLaunchKernelGGL(sn_colsum_batch_kernel, dim3(cdiv(maxM, 256), n), dim3(256), 0, st, J);
@@ -1344,7 +1441,7 @@ int hific_spectral_norm_fwd_batch(const float* const* W, float* const* u, float*
     } else {
         hipLaunchKernelGGL(sn_wv_batch_kernel, dim3(maxK, n), dim3(256), 0, st, J);
     }
-    hipLaunchKernelGGL(sn_sigma_batch_kernel, dim3(n), dim3(256), 0, st, J);
+    hipLaunchKernelGGL(sn_sigma_batch_kernel, dim3(n), dim3(256), 0, st, J, snap);
     return hific_launch_status();
 }
 
@@ -1378,8 +1475,9 @@ int hific_spectral_norm_bwd(const float* dW, const float* Worig, const float* u,
     float* part = (float*)ws;
     float* dot = part + nb;
     const long long n = (long long)K * M;
-    hipLaunchKernelGGL(sn_dot_partial_kernel, dim3(nb), dim3(256), 0, st, dW, Worig, part, n);
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f, dot);
+    unsigned* tk = hific_tickets(st, 1);
+    hipLaunchKernelGGL(sn_dot_partial_kernel, dim3(nb), dim3(256), 0, st, dW, Worig, part, n, tk, 1.f, dot);
+    if (!tk) hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.f, dot);
     hipLaunchKernelGGL(sn_bwd_kernel, EW_GRID(n), dim3(256), 0, st, dW, u, v, sigma, dot, dWorig, K, M, accumulate);
     return hific_launch_status();
 }

@@ -38,12 +38,18 @@ __global__ void lower_bound_bwd_kernel(const float* __restrict__ x, const float*
     EW_LOOP(i, n) { const float g = dy[i]; dx[i] = (x[i] >= bound || g < 0.f) ? g : 0.f; }
 }
 __global__ __launch_bounds__(256) void logsum_partial_kernel(const float* __restrict__ p, float eps,
-                                                             float* __restrict__ part, long long n) {
+                                                             float* __restrict__ part, long long n, unsigned* ticket, float tk_mul, float* tk_out) {
     __shared__ float sh[4];
     float s = 0.f;
     EW_LOOP(i, n) s += logf(p[i] + eps);
     s = block_sum_256e(s, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (threadIdx.x == 0) hific_st_agent(part + blockIdx.x, s);
+    if (ticket && hific_last_block(ticket, gridDim.x)) {          // final_sum_kernel_e's sums by the last-arriving workgroup
+        float t = 0.f;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += hific_ld_agent(part + i);
+        t = block_sum_256e(t, sh);
+        if (threadIdx.x == 0) *tk_out = t * tk_mul;
+    }
 }
 __global__ __launch_bounds__(256) void final_sum_kernel_e(const float* __restrict__ part, int n, float mul,
                                                           float* __restrict__ out) {
@@ -346,8 +352,9 @@ int hific_logsum_fwd(const float* p, float* out, long long n, float eps, float m
     const int nb = 256;
     if (ws_bytes < nb * sizeof(float)) return HIFIC_ERR_WS;
     float* part = (float*)ws;
-    hipLaunchKernelGGL(logsum_partial_kernel, dim3(nb), dim3(256), 0, st, p, eps, part, n);
-    hipLaunchKernelGGL(final_sum_kernel_e, dim3(1), dim3(256), 0, st, part, nb, mul, out);
+    unsigned* tk = hific_tickets(st, 1);
+    hipLaunchKernelGGL(logsum_partial_kernel, dim3(nb), dim3(256), 0, st, p, eps, part, n, tk, mul, out);
+    if (!tk) hipLaunchKernelGGL(final_sum_kernel_e, dim3(1), dim3(256), 0, st, part, nb, mul, out);
     return hific_launch_status();
 }
 // dp (=|+=) (*g) * mul / (p + eps)

@@ -43,7 +43,8 @@ __global__ void lpips_prep_bwd_kernel(const T* __restrict__ dgen, TO* __restrict
 #define LP_U 8
 template <typename T>
 __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const T* __restrict__ f, const float* __restrict__ w,
-                                                            float* __restrict__ part, int B, int C, int HW, float eps) {
+                                                            float* __restrict__ part, int B, int C, int HW, float eps,
+                                                            unsigned* ticket, float* val, float inv_hw, int accumulate) {
     __shared__ float r0[4][64], r1[4][64];
     const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -84,7 +85,20 @@ __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const T* __restrict_
     d = wave_sum(d);
     if (px == 0) r0[cg][0] = d;
     __syncthreads();
-    if (threadIdx.x == 0) part[(size_t)b * gridDim.x + blockIdx.x] = r0[0][0] + r0[1][0] + r0[2][0] + r0[3][0];
+    if (threadIdx.x == 0) hific_st_agent(part + (size_t)b * gridDim.x + blockIdx.x, r0[0][0] + r0[1][0] + r0[2][0] + r0[3][0]);
+    // lpips_tap_reduce_kernel's sum for image pair b, by the last-arriving of its gridDim.x workgroups (one ticket per b)
+    if (ticket && hific_last_block(ticket + b, gridDim.x)) {
+        const int nchunk = (int)gridDim.x;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < nchunk; i += 256) s += hific_ld_agent(part + (size_t)b * nchunk + i);
+        s = wave_sum(s);
+        if (px == 0) r1[cg][0] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t = (r1[0][0] + r1[1][0] + r1[2][0] + r1[3][0]) * inv_hw;
+            if (accumulate) val[b] += t; else val[b] = t;
+        }
+    }
 }
 // val[b] (=|+=) sum_chunks part[b][chunk] / HW
 __global__ __launch_bounds__(256) void lpips_tap_reduce_kernel(const float* __restrict__ part, float* __restrict__ val,
@@ -203,12 +217,14 @@ int hific_lpips_tap_fwd(const void* f, const float* w, float* val, int B, int C,
     const int nchunk = cdiv(HW, 64);
     if ((size_t)B * nchunk * sizeof(float) > ws_bytes) return HIFIC_ERR_WS;
     float* part = (float*)ws;
+    unsigned* tk = hific_tickets(st, B);
+    const float inv_hw = 1.f / (float)HW;
     if (dtype == HIFIC_F32)
-        hipLaunchKernelGGL(lpips_tap_fwd_kernel<float>, dim3(nchunk, B), dim3(256), 0, st, (const float*)f, w, part, B, C, HW, 1e-10f);
+        hipLaunchKernelGGL(lpips_tap_fwd_kernel<float>, dim3(nchunk, B), dim3(256), 0, st, (const float*)f, w, part, B, C, HW, 1e-10f, tk, val, inv_hw, accumulate);
     else if (dtype == HIFIC_BF16)
-        hipLaunchKernelGGL(lpips_tap_fwd_kernel<bf16_t>, dim3(nchunk, B), dim3(256), 0, st, (const bf16_t*)f, w, part, B, C, HW, 1e-10f);
+        hipLaunchKernelGGL(lpips_tap_fwd_kernel<bf16_t>, dim3(nchunk, B), dim3(256), 0, st, (const bf16_t*)f, w, part, B, C, HW, 1e-10f, tk, val, inv_hw, accumulate);
     else return HIFIC_ERR_ARG;
-    hipLaunchKernelGGL(lpips_tap_reduce_kernel, dim3(B), dim3(256), 0, st, part, val, nchunk, 1.f / (float)HW, accumulate);
+    if (!tk) hipLaunchKernelGGL(lpips_tap_reduce_kernel, dim3(B), dim3(256), 0, st, part, val, nchunk, inv_hw, accumulate);
     return hific_launch_status();
 }
 // df1: [B,C,HW] gradient wrt the pred-half features; gval: [B] f32 (d loss / d val[b])

@@ -46,8 +46,10 @@ class CodingModel(nn.Module):
         self.likelihood_logistic = 0
 
     def _draw_noise(self, x):
-        # same RNG call as the reference (_quantize: torch.nn.init.uniform_(torch.zeros_like(x), -0.5, 0.5))
-        return torch.nn.init.uniform_(torch.zeros_like(x), -0.5, 0.5)
+        # same RNG call as the reference (_quantize: torch.nn.init.uniform_(torch.zeros_like(x), -0.5, 0.5)): uniform_ overwrites
+        # every element, so the zero fill is skipped (one launch per draw); same generator consumption, same values
+        with torch.no_grad():
+            return torch.empty_like(x).uniform_(-0.5, 0.5)
 
     def _quantize(self, x, mode='noise', means=None):
         if mode == 'noise':
@@ -56,12 +58,17 @@ class CodingModel(nn.Module):
             return ops.RoundFn.apply(x.contiguous(), None if means is None else means.contiguous())
         raise NotImplementedError
 
-    def _estimate_entropy(self, likelihood, spatial_shape):
+    def _estimate_entropy(self, likelihood, spatial_shape, want_bits=True):
+        """src/hyperprior.py:80-93.  `want_bits=False` (the training forward, which only uses the rate per pixel): 1 / n_pixels
+        is folded into the reduction kernel's multiplier - no separate zero-dimensional division (and its backward) per
+        entropy term; n_bits is then None."""
         EPS = 1e-9
         quotient = -np.log(2.)
         batch_size = likelihood.size()[0]
         assert len(spatial_shape) == 2, 'Mispecified spatial dims'
         n_pixels = np.prod(spatial_shape)
+        if not want_bits:
+            return None, ops.LogSumFn.apply(likelihood.contiguous(), EPS, 1.0 / (batch_size * quotient * float(n_pixels)))
         n_bits = ops.LogSumFn.apply(likelihood.contiguous(), EPS, 1.0 / (batch_size * quotient))
         bpp = n_bits / n_pixels
         return n_bits, bpp
@@ -214,9 +221,9 @@ class Hyperprior(CodingModel):
         def rate_side():
             # differential / discrete entropy, hyperlatents
             noisy_hyperlatent_likelihood = self.hyperlatent_likelihood(nh_lik)
-            _, noisy_hyperlatent_bpp = self._estimate_entropy(noisy_hyperlatent_likelihood, spatial_shape)
+            _, noisy_hyperlatent_bpp = self._estimate_entropy(noisy_hyperlatent_likelihood, spatial_shape, want_bits=False)
             quantized_hyperlatent_likelihood = self.hyperlatent_likelihood(qh_lik)
-            _, quantized_hyperlatent_bpp = self._estimate_entropy(quantized_hyperlatent_likelihood, spatial_shape)
+            _, quantized_hyperlatent_bpp = self._estimate_entropy(quantized_hyperlatent_likelihood, spatial_shape, want_bits=False)
 
             latent_scales = self.synthesis_std(hd_std)
             latent_scales = lower_bound_toward(latent_scales, self.scale_lower_bound)
@@ -225,12 +232,12 @@ class Hyperprior(CodingModel):
             # differential entropy, latents (the reference adds noise to the latents irrespective of `means`)
             noisy_latents = self._quantize(lat_c, mode='noise', means=mu_a)
             noisy_latent_likelihood = self.latent_likelihood(noisy_latents, mean=mu_c, scale=sc_a)
-            _, noisy_latent_bpp = self._estimate_entropy(noisy_latent_likelihood, spatial_shape)
+            _, noisy_latent_bpp = self._estimate_entropy(noisy_latent_likelihood, spatial_shape, want_bits=False)
 
             # discrete entropy, latents
             quantized_latents = self._quantize(lat_e, mode='quantize', means=mu_e)
             quantized_latent_likelihood = self.latent_likelihood(quantized_latents, mean=mu_h, scale=sc_b)
-            _, quantized_latent_bpp = self._estimate_entropy(quantized_latent_likelihood, spatial_shape)
+            _, quantized_latent_bpp = self._estimate_entropy(quantized_latent_likelihood, spatial_shape, want_bits=False)
             return (noisy_latent_bpp, noisy_hyperlatent_bpp, noisy_latent_bpp + noisy_hyperlatent_bpp,
                     quantized_latent_bpp, quantized_hyperlatent_bpp, quantized_latent_bpp + quantized_hyperlatent_bpp)
 

@@ -23,6 +23,7 @@ P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_longlong
 SIGNATURES = {
     "hific_version": (I, []),
     "hific_device_info": (I, [I, c_char_p, POINTER(c_int), POINTER(c_int)]),
+    "hific_set_ticket_buffer": (I, [P, P, Z]),
     "hific_conv2d_ws_bytes": (Z, [I] * 13),
     "hific_conv_transpose2d_ws_bytes": (Z, [I] * 11),
     "hific_conv2d_fwd": (I, [P, P, P, P, P, P] + [I] * 16 + [P, Z, P, Z, I, P]),
@@ -51,6 +52,8 @@ SIGNATURES = {
     "hific_maxpool2s2_bwd": (I, [P, P, P, L, I, I, I, P]),
     "hific_maxpool3s2_fwd": (I, [P, P, L, I, I, I, P]),
     "hific_maxpool3s2_bwd": (I, [P, P, P, L, I, I, I, P]),
+    "hific_loss_combine_fwd": (I, [P, P, I, P, P, P, F, F, F, F, F, F, P, P, P]),
+    "hific_loss_combine_bwd": (I, [P, P, I, F, F, F, P, P]),
     "hific_mse_fwd": (I, [P, P, P, L, F, I, P, Z, P]),
     "hific_mse_bwd": (I, [P, P, P, P, L, F, I, P]),
     "hific_bce_fwd": (I, [P, F, P, L, P, Z, P]),
@@ -169,6 +172,22 @@ def stream():
     return _raw_stream(_cur_device())
 
 
+_stream_objs = {}
+
+
+def stream_obj(device=None):
+    """torch.cuda.current_stream(device) without its ~8 us of device-index normalisation: Stream objects cached by raw
+    handle (the current stream of the CURRENT device; callers pass `device` only for symmetry - ops run under the tensor's
+    device).  ~150 queries per training cycle."""
+    dev = _cur_device()
+    raw = _raw_stream(dev)
+    key = (dev, raw)
+    st = _stream_objs.get(key)
+    if st is None:
+        st = _stream_objs[key] = torch.cuda.current_stream(dev)
+    return st
+
+
 def workspace(device, min_bytes=0):
     """Persistent per-device scratch (packed weights, split-K partials, padded-grad buffers).  Re-used by every op:
     safe because all ops are stream-ordered on the current stream."""
@@ -179,7 +198,31 @@ def workspace(device, min_bytes=0):
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
+        if key not in _tickets and _TICKETS_ON:
+            # the stream's ticket counters (include/hific_hip.h "tickets"): zeroed once, self-cleaning afterwards
+            tk = torch.zeros(_TICKET_BYTES, dtype=torch.uint8, device=device)
+            _tickets[key] = tk
+            call("hific_set_ticket_buffer", key[1], tk.data_ptr(), tk.numel())
     return ws
+
+
+_tickets = {}
+_TICKET_BYTES = 16384
+_TICKETS_ON = os.environ.get("HIFIC_TICKETS", "1") != "0"
+
+
+def set_tickets(on):
+    """Registers / removes the ticket buffers of every stream that has a workspace (tests: A/B of the two-launch forms)."""
+    global _TICKETS_ON
+    _TICKETS_ON = bool(on)
+    for key, ws in _workspaces.items():
+        if on:
+            tk = _tickets.get(key)
+            if tk is None:
+                tk = _tickets[key] = torch.zeros(_TICKET_BYTES, dtype=torch.uint8, device=ws.device)
+            call("hific_set_ticket_buffer", key[1], tk.data_ptr(), tk.numel())
+        else:
+            call("hific_set_ticket_buffer", key[1], None, 0)
 
 
 def exported_symbols():

@@ -12,6 +12,8 @@ runs unchanged on the same modules through `inject.patch_reference()`; this file
 """
 from collections import defaultdict, namedtuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,10 @@ from .loss import perceptual_loss as ps
 
 Intermediates = namedtuple("Intermediates", ["input_image", "reconstruction", "latents_quantized", "n_bpp", "q_bpp"])
 Disc_out = namedtuple("disc_out", ["D_real", "D_gen", "D_real_logits", "D_gen_logits"])
+
+
+# the scalar loss composition as one kernel (ops.LossCombineFn) on the device-rate-select path; HIFIC_FUSED_LOSS=0: torch glue
+_FUSED_LOSS = os.environ.get("HIFIC_FUSED_LOSS", "1") not in ("0", "")
 
 
 class Model(nn.Module):
@@ -123,7 +129,8 @@ class Model(nn.Module):
     def perceptual_loss_wrapper(self, x_gen, x_real, normalize=True):
         return torch.mean(self.perceptual_loss.forward(x_gen, x_real, normalize=normalize))
 
-    def compression_loss(self, intermediates, hyperinfo):
+    def _compression_terms(self, intermediates):
+        """(distortion, LPIPS value per image [B,1,1,1]): the two image-sized reductions of the compression loss."""
         x_real = intermediates.input_image
         x_gen = intermediates.reconstruction
         if self.args.normalize_input_image is True:          # [-1,1] -> [0,1] (model.py:206-209)
@@ -131,7 +138,31 @@ class Model(nn.Module):
             x_gen = ops.scale_shift(x_gen, 0.5, 0.5)
         x_gen_mse, x_gen_lpips = ops.fork(x_gen)
         distortion = self.distortion_loss(x_gen_mse, x_real)
-        perceptual = self.perceptual_loss_wrapper(x_gen_lpips, x_real, normalize=True)
+        return distortion, self.perceptual_loss.forward(x_gen_lpips, x_real, normalize=True)
+
+    def _fused_loss_ok(self, x):
+        """The scalar composition as one device kernel (ops.LossCombineFn): with the device-side rate-penalty rule
+        (`device_rate_select`, no `.item()`), on steps that store no loss terms."""
+        return bool(self.device_rate_select and x.is_cuda and _FUSED_LOSS
+                    and not (self.writeout and (self.step_counter % self.log_interval == 1)))
+
+    def _combined_loss(self, distortion, lp, intermediates, G_loss=None):
+        """total = k_M mse + k_P lpips + lambda(q_bpp) n_bpp [+ beta G_loss] (model.py:211-220,373-376; losses.py:8-28)."""
+        from .helpers.utils import get_scheduled_params
+        from .parallel import allreduce_scalar_mean
+        a = self.args
+        lam_A = get_scheduled_params(a.lambda_A, a.lambda_schedule, self.step_counter, a.ignore_schedule)
+        lam_B = get_scheduled_params(a.lambda_B, a.lambda_schedule, self.step_counter, a.ignore_schedule)
+        assert lam_A > lam_B, "Expected lambda_A > lambda_B, got (A) {} <= (B) {}".format(lam_A, lam_B)
+        target = get_scheduled_params(a.target_rate, a.target_schedule, self.step_counter, a.ignore_schedule)
+        q = allreduce_scalar_mean(intermediates.q_bpp.detach(), None)
+        total, _aux = ops.LossCombineFn.apply(distortion, lp.contiguous(), intermediates.n_bpp, q,
+                                              G_loss, a.k_M, a.k_P, lam_A, lam_B, target, a.beta)
+        return total
+
+    def compression_loss(self, intermediates, hyperinfo):
+        distortion, lp = self._compression_terms(intermediates)
+        perceptual = torch.mean(lp)
         w_dist, w_perc = self.args.k_M * distortion, self.args.k_P * perceptual
         w_rate, rate_penalty = losses.weighted_rate_loss(
             self.args, total_nbpp=intermediates.n_bpp, total_qbpp=intermediates.q_bpp,
@@ -199,12 +230,26 @@ class Model(nn.Module):
             for t in (inter_c.input_image, inter_c.reconstruction, inter_c.n_bpp, inter_c.q_bpp) + tuple(hyperinfo):
                 if torch.is_tensor(t):
                     t.record_stream(s2)
+            fused = self._fused_loss_ok(x)
             with torch.cuda.stream(s2):
-                loss = self.compression_loss(inter_c, hyperinfo)
+                if fused:
+                    distortion, lp = self._compression_terms(inter_c)
+                else:
+                    loss = self.compression_loss(inter_c, hyperinfo)
             out['disc'], G_loss = self.GAN_loss(inter_d, train_generator)
             main.wait_stream(s2)
-            loss.record_stream(main)
-            loss = loss + self.args.beta * G_loss
+            if fused:
+                distortion.record_stream(main); lp.record_stream(main)
+                loss = self._combined_loss(distortion, lp, inter_c, G_loss)
+            else:
+                loss.record_stream(main)
+                loss = loss + self.args.beta * G_loss
+        elif self._fused_loss_ok(x):
+            distortion, lp = self._compression_terms(inter_c)
+            G_loss = None
+            if self.use_discriminator:
+                out['disc'], G_loss = self.GAN_loss(inter_d, train_generator)
+            loss = self._combined_loss(distortion, lp, inter_c, G_loss)
         else:
             loss = self.compression_loss(inter_c, hyperinfo)
             if self.use_discriminator:

@@ -145,9 +145,37 @@ class Generator(nn.Module):
         return ops.conv2d(h, out.weight, out.bias, stride=1, pads=out.pads, pad_mode=out.hip_pad_mode, out_f32=True,
                           exact=True, x3=h3)
 
+    def _plain_fused_ok(self, x):
+        """Every conv -> norm pair as one autograd node (ops.ConvNormFn: same kernels, bit-identical, fewer Python-level ops):
+        ChannelNorm variant whose norms own the conv bias gradients, no noise concat."""
+        if not (x.is_cuda and ops.conv_norm_fused_on() and self.sample_noise is not True):
+            return False
+        c0, n0 = self.conv_block_init[2], self.conv_block_init[3]
+        return isinstance(n0, channel.ChannelNorm2D) and (c0.bias is None or c0.bias_grad_in_norm) \
+            and not any(m.exact_index_chain for m in (c0, self.conv_block_out[1]))
+
+    def _forward_plain_fused(self, x):
+        cn = ops.conv_norm
+        head = cn(self.conv_block_init[0](x), self.conv_block_init[2], self.conv_block_init[3])
+        head_res, head_skip = ops.fork(head)
+        h = head_res
+        for m in range(self.n_residual_blocks):
+            blk = getattr(self, f'resblock_{m}')
+            h_conv, h_id = ops.fork(h)
+            h = cn(cn(h_conv, blk.conv1, blk.norm1), blk.conv2, blk.norm2, resid=h_id)
+        h = ops.add(h, head_skip)
+        for i in range(4):
+            u = getattr(self, f'upconv_block{i + 1}')
+            h = cn(h, u[0], u[1])
+        return self.conv_block_out(h)
+
     def forward(self, x):
         if self._exact_chain_ok(x):
             return self._forward_exact_chain(x)
+        exact_unfused = self.conv_block_out[1].exact_recon and (
+            ops.exact_training_on() or (ops.exact_reconstruction_on() and not torch.is_grad_enabled()))
+        if not exact_unfused and self._plain_fused_ok(x):
+            return self._forward_plain_fused(x)
         head = self.conv_block_init(x)
         if self.sample_noise is True:
             # same draw as the reference: host RNG, then moved to the head's device / dtype (generator.py:149-152)

@@ -59,7 +59,10 @@ _warned_recon_big = False
 
 
 def _exact_mode(m, x=None):
-    """False (plain bf16), True (split operands over 3C channels) or "pair" (native split kernel) for layer m's forward."""
+    """False (plain bf16), True (split operands over 3C channels) or "pair" (native split kernel) for layer m's forward;
+    "recon" / "recon_pair" when the layer is exact ONLY as a Generator layer under the exact-training / -reconstruction options
+    (ops.Conv2dFn then saves the bf16 image of its float32 input and runs the bf16 backward; a layer of the exact-index chain
+    keeps its float32 backward under HIFIC_EXACT_FUSED=0 - ADVICE round 5)."""
     chain = m.exact_index_chain and ops.exact_index_on()
     # exact-reconstruction option: the Generator's layers in no-grad forwards (ops.set_exact_reconstruction)
     # ... and, with ops.set_exact_training, in training forwards too (float32 activations through the autograd graph)
@@ -78,6 +81,8 @@ def _exact_mode(m, x=None):
     if not (chain or recon):
         return False
     pair = _PAIR_HYPER and ops.exact_pair_on() and m.stride[0] == 2 and m.in_channels >= 32
+    if recon and not chain:
+        return "recon_pair" if pair else "recon"
     return "pair" if pair else True
 
 

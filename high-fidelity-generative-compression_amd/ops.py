@@ -60,8 +60,8 @@ _PACK_CACHE_ON = __import__("os").environ.get("HIFIC_PACK_CACHE", "1") != "0"
 
 
 class _PackEntry:
-    __slots__ = ("weight", "buf", "job", "token", "nblocks", "lds", "dtype", "kind", "event", "pack_sid", "waited",
-                 "last_use", "pinned")
+    __slots__ = ("weight", "buf", "bufptr", "bufbytes", "job", "token", "nblocks", "lds", "dtype", "kind", "event", "pack_sid",
+                 "waited", "last_use", "pinned")
 
 
 class WeightPackCache:
@@ -157,6 +157,7 @@ class WeightPackCache:
             call("hific_pack_job_info", e.job, ctypes.byref(nb), ctypes.byref(ld), ctypes.byref(wb), ctypes.byref(dt))
             e.nblocks, e.lds, e.dtype = nb.value, ld.value, dt.value
             e.buf = torch.empty(int(wb.value), dtype=torch.uint8, device=weight.device)
+            e.bufptr, e.bufbytes = e.buf.data_ptr(), e.buf.numel()
             e.weight = weakref.ref(weight)
             call("hific_pack_job_set_ptrs", e.job, e.buf.data_ptr(), weight.data_ptr(), None)
             e.token = None                       # never packed yet
@@ -169,12 +170,12 @@ class WeightPackCache:
             self.refresh_stale()
         # packed on another stream (the batched re-pack runs on the stream of the first stale lookup; data-gradient packs on
         # a dedicated one): order this stream after it, once per re-pack
-        cur = torch.cuda.current_stream(weight.device)
-        sid = cur.cuda_stream
-        if e.event is not None and sid != e.pack_sid and sid not in e.waited:
-            cur.wait_event(e.event)
-            e.waited.add(sid)
-        return e.buf.data_ptr(), e.buf.numel(), 2
+        if e.event is not None:
+            sid = stream()
+            if sid != e.pack_sid and sid not in e.waited:
+                lib.stream_obj().wait_event(e.event)
+                e.waited.add(sid)
+        return e.bufptr, e.bufbytes, 2
 
     def refresh_stale(self):
         """Re-packs every entry whose weight changed since it was packed (or that was never packed), one batched launch per
@@ -364,6 +365,20 @@ def exact_generator_fused_on():
 def set_exact_generator_fused(on):
     global _EXACT_GEN_FUSED
     _EXACT_GEN_FUSED = bool(on)
+
+
+# conv -> ChannelNorm pairs of the plain path as one autograd node (ConvNormFn; host time only, bit-identical): HIFIC_CONV_NORM_FUSED=0
+# restores one node per op
+_CONV_NORM_FUSED = os.environ.get("HIFIC_CONV_NORM_FUSED", "1") not in ("0", "")
+
+
+def conv_norm_fused_on():
+    return _CONV_NORM_FUSED
+
+
+def set_conv_norm_fused(on):
+    global _CONV_NORM_FUSED
+    _CONV_NORM_FUSED = bool(on)
 
 
 class exact_index_suspended:
@@ -645,14 +660,19 @@ class _SideLaunch:
         for t in tensors:
             if t is not None:
                 t.record_stream(side)           # the caching allocator must not recycle them under the side kernel
-        self._ctx = torch.cuda.stream(side)
+        self._side = side
 
+    # (torch.cuda.stream()'s context manager re-queries the current stream and device on both ends: ~20 us per use, ~60 uses
+    # per training cycle; the side stream lives on the tensors' device, which is the current one inside an op)
     def __enter__(self):
-        self._ctx.__enter__()
+        self._prev = lib.stream_obj()
+        sd = self._side
+        torch._C._cuda_setStream(stream_id=sd.stream_id, device_index=sd.device_index, device_type=sd.device_type)
         return self
 
     def __exit__(self, *exc):
-        self._ctx.__exit__(*exc)
+        pv = self._prev
+        torch._C._cuda_setStream(stream_id=pv.stream_id, device_index=pv.device_index, device_type=pv.device_type)
         _side_state["pending"] = True
         if not _side_state["cb"]:
             _side_state["cb"] = True
@@ -708,6 +728,15 @@ def _use_side(*slots):
     return _SIDE_ON and all(sl is not None for sl in slots)
 
 
+def _c16(t):
+    """Contiguous AND 16-byte aligned: the pipelined / weight-resident conv kernels move 16-byte pieces and their launch plans
+    are cached without pointers, so a contiguous view at an odd storage offset (a narrowed / as_strided tensor) is copied
+    here instead of failing inside the library.  torch's own allocations are 512-byte aligned: no copy on the
+    training path."""
+    t = t.contiguous()
+    return t if (t.data_ptr() & 15) == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 def _act_code(act):
     return {None: lib.ACT_NONE, "none": lib.ACT_NONE, "relu": lib.ACT_RELU, "leaky_relu": lib.ACT_LEAKY}[act]
 
@@ -727,7 +756,10 @@ class Conv2dFn(Function):
         assert Cw == C, "channel mismatch"
         OH = (H + pt + pb - R) // stride + 1
         OW = (W + pl + pr - S) // stride + 1
-        lay = SPLIT_PAIR if (exact == "pair" and C >= 16) else SPLIT_3C
+        # exact: False | True | "pair" (exact-index chain) | "recon" | "recon_pair" (a Generator layer under the exact-training /
+        # exact-reconstruction options, network/layers.py::_exact_mode - only THOSE take the bf16 backward below)
+        recon = exact in ("recon", "recon_pair")
+        lay = SPLIT_PAIR if (exact in ("pair", "recon_pair") and C >= 16) else SPLIT_3C
         exact = bool(exact) and cd == HIFIC_BF16 and w_scale is None
         ydt = torch.float32 if (cd == HIFIC_F32 or out_f32 or exact) else torch.bfloat16
         if cd == HIFIC_F32 and x.dtype != torch.float32:
@@ -764,7 +796,7 @@ class Conv2dFn(Function):
         # activation / gradient to bf16 anyway, and only bf16 operands reach the fast kernels (wgrad_s1 / wgrad_s2 / gconv_sp9 RFX;
         # with float32 operands the residual-block weight gradient ran 317 us on the generic kernel against 88 us).  Saves the
         # bf16 image of x instead of x.
-        ctx.bf16_bwd = bool(exact and _EXACT_TRAIN and x.dtype == torch.float32)
+        ctx.bf16_bwd = bool(exact and recon and torch.is_grad_enabled() and x.dtype == torch.float32)
         ctx.x_dtype = x.dtype
         xs = cast(x, torch.bfloat16) if ctx.bf16_bwd else x
         ctx.save_for_backward(xs, weight, w_scale, y if act not in (None, "none") else None)
@@ -777,7 +809,7 @@ class Conv2dFn(Function):
         cd = ctx.cd
         N, C, H, W = x.shape
         K, _, R, S = weight.shape
-        dy = dy.contiguous()
+        dy = _c16(dy)
         wsp, wsb = _ws(x)
         if y is not None:
             dz = torch.empty_like(dy)
@@ -790,7 +822,7 @@ class Conv2dFn(Function):
         dx = dw = db = None
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_grad
         side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
-        ev = torch.cuda.current_stream(x.device).record_event() if side else None       # dy is ready here
+        ev = lib.stream_obj().record_event() if side else None       # dy is ready here
         if ctx.needs_input_grad[0]:
             dx = torch.empty(x.shape, dtype=ctx.x_dtype, device=x.device)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
@@ -827,7 +859,7 @@ def conv2d(x, weight, bias, stride=1, pads=(0, 0, 0, 0), pad_mode=lib.PAD_ZERO, 
     pt, pl, pb, pr = pads
     if exact and x3 is None and _compute_dtype == torch.bfloat16 and x.dtype != torch.float32:
         x = cast_grad(x, torch.float32)
-    return Conv2dFn.apply(x.contiguous(), weight, bias, (stride, pt, pl, pb, pr, pad_mode), act, out_f32, w_scale, exact,
+    return Conv2dFn.apply(_c16(x), weight, bias, (stride, pt, pl, pb, pr, pad_mode), act, out_f32, w_scale, exact,
                           bias_grad, x3)
 
 
@@ -845,7 +877,8 @@ class ConvTranspose2dFn(Function):
         assert Ciw == Ci
         OH = (H - 1) * stride - 2 * pad + R + outpad
         OW = (W - 1) * stride - 2 * pad + S + outpad
-        lay = SPLIT_PAIR if (exact == "pair" and Ci >= 16) else SPLIT_3C
+        recon = exact in ("recon", "recon_pair")                # see Conv2dFn
+        lay = SPLIT_PAIR if (exact in ("pair", "recon_pair") and Ci >= 16) else SPLIT_3C
         exact = bool(exact) and cd == HIFIC_BF16
         ydt = torch.float32 if (cd == HIFIC_F32 or out_f32 or exact) else torch.bfloat16
         if cd == HIFIC_F32 and x.dtype != torch.float32:
@@ -868,7 +901,7 @@ class ConvTranspose2dFn(Function):
                  outpad, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
         ctx.geom, ctx.act, ctx.cd, ctx.has_bias = geom, act, cd, bias is not None
         ctx.w_slot, ctx.b_slot = _slot(weight), _slot(bias)
-        ctx.bf16_bwd = bool(exact and _EXACT_TRAIN and x.dtype == torch.float32)        # see Conv2dFn
+        ctx.bf16_bwd = bool(exact and recon and torch.is_grad_enabled() and x.dtype == torch.float32)        # see Conv2dFn
         ctx.x_dtype = x.dtype
         xs = cast(x, torch.bfloat16) if ctx.bf16_bwd else x
         ctx.save_for_backward(xs, weight, y if act not in (None, "none") else None)
@@ -881,7 +914,7 @@ class ConvTranspose2dFn(Function):
         cd = ctx.cd
         N, Ci, H, W = x.shape
         _, Co, R, S = weight.shape
-        dy = dy.contiguous()
+        dy = _c16(dy)
         wsp, wsb = _ws(x)
         if y is not None:
             dz = torch.empty_like(dy)
@@ -894,7 +927,7 @@ class ConvTranspose2dFn(Function):
         dx = dw = db = None
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias_grad
         side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
-        ev = torch.cuda.current_stream(x.device).record_event() if side else None
+        ev = lib.stream_obj().record_event() if side else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(x.shape, dtype=ctx.x_dtype, device=x.device)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
@@ -926,7 +959,7 @@ class ConvTranspose2dFn(Function):
 def conv_transpose2d(x, weight, bias, stride, pad, outpad, act=None, out_f32=False, exact=False, bias_grad=True):
     if exact and _compute_dtype == torch.bfloat16 and x.dtype != torch.float32:
         x = cast_grad(x, torch.float32)
-    return ConvTranspose2dFn.apply(x.contiguous(), weight, bias, (stride, pad, outpad), act, out_f32, exact, bias_grad)
+    return ConvTranspose2dFn.apply(_c16(x), weight, bias, (stride, pad, outpad), act, out_f32, exact, bias_grad)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -1069,7 +1102,7 @@ class ExactConvNormFn(Function):
             stride, pt, pl, pb, pr, pad_mode = ctx.geom
             K, _, R, S = weight.shape
         OH, OW = zb.shape[2], zb.shape[3]
-        dy = dy.contiguous()
+        dy = _c16(dy)
         if dy.dtype != torch.bfloat16:
             dy = cast(dy, torch.bfloat16)
         cd = HIFIC_BF16
@@ -1090,7 +1123,7 @@ class ExactConvNormFn(Function):
         dx = dw = None
         want_w = ctx.needs_input_grad[2]
         side = want_w and _use_side(ctx.w_slot)
-        ev = torch.cuda.current_stream(x.device).record_event() if side else None
+        ev = lib.stream_obj().record_event() if side else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             flags = (_is_f32(dx) << 1)
@@ -1126,15 +1159,154 @@ class ExactConvNormFn(Function):
 def exact_conv_norm(x, x3, weight, bias, stride, pads, pad_mode, gamma, beta, eps, relu, lay_in=SPLIT_3C, lay_out=SPLIT_3C,
                     resid=None, resid3=None, lay_res=SPLIT_3C):
     pt, pl, pb, pr = pads
-    return ExactConvNormFn.apply(x.contiguous(), x3, weight, bias, (stride, pt, pl, pb, pr, pad_mode), gamma, beta, eps, relu,
+    return ExactConvNormFn.apply(_c16(x), x3, weight, bias, (stride, pt, pl, pb, pr, pad_mode), gamma, beta, eps, relu,
                                  lay_in, lay_out, resid, resid3, lay_res)
 
 
 def exact_conv_transpose_norm(x, x3, weight, bias, stride, pad, outpad, gamma, beta, eps, relu, lay_in=SPLIT_3C,
                               lay_out=SPLIT_3C):
     """The up-convolution blocks of the exact Generator chain (generator.py:115-137): nn.ConvTranspose2d -> ChannelNorm -> ReLU."""
-    return ExactConvNormFn.apply(x.contiguous(), x3, weight, bias, (stride, pad, outpad), gamma, beta, eps, relu, lay_in,
+    return ExactConvNormFn.apply(_c16(x), x3, weight, bias, (stride, pad, outpad), gamma, beta, eps, relu, lay_in,
                                  lay_out, None, None, SPLIT_3C)
+
+
+class ConvNormFn(Function):
+    """conv (or nn.ConvTranspose2d: geom of 3 entries) -> ChannelNorm[+ReLU][+residual] of the PLAIN path as one autograd
+    node - the same kernels, in the same order, as Conv2dFn / ConvTranspose2dFn followed by ChannelNormFn with the bias
+    gradient fused (bit-identical), but one Function.apply, one saved-tensor set and one backward call per block instead of
+    two: the Generator's 23 conv -> norm pairs (src/network/generator.py:9-44,98-137) are 46 of the ~230 forward nodes of a
+    training forward.  Host time only; round 6."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, gamma, beta, eps, relu, resid=None):
+        require_gpu(x, weight, bias, gamma, beta, resid)
+        cd = _cd()
+        transposed = len(geom) == 3
+        N, C, H, W = x.shape
+        if cd == HIFIC_F32 and x.dtype != torch.float32:
+            raise lib.HificError("float32 compute mode needs float32 activations")
+        zdt = torch.float32 if cd == HIFIC_F32 else torch.bfloat16
+        flags = _is_f32(x) if cd == HIFIC_BF16 else 0
+        wsp, wsb = _ws(x)
+        if transposed:
+            stride, pad, outpad = geom
+            Cw, K, R, S = weight.shape
+            assert Cw == C
+            OH = (H - 1) * stride - 2 * pad + R + outpad
+            OW = (W - 1) * stride - 2 * pad + S + outpad
+            z = torch.empty((N, K, OH, OW), dtype=zdt, device=x.device)
+            wc = _wcache(weight, 0, (N, C, H, W, K, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
+            call("hific_conv_transpose2d_fwd", ptr(x), ptr(weight), ptr(bias), ptr(z), N, C, H, W, K, R, S, stride, pad,
+                 outpad, lib.ACT_NONE, cd, flags, wsp, wsb, *wc, stream())
+        else:
+            stride, pt, pl, pb, pr, pad_mode = geom
+            K, Cw, R, S = weight.shape
+            assert Cw == C
+            OH = (H + pt + pb - R) // stride + 1
+            OW = (W + pl + pr - S) // stride + 1
+            z = torch.empty((N, K, OH, OW), dtype=zdt, device=x.device)
+            wc = _wcache(weight, 0, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None)
+            call("hific_conv2d_fwd", ptr(x), ptr(weight), None, ptr(bias), None, ptr(z), N, C, H, W, K, R, S, stride, pt, pl, pb,
+                 pr, pad_mode, lib.ACT_NONE, cd, flags, wsp, wsb, *wc, stream())
+        y = torch.empty_like(z)
+        mean = torch.empty((N, OH * OW), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        fused = False
+        if resid is not None:
+            assert resid.shape == z.shape and resid.dtype == z.dtype
+            rc = lib.raw("hific_channelnorm_fwd_res")(ptr(z), ptr(gamma), ptr(beta), ptr(resid), ptr(y), ptr(mean), ptr(rstd), N,
+                                                      K, OH * OW, float(eps), int(relu), lib.dtype_code(z), stream())
+            if rc == 0:
+                fused = True
+            elif rc != -4:
+                raise lib.HificError(f"hific_channelnorm_fwd_res failed (rc={rc})")
+        if not fused:
+            call("hific_channelnorm_fwd", ptr(z), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), N, K, OH * OW,
+                 float(eps), int(relu), lib.dtype_code(z), stream())
+            if resid is not None:
+                y = _add(y, resid)
+        ctx.geom, ctx.relu, ctx.has_bias, ctx.transposed, ctx.cd = geom, int(relu), bias is not None, transposed, cd
+        ctx.has_resid = resid is not None
+        ctx.w_slot, ctx.b_slot, ctx.g_slot, ctx.be_slot = _slot(weight), _slot(bias), _slot(gamma), _slot(beta)
+        ctx.save_for_backward(x, weight, z, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z, gamma, beta, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        cd = ctx.cd
+        if ctx.transposed:
+            stride, pad, outpad = ctx.geom
+            _, K, R, S = weight.shape
+        else:
+            stride, pt, pl, pb, pr, pad_mode = ctx.geom
+            K, _, R, S = weight.shape
+        OH, OW = z.shape[2], z.shape[3]
+        dy = _c16(dy)
+        if dy.dtype != z.dtype:
+            raise lib.HificError("ChannelNorm backward: grad dtype mismatch")
+        # ---- ChannelNorm backward with the convolution's bias gradient out of the same kernel -------------------------
+        dz = torch.empty_like(z)
+        dgt, acc_g, dg = _grad_target(ctx.g_slot, gamma)
+        dbt, acc_b, dbe = _grad_target(ctx.be_slot, beta)
+        assert acc_g == acc_b
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dpt, acc_p, db = (None, 0, None)
+        if want_b:
+            dpt, acc_p, db = _grad_target(ctx.b_slot, gamma.new_empty(K))
+        wsp, wsb = _ws(x)
+        call("hific_channelnorm_bwd", ptr(z), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dz), ptr(dgt),
+             ptr(dbt), N, K, OH * OW, ctx.relu, acc_g, lib.dtype_code(z), wsp, wsb, ptr(dpt), acc_p, stream())
+        _written(ctx.g_slot, ctx.be_slot, ctx.b_slot if want_b else None)
+        # ---- convolution backward on (x, dz) ---------------------------------------------------------------------
+        dx = dw = None
+        want_w = ctx.needs_input_grad[1]
+        side = want_w and _use_side(ctx.w_slot)
+        ev = lib.stream_obj().record_event() if side else None
+        dz_f32 = _is_f32(dz) if cd == HIFIC_BF16 else 0
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            flags = dz_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0)
+            if ctx.transposed:
+                wc = _wcache(weight, 1, (N, C, H, W, K, R, S, stride, pad, outpad), cd, flags, None, transposed=True)
+                call("hific_conv_transpose2d_bwd_data", ptr(dz), ptr(weight), ptr(dx), N, C, H, W, K, R, S, stride, pad,
+                     outpad, cd, flags, wsp, wsb, *wc, stream())
+            else:
+                wc = _wcache(weight, 1, (N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags, None)
+                call("hific_conv2d_bwd_data", ptr(dz), ptr(weight), None, ptr(dx), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                     pad_mode, cd, flags, wsp, wsb, *wc, stream())
+
+        def wgrad():
+            nonlocal dw
+            wsp_, wsb_ = _ws(x)
+            dwt, acc, dw = _grad_target(ctx.w_slot, weight)
+            flags = (_is_f32(x) if cd == HIFIC_BF16 else 0) | (dz_f32 << 1)
+            if ctx.transposed:
+                call("hific_conv_transpose2d_bwd_weight", ptr(x), ptr(dz), ptr(dwt), N, C, H, W, K, R, S, stride, pad, outpad,
+                     acc, cd, flags, wsp_, wsb_, stream())
+            else:
+                call("hific_conv2d_bwd_weight", ptr(x), ptr(dz), ptr(dwt), N, C, H, W, K, R, S, stride, pt, pl, pb, pr,
+                     pad_mode, acc, cd, flags, wsp_, wsb_, stream())
+        if want_w:
+            if side:
+                with _SideLaunch(ev, x, dz, key=ctx.w_slot):
+                    wgrad()
+            else:
+                wgrad()
+        _written(ctx.w_slot if want_w else None)
+        return dx, dw, db, None, dg, dbe, None, None, (dy if ctx.has_resid else None)
+
+
+def conv_norm(x, conv, norm, resid=None):
+    """One conv -> ChannelNorm block of the plain path (layers.HipConv2d / HipConvTranspose2d + channel.ChannelNorm2D whose
+    bias gradient is fused: channel.fuse_bias_grad) as one node."""
+    if conv.transposed:
+        geom = (conv.stride[0], conv.padding[0], conv.output_padding[0])
+    else:
+        geom = (conv.stride[0],) + tuple(conv.pads) + (conv.hip_pad_mode,)
+    return ConvNormFn.apply(_c16(x), conv.weight, conv.bias, geom, norm.gamma, norm.beta, norm.eps, norm.fuse_relu,
+                            None if resid is None else resid.contiguous())
 
 
 class AddSplitFn(Function):
@@ -1459,6 +1631,36 @@ class LogSumFn(Function):
 
 
 # ------------------------------------------------------------------------------------------------------
+class LossCombineFn(Function):
+    """total = ((penalty * nbpp + k_M * mse) + k_P * mean(lp)) [+ beta * g_loss] with penalty = q > target ? lambda_A : lambda_B
+    evaluated on the device (hific_loss_combine_fwd): the loss composition of src/model.py:211-220,373-376 and the rate
+    schedule of src/loss/losses.py:8-28 as ONE autograd node instead of ~12 zero-dimensional torch ops.  Returns (total, aux)
+    with aux = [perceptual, penalty, weighted_rate, weighted_distortion] (no gradient) for logging."""
+
+    @staticmethod
+    def forward(ctx, mse, lp, nbpp, q, g_loss, kM, kP, lamA, lamB, target, beta):
+        require_gpu(mse, lp, nbpp, q, g_loss)
+        B = lp.numel()
+        total = torch.empty((), dtype=torch.float32, device=mse.device)
+        aux = torch.empty(4, dtype=torch.float32, device=mse.device)
+        call("hific_loss_combine_fwd", ptr(mse), ptr(lp), B, ptr(nbpp), ptr(q), ptr(g_loss), float(kM), float(kP), float(lamA),
+             float(lamB), float(target), float(beta), ptr(total), ptr(aux), stream())
+        ctx.c = (B, float(kM), float(kP), float(beta), tuple(lp.shape), g_loss is not None)
+        ctx.save_for_backward(aux)
+        ctx.mark_non_differentiable(aux)
+        return total, aux
+
+    @staticmethod
+    def backward(ctx, g, _aux):
+        (aux,) = ctx.saved_tensors
+        B, kM, kP, beta, lp_shape, has_g = ctx.c
+        g = g.contiguous().float()
+        grads = torch.empty(3 + B, dtype=torch.float32, device=aux.device)
+        call("hific_loss_combine_bwd", ptr(g), ptr(aux), B, kM, kP, beta, ptr(grads), stream())
+        return (grads[0], grads[3:].view(lp_shape), grads[1], None, grads[2] if has_g else None,
+                None, None, None, None, None, None)
+
+
 class MSEFn(Function):
     """mean((scale*a - scale*b)^2); a = reconstruction (compute dtype), b = float32 input image (no grad)."""
 
@@ -1606,18 +1808,35 @@ def spectral_norm_power_iteration(weight_orig, u, v, do_iter, eps=1e-12):
 
 def spectral_norm_power_iteration_batch(layers, do_iter, eps=1e-12):
     """`layers`: [(weight_orig, u, v), ...] (<= 8): one power iteration each (in place on u, v; no autograd), all layers per
-    launch (hific_spectral_norm_fwd_batch).  Returns one [sigma, 1/sigma] tensor per layer (views of one buffer)."""
+    launch (hific_spectral_norm_fwd_batch).  Returns one tensor per layer (views of one buffer): [sigma, 1/sigma] followed by
+    copies of the post-iteration u (K) and v (M) - the snapshot SNConv2dFn / D1StageFn save for their backward instead of
+    cloning the buffers (16 device copies per training cycle); `sn_uv(sig, u, v)` splits it."""
     n = len(layers)
     ws0, us, vs = zip(*layers)
     require_gpu(*ws0, *us, *vs)
-    sig = torch.empty((n, 2), dtype=torch.float32, device=ws0[0].device)
-    Ks = (ctypes.c_int * n)(*[w.shape[0] for w in ws0])
-    Ms = (ctypes.c_int * n)(*[w.numel() // w.shape[0] for w in ws0])
-    sp = (ctypes.c_void_p * n)(*[sig[i].data_ptr() for i in range(n)])
+    kk = [w.shape[0] for w in ws0]
+    mm = [w.numel() // w.shape[0] for w in ws0]
+    offs, tot = [], 0
+    for k, m in zip(kk, mm):
+        offs.append(tot); tot += 2 + k + m
+    sig = torch.empty(tot, dtype=torch.float32, device=ws0[0].device)
+    Ks = (ctypes.c_int * n)(*kk)
+    Ms = (ctypes.c_int * n)(*mm)
+    base = sig.data_ptr()
+    sp = (ctypes.c_void_p * n)(*[base + 4 * o for o in offs])
     wsp, wsb = _ws(ws0[0])
-    call("hific_spectral_norm_fwd_batch", _ptr_array(ws0), _ptr_array(us), _ptr_array(vs), sp, Ks, Ms, n, int(do_iter),
-         float(eps), wsp, wsb, stream())
-    return [sig[i] for i in range(n)]
+    call("hific_spectral_norm_fwd_batch", _ptr_array(ws0), _ptr_array(us), _ptr_array(vs), sp, Ks, Ms, n,
+         (1 if do_iter else 0) | 2, float(eps), wsp, wsb, stream())
+    return [sig[o:o + 2 + k + m] for o, k, m in zip(offs, kk, mm)]
+
+
+def sn_uv(sig, u, v):
+    """(sigma pair, u, v) for a spectral-norm layer's backward: the snapshot carried behind sigma when `sig` came from
+    spectral_norm_power_iteration_batch, else clones of the live buffers (which the next forward iterates in place)."""
+    K, M = u.numel(), v.numel()
+    if sig.numel() == 2 + K + M:
+        return sig[:2], sig[2:2 + K], sig[2 + K:]
+    return sig, u.clone(), v.clone()
 
 
 # spectral-norm convolutions: 1/sigma in the conv epilogue + cached packs (flags bit 4); HIFIC_SN_EPI_SCALE=0: scaled packs
@@ -1655,7 +1874,8 @@ class SNConv2dFn(Function):
              stream())
         ctx.geom, ctx.act, ctx.cd = geom, act, cd
         ctx.w_slot, ctx.b_slot = _slot(weight_orig), _slot(bias)
-        ctx.save_for_backward(x, weight_orig, u.clone(), v.clone(), sig, y if act not in (None, "none") else None)
+        sig2, us, vs = sn_uv(sig, u, v)
+        ctx.save_for_backward(x, weight_orig, us, vs, sig2, y if act not in (None, "none") else None)
         return y
 
     @staticmethod
@@ -1665,7 +1885,7 @@ class SNConv2dFn(Function):
         cd = ctx.cd
         N, C, H, W = x.shape
         K, _, R, S = weight_orig.shape
-        dy = dy.contiguous()
+        dy = _c16(dy)
         wsp, wsb = _ws(x)
         if y is not None:
             dz = torch.empty_like(dy)
@@ -1677,7 +1897,7 @@ class SNConv2dFn(Function):
         dx = dw = db = None
         want_w, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
-        ev = torch.cuda.current_stream(x.device).record_event() if side else None
+        ev = lib.stream_obj().record_event() if side else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             flags = dy_f32 | ((_is_f32(dx) << 1) if cd == HIFIC_BF16 else 0) | _SN_EPI_SCALE
@@ -1758,7 +1978,8 @@ class D1StageFn(Function):
              N, C, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
         ctx.geom, ctx.act, ctx.cd, ctx.dims = geom, act, cd, (B, Ci, Cc, H, W, int(f))
         ctx.w_slot, ctx.b_slot = _slot(weight_orig), _slot(bias)
-        ctx.save_for_backward(x, weight_orig, u.clone(), v.clone(), sig, y if act not in (None, "none") else None)
+        sig2, us, vs = sn_uv(sig, u, v)
+        ctx.save_for_backward(x, weight_orig, us, vs, sig2, y if act not in (None, "none") else None)
         return y
 
     @staticmethod
@@ -1780,7 +2001,7 @@ class D1StageFn(Function):
         dgen = dctx = dw = db = None
         want_w, want_b = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
         side = (want_w or want_b) and _use_side(ctx.w_slot if want_w else True, ctx.b_slot if want_b else True)
-        ev = torch.cuda.current_stream(x.device).record_event() if side else None
+        ev = lib.stream_obj().record_event() if side else None
         if ctx.needs_input_grad[1]:
             # generated images: data gradient of the second half of the batch for the image channels only
             wsp, wsb = _ws(x)

@@ -47,6 +47,19 @@ typedef struct ihipStream_t* hipStream_t;
 int hific_version(void);
 int hific_device_info(int device, char* name64, int* cus, int* lds_per_cu);
 
+/* ---- tickets (round 6): two-stage reductions finished inside ONE launch --------------------------------------------------
+ * Channel sums (bias gradients), scalar loss sums (MSE, BCE / least-squares GAN losses, the four entropy estimates, spectral
+ * norm's <dW, W>) and the LPIPS tap sums are "partials per workgroup, then a tiny second launch" reductions (~57 second
+ * launches of 4-7 us per training cycle of src/model.py:346-387; second stages of a few hundred floats).  When
+ * the caller registers a ticket buffer for a stream - `bytes` / 4 unsigned counters in device memory, ZERO at registration,
+ * owned by the caller, valid until removed with buf = NULL - kernels launched on that stream let their last-arriving
+ * workgroup run the second stage (agent-scope release / acquire around an atomic counter; the counters are zero again when
+ * the launch ends).  Without a registered buffer (or with HIFIC_TICKETS=0) every entry point keeps its two-launch form: same
+ * results (the scalar, channel and tap sums bit for bit; the ChannelNorm parameter sums in another, fixed, summation order).
+ * One buffer per stream: launches of one stream are ordered, launches of different streams must not share counters.
+ * 16 KiB per stream is enough for every entry point. */
+int hific_set_ticket_buffer(hipStream_t stream, void* buf, size_t bytes);
+
 /* ---- convolutions (csrc/gconv.hip) ------------------------------------------------------------------------
  * Replaces nn.Conv2d (+ the nn.ReflectionPad2d in front of it, + the activation behind it):
  *   src/network/encoder.py:56-101, src/network/generator.py:28-29,98-103,139-142, src/network/hyper.py:52-54,
@@ -158,6 +171,16 @@ int hific_maxpool2s2_bwd(const void* x, const void* dy, void* dx, long long plan
 int hific_maxpool3s2_fwd(const void* x, void* y, long long planes, int H, int W, int dtype, hipStream_t stream);
 int hific_maxpool3s2_bwd(const void* x, const void* dy, void* dx, long long planes, int H, int W, int dtype,
                          hipStream_t stream);
+/* The scalar loss composition of one training forward as one launch (src/model.py:211-220,373-376; src/loss/losses.py:8-28):
+ * total = ((penalty * nbpp + k_M * mse) + k_P * mean_b lp[b]) [+ beta * g_loss], penalty = q > target ? lambda_A : lambda_B,
+ * all operands device scalars (lp: B floats, g_loss nullable, q = the - under data parallelism globally averaged - q_bpp);
+ * aux[4] = {perceptual, penalty, penalty * nbpp, k_M * mse}.  Backward: grads[3 + B] = g * d total / d {mse, nbpp, g_loss,
+ * lp[0..B)}.  Replaces ~12 zero-dimensional ATen launches and autograd nodes per forward. */
+int hific_loss_combine_fwd(const float* mse, const float* lp, int B, const float* nbpp, const float* q, const float* g_loss,
+                           float kM, float kP, float lamA, float lamB, float target, float beta, float* total, float* aux,
+                           hipStream_t stream);
+int hific_loss_combine_bwd(const float* g, const float* aux, int B, float kM, float kP, float beta, float* grads,
+                           hipStream_t stream);
 /* distortion loss mean((255 a - 255 b)^2): src/model.py:190-194 */
 int hific_mse_fwd(const void* a, const float* b, float* out, long long n, float scale, int dtype, void* ws,
                   size_t ws_bytes, hipStream_t stream);
@@ -199,7 +222,10 @@ int hific_d1_ctx_grad(const void* dz, const float* w, const float* inv_sigma, vo
                       int W, int f, int dtype, void* ws, size_t ws_bytes, hipStream_t stream);
 /* The same power iteration for n <= 8 layers in one call (src/network/discriminator.py:53-62: the four spectral-norm convs of
  * the Discriminator; their iterations depend only on the weights): per layer bit-identical to hific_spectral_norm_fwd, 6
- * launches for the whole set instead of 6 per layer.  ws >= sum_i (M_i + K_i + ceil(K_i / 16) M_i) floats. */
+ * launches for the whole set instead of 6 per layer.  ws >= sum_i (M_i + K_i + ceil(K_i / 16) M_i) floats.
+ * do_iter bit 0: run the iteration (training); bit 1 (round 6): sig[i] has 2 + K_i + M_i floats and receives, behind
+ * [sigma, 1/sigma], copies of the post-iteration u_i and v_i - what the backward of THIS forward needs once the next forward
+ * has iterated u, v in place (torch.nn.utils.spectral_norm clones them for the same reason). */
 int hific_spectral_norm_fwd_batch(const float* const* W, float* const* u, float* const* v, float* const* sig, const int* K,
                                   const int* M, int n, int do_iter, float eps, void* ws, size_t ws_bytes, hipStream_t stream);
 /* torch.nn.utils.spectral_norm power iteration + sigma (discriminator.py:46-62); sigma_out = {sigma, 1/sigma} */

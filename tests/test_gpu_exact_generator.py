@@ -189,3 +189,32 @@ def test_generator_exact_chain_no_grad_route_equals_training_route(hific, dev, s
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert plain.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_generator_conv_norm_nodes_are_bit_identical_to_separate_ops(hific, dev, sd, dt):
+    """ops.ConvNormFn (conv -> ChannelNorm as one autograd node, the plain path's default) launches the same kernels in the
+    same order as Conv2dFn / ConvTranspose2dFn + ChannelNormFn: output and every gradient bit for bit."""
+    from hific_amd import ops
+    hific.set_compute_dtype(dt)
+    y = (O.make_noise(3, (2, 220, 8, 8)) * 4)
+    g = None
+    res = []
+    for fused in (True, False):
+        ops.set_conv_norm_fused(fused)
+        try:
+            gen = _gen(hific, dev, sd)
+            yd = y.to(dev).requires_grad_(True)
+            x = gen(yd)
+            if g is None:
+                g = O.make_noise(4, tuple(x.shape)).to(dev).to(x.dtype)
+            x.backward(g)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_conv_norm_fused(True)
+        res.append((x.detach().clone(), yd.grad.clone(), {k: p.grad.clone() for k, p in gen.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert set(res[0][2]) == set(res[1][2])
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    hific.set_compute_dtype(torch.float32)

@@ -231,30 +231,37 @@ def test_discriminator_pair_input_equals_cat_and_repeat_interleave(hific, dev, s
     hific.set_compute_dtype(torch.float32)
 
 
-def test_discriminator_pair_input_on_a_one_row_latent_takes_the_two_node_path(hific, dev, sd):
-    """16 x N crops (a 1-row latent) are valid in the reference; hific_d1_ctx_grad has no kernel for them, so
-    forward_pairs must not choose the fused input stage there - forward AND backward run, equal to the cat / repeat path."""
+def test_discriminator_input_stage_is_chosen_only_where_its_backward_has_a_kernel(hific, dev, sd, monkeypatch):
+    """ADVICE round 5: ops.D1StageFn's backward (hific_d1_ctx_grad) needs >= 2 cells per side and 4 KiB of workspace per cell;
+    forward_pairs must check that BEFORE choosing the fused node (it used to fail in the middle of backward) and otherwise take
+    UpsamplePairConcatFn + SNConv2d, with the same results.  (A 1-row latent never reaches the Discriminator: its context
+    convolution reflect-pads by 1, which torch rejects on a 1-row plane too.)"""
     from hific_amd.network.discriminator import Discriminator
+    from hific_amd import lib
     hific.set_compute_dtype(torch.float32)
-    D = _load(Discriminator((3, 16, 64), (220, 1, 4), C=220), sd, "Discriminator.").to(dev).eval()
+    D = _load(Discriminator((3, 32, 64), (220, 2, 4), C=220), sd, "Discriminator.").to(dev).eval()
     B = 2
-    real = O.make_image(9, B, 16, 64).to(dev)
-    gen0 = O.make_image(12, B, 16, 64).to(dev)
-    lat = (O.make_noise(10, (B, 220, 1, 4)) * 4).to(dev)
-    assert not D._d1_stage_eligible(real, torch.empty(B, 12, 1, 4, device=dev))
-    assert D._d1_stage_eligible(torch.empty(B, 3, 64, 64, device=dev), torch.empty(B, 12, 4, 4, device=dev))
-    res = []
-    for mode in ("cat", "pair"):
+    real = O.make_image(9, B, 32, 64).to(dev)
+    gen0 = O.make_image(12, B, 32, 64).to(dev)
+    lat = (O.make_noise(10, (B, 220, 2, 4)) * 4).to(dev)
+    assert not D._d1_stage_eligible(torch.empty(B, 3, 16, 64, device=dev), torch.empty(B, 12, 1, 4, device=dev))
+    assert D._d1_stage_eligible(real, torch.empty(B, 12, 2, 4, device=dev))
+    res = {}
+    for mode in ("fused", "small_workspace"):
+        if mode == "small_workspace":           # not enough workspace for the window sums -> the two-node path
+            small = torch.empty(B * 2 * 4 * 4096 - 1, dtype=torch.uint8, device=dev)
+            monkeypatch.setattr(lib, "workspace", lambda device, min_bytes=0: small)
+            assert not D._d1_stage_eligible(real, torch.empty(B, 12, 2, 4, device=dev))
+            monkeypatch.undo()
+            monkeypatch.setattr(D, "_d1_stage_eligible", lambda *a: False)
         D.zero_grad()
         gen = gen0.clone().requires_grad_(True)
-        if mode == "cat":
-            out, logits = D(torch.cat([real, gen], dim=0), torch.repeat_interleave(lat, 2, dim=0))
-        else:
-            out, logits = D.forward_pairs(real, gen, lat)
+        out, logits = D.forward_pairs(real, gen, lat)
         logits.sum().backward()
         torch.cuda.synchronize()
-        res.append((logits.detach().clone(), gen.grad.clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        res[mode] = (logits.detach().clone(), gen.grad.clone())
+    assert torch.equal(res["fused"][0], res["small_workspace"][0])
+    assert _relerr(res["fused"][1].cpu(), res["small_workspace"][1].cpu()) < 1e-5
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 64), (3, 32, 512), (1, 256, 256)], ids=["64x64", "32x512_segments", "256x256"])

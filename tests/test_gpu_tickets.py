@@ -1,0 +1,116 @@
+"""Tickets (include/hific_hip.h "tickets", csrc/common.h): the last-arriving workgroup of a partial-sum kernel runs the second
+stage of the reduction inside the same launch.  With the stream's ticket buffer registered (lib.workspace does it) against the
+two-launch forms (lib.set_tickets(False)): scalar loss sums, channel sums and LPIPS tap sums bit for bit (the ChannelNorm
+parameter sums keep their separate launch: also compared here, the switch must not touch them); hundreds of back-to-back
+launches leave the counters zero."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore(hific):
+    from hific_amd import lib
+    yield
+    lib.set_tickets(True)
+
+
+def _ab(fn):
+    from hific_amd import lib
+    lib.set_tickets(True)
+    a = fn()
+    lib.set_tickets(False)
+    b = fn()
+    lib.set_tickets(True)
+    torch.cuda.synchronize()
+    return a, b
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_scalar_and_channel_sums_are_bit_identical(hific, dev, dt):
+    from hific_amd import ops, lib
+    hific.set_compute_dtype(dt)
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = torch.randn(4, 37, 50, 40, generator=g, device=dev).to(dt)
+    b = torch.randn(4, 37, 50, 40, generator=g, device=dev)
+    z = torch.randn(4096 + 13, generator=g, device=dev)
+    p = torch.rand(3, 220, 16, 16, generator=g, device=dev) + 1e-3
+    lib.workspace(dev)
+
+    def run():
+        out = [ops.MSEFn.apply(a, b, 255.0).detach().clone(),
+               ops.BCELogitsFn.apply(z, 1.0).detach().clone(), ops.BCELogitsFn.apply(z, 0.0).detach().clone(),
+               ops.LsqSigmoidFn.apply(z, 1.0).detach().clone(),
+               ops.LogSumFn.apply(p, 1e-9, -0.37).detach().clone()]
+        cs = torch.empty(37, device=dev)
+        wsb = lib.workspace(dev)
+        lib.call("hific_channel_sum", a.data_ptr(), cs.data_ptr(), 4, 37, 2000, 0, lib.dtype_code(a), wsb.data_ptr(),
+                 wsb.numel(), lib.stream())
+        out.append(cs.clone())
+        lib.call("hific_channel_sum", a.data_ptr(), cs.data_ptr(), 4, 37, 2000, 1, lib.dtype_code(a), wsb.data_ptr(),
+                 wsb.numel(), lib.stream())
+        out.append(cs.clone())
+        return out
+    x, y = _ab(run)
+    for u, v in zip(x, y):
+        assert torch.equal(u, v)
+    ref = (a.float() * 255 - b * 255).pow(2).mean()
+    assert abs(float(x[0]) - float(ref)) < 1e-4 * float(ref)
+    assert torch.allclose(x[5], a.float().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(x[6], 2 * a.float().sum(dim=(0, 2, 3)), rtol=1e-4, atol=2e-2)
+    hific.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("N,C,H,W,dt,relu", [(16, 960, 16, 16, torch.bfloat16, 1), (2, 60, 64, 64, torch.bfloat16, 1),
+                                             (2, 220, 8, 8, torch.float32, 0), (3, 480, 32, 32, torch.bfloat16, 0),
+                                             (1, 37, 17, 5, torch.float32, 1)])
+def test_channelnorm_parameter_gradients(hific, dev, N, C, H, W, dt, relu):
+    from hific_amd import ops
+    hific.set_compute_dtype(dt)
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(N, C, H, W, generator=g, device=dev).to(dt)
+    dy = torch.randn(N, C, H, W, generator=g, device=dev).to(dt)
+    gamma = (torch.rand(1, C, 1, 1, generator=g, device=dev) + 0.5).requires_grad_(True)
+    beta = (torch.randn(1, C, 1, 1, generator=g, device=dev) * 0.2).requires_grad_(True)
+    bias = torch.zeros(C, device=dev, requires_grad=True)
+
+    def run():
+        gamma.grad = beta.grad = bias.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = ops.channel_norm(xx, gamma, beta, 1e-3, relu=bool(relu), prev_bias=bias)
+        y.backward(dy)
+        return [xx.grad.clone(), gamma.grad.clone(), beta.grad.clone(), bias.grad.clone()]
+    (dx1, dg1, db1, dp1), (dx2, dg2, db2, dp2) = _ab(run)
+    assert torch.equal(dx1, dx2)
+    for u, v in ((dg1, dg2), (db1, db2), (dp1, dp2)):
+        scale = float(v.abs().max()) + 1e-20
+        assert float((u - v).abs().max()) <= 2e-6 * scale + 1e-6 * float(v.abs().mean()) * (N * H * W) ** 0.5, float((u - v).abs().max()) / scale
+    again = run()
+    assert all(torch.equal(p, q) for p, q in zip((dx1, dg1, db1, dp1), again))          # fixed summation order
+    hific.set_compute_dtype(torch.float32)
+
+
+def test_lpips_tap_sums_bit_identical_and_counters_self_clean(hific, dev):
+    from hific_amd import lib
+    g = torch.Generator(device=dev).manual_seed(3)
+    B, C, HW = 5, 192, 27 * 27
+    f = torch.randn(2 * B, C, HW, generator=g, device=dev)
+    w = torch.rand(C, generator=g, device=dev)
+    wsb = lib.workspace(dev)
+
+    def run():
+        val = torch.zeros(B, device=dev)
+        for acc in (0, 1):
+            lib.call("hific_lpips_tap_fwd", f.data_ptr(), w.data_ptr(), val.data_ptr(), B, C, HW, acc, lib.HIFIC_F32,
+                     wsb.data_ptr(), wsb.numel(), lib.stream())
+        return val.clone()
+    a, b = _ab(run)
+    assert torch.equal(a, b)
+    # 300 launches back to back: every one must find its counters at zero
+    lib.set_tickets(True)
+    outs = [run() for _ in range(150)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, a) for o in outs)
+    key = next(k for k in lib._tickets)
+    assert int(lib._tickets[key].view(torch.int32).abs().sum()) == 0
