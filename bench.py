@@ -211,12 +211,18 @@ def scale_report(args, step, reducers, opts, world, rank, dev, fence, ms_step):
     import torch.distributed as dist
     from hific_amd import parallel
     n = max(3, min(args.steps, 6))
-    rep = {"buckets_timeline": {k: [{"bucket": b, "wire_mbytes": mb, "issue_ms": ti, "duration_ms": td}
-                                    for b, mb, ti, td in r.bucket_timeline()] for k, r in reducers.items()},
-           "buckets_timeline_note": "last measured backward on this rank: issue = ms after the first bucket reached its "
-                                    "collective on the reduce stream, duration = collective start to end"}
     for r in reducers.values():
         r.measure_exposed(False)
+        r.measure_timeline(True)            # a separate short pass: the per-bucket events serialise the reduce stream
+    step(); step()
+    torch.cuda.synchronize()
+    rep = {"buckets_timeline": {k: [{"bucket": b, "wire_mbytes": mb, "issue_ms": ti, "duration_ms": td}
+                                    for b, mb, ti, td in r.bucket_timeline()] for k, r in reducers.items()},
+           "buckets_timeline_note": "one extra backward after the timed region with per-bucket events on (they make the reduce "
+                                    "stream wait for each collective - not on while timing): issue = ms after the first bucket "
+                                    "reached its collective on the reduce stream, duration = collective start to end"}
+    for r in reducers.values():
+        r.measure_timeline(False)
     # ---- the other payload, same model state ------------------------------------------------------------------------------
     cur = next(iter(reducers.values())).payload
     other = "bf16" if cur == "f32" else "f32"
@@ -347,6 +353,37 @@ def _trace_filter(kind):
     if kind == "gconv_sp9_kernel<2,4>":
         return "gconv_sp9_kernel<2,4,false", 256 * 512
     return kind, None
+
+
+def practical_peak():
+    """The measured ceiling of the dominant kernel's tile: the residual-trunk convolution (960 -> 960, 3x3, 16 x 16x16, the
+    same launch geometry) run from libhific_hip_mfma_only.so - the library built with gconv_sp9_kernel's patch loads, weight
+    loads, LDS fragment reads and chunk barriers compiled out (csrc/build.sh, -DSP9_ABL=15; results are wrong by
+    construction), i.e. the bare v_mfma_f32_32x32x16_bf16 stream of that tile on register-resident non-zero operands.  Timed by
+    the in-library HIP events in a child process (tools/micro_sp9.py).  `roofline.peak` stays the data-sheet 2.5 PF."""
+    so = os.path.join(ROOT, "high-fidelity-generative-compression_amd", "libhific_hip_mfma_only.so")
+    tool = os.path.join(ROOT, "tools", "micro_sp9.py")
+    if not (os.path.exists(so) and os.path.exists(tool)):
+        return None
+    env = dict(os.environ, HIFIC_LIB_PATH=so, MOPS="fwd", HIFIC_TICKETS="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run([sys.executable, tool, "40"], env=env, capture_output=True, text=True, timeout=120).stdout
+    except Exception:
+        return None
+    for line in out.splitlines():
+        if "gconv_sp9_kernel<2,4>" in line and "narrow" not in line and " us x" in line:
+            try:
+                us = float(line.split(":")[-1].split("us")[0])
+                tf = float(line.rsplit("x", 1)[-1].split()[1])
+            except Exception:
+                continue
+            return {"tflops": tf, "avg_launch_us": us, "unit": "TFLOP/s",
+                    "how": "the trunk launch (67.95 GFLOP) with every memory instruction of gconv_sp9_kernel<2,4> compiled out "
+                           "(libhific_hip_mfma_only.so, -DSP9_ABL=15): the MFMA issue rate of this tile on resident, non-zero "
+                           "operands on THIS box - the ceiling a perfect operand pipeline would reach"}
+    return None
 
 
 def measure_traffic(args, kernel_name):
@@ -1030,6 +1067,10 @@ def main():
                 out["parity"] = parity_leg(args, dev)
             except Exception as e:                      # the throughput line must survive a checker failure
                 out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+        pp = practical_peak()
+        if pp is not None:
+            out["roofline"]["practical_peak"] = pp
+            out["roofline"]["frac_of_practical_peak"] = round(out["roofline"]["achieved"] / pp["tflops"], 4)
         if not args.no_traffic and os.environ.get("HIFIC_BENCH_PMC", "1") != "0":
             traffic, why = measure_traffic(args, dom)
         out["roofline"]["traffic"] = traffic

@@ -30,6 +30,15 @@ for pid in $PIDS; do
   fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
+# measurement-only twin (bench.py `roofline.practical_peak`): the same library with the residual-trunk kernel's memory instructions
+# compiled out (-DSP9_ABL=15: no patch loads, no weight loads, no LDS fragment reads, no chunk barrier - WRONG RESULTS by
+# construction), i.e. the bare MFMA stream of that tile on resident operands.  Never loaded by the product (lib.py loads $OUT).
+if [ -z "$EXTRA" ] && [ "$OUT" = "../libhific_hip.so" ]; then
+  if [ ! -f $OBJDIR/gconv_sp9_abl.o ] || [ gconv_sp9.hip -nt $OBJDIR/gconv_sp9_abl.o ] || [ gconv_stage.h -nt $OBJDIR/gconv_sp9_abl.o ] || [ gconv_dev.h -nt $OBJDIR/gconv_sp9_abl.o ] || [ gconv.h -nt $OBJDIR/gconv_sp9_abl.o ]; then
+    hipcc $FLAGS -DSP9_ABL=15 -c gconv_sp9.hip -o $OBJDIR/gconv_sp9_abl.o
+  fi
+  hipcc --offload-arch=gfx950 -shared -fPIC $(echo $OBJS | sed "s#$OBJDIR/gconv_sp9.o#$OBJDIR/gconv_sp9_abl.o#") -o ../libhific_hip_mfma_only.so
+fi
 # host-side (CPU) table construction + rANS coder for the EVALUATION path: plain g++, no device code
 g++ -O2 -std=c++17 -fPIC -shared -fno-fast-math host_tables.cpp host_rans.cpp -o ../libhific_host.so
 echo "built $OUT"

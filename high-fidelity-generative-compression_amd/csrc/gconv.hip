@@ -891,6 +891,15 @@ static int launch_gconv_tb(GcParams& p, const float* w, const float* w_scale, lo
             p.ph[0].OHt == p.ph[1].OHt && p.ph[0].OWt == p.ph[1].OWt && p.ph[2].OHt == p.ph[3].OHt &&
             p.ph[2].OWt == p.ph[3].OWt && (((size_t)p.out) & 7) == 0 && !env_int("HIFIC_MP_NO_PAIR", 0))
             p.epi_wide = 2;
+        // ... as 16-byte pieces through LDS (gconv_mp_kernel epi_wide 4): bf16 output, 4-pixel groups inside a tile row and the
+        // image, 16-byte aligned rows; needs 4 x 32 x 288 bytes of LDS after the main loop
+        if (p.epi_wide == 2 && !p.out_f32 && p.TW % 4 == 0 && p.OWf % 8 == 0 && (((size_t)p.out) & 15) == 0 &&
+            p.ph[0].OWt % 4 == 0 && p.ph[2].OWt % 4 == 0 && (long long)p.N * p.K * p.OHf * p.OWf < (1ll << 31) &&
+            env_int("HIFIC_MP_WIDE", 1)) {
+            p.epi_wide = 4;
+            const size_t need = (size_t)4 * 32 * 288;
+            if (need > lds) lds = need;
+        }
         // reflect-fold data gradients with an even left pad (the Encoder's asymmetric pad (1, 0, 0, 1)): pair stores into dx
         if (p.fold_h && p.out2 && !p.bias && p.act == ACT_NONE && p.fold_pl % 2 == 0 && p.fold_w % 2 == 0 &&
             p.ph[0].ooy == p.ph[1].ooy && p.ph[2].ooy == p.ph[3].ooy && p.ph[0].oox == 0 && p.ph[1].oox == 1 &&

@@ -274,6 +274,61 @@ void gconv_mp_kernel(const GcParams p) {
         }
         return;
     }
+    if (p.epi_wide == 4) {
+        // Wide pair stores (round 6): the pair store above is ONE 4-byte store per (row, pixel) - 32 stores per lane and tile,
+        // 67 of the 169 us of the 60 <- 120 @128 -> 256 layer in the round-4 ablation.  Here every wave interleaves the two column
+        // phases of its 32 rows x 64 pixels through a private LDS region ([row][64 px x 2 phases] bf16, pitch 288 B: the two
+        // half-waves land on disjoint banks) and stores 16-byte pieces = 4 pixels x 2 phases of one row: 8 stores per lane.
+        // Planner guarantees: bf16 output, TW % 4 == 0, OWt % 4 == 0 (a piece never straddles a tile row or the image edge),
+        // OWf % 8 == 0 and a 16-byte aligned output (every piece is 16-byte aligned), column phases at oox = 0 / 1.
+        constexpr int EP = 288;
+        const bool hb = p.bias != nullptr;
+        const float* bp = hb ? p.bias : (const float*)p.in;
+        const float slope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LEAKY ? 0.2f : 1.f);
+        const float osc = p.oscale ? *p.oscale : 1.f;
+        __syncthreads();                                   // every wave is done with the patch / weight ring
+        unsigned char* reg = smem + wave * (32 * EP);
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            bv[r] = (hb && m < p.K) ? bp[m] : 0.f;
+        }
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float x0 = acc0[ni][r] * osc + bv[r], x1 = acc1[ni][r] * osc + bv[r];
+                x0 = x0 > 0.f ? x0 : x0 * slope;
+                x1 = x1 > 0.f ? x1 : x1 * slope;
+                *(unsigned*)(reg + rl * EP + (ni * 32 + l31) * 4) = f2bf2(x0, x1);
+            }
+        __syncthreads();
+        // lane -> pixel group j = lane % 16 (4 consecutive pixels of one tile row), rows lane / 16 + 4 i
+        const int j = lane & 15;
+        const int pt = (wn * WN) * 32 + 4 * j;
+        const int img = pt / thw;
+        const int rem = pt - img * thw;
+        const int ty_ = rem / p.TW, tx_ = rem - ty_ * p.TW;
+        const int u_ = u0 + ty_, v_ = v0 + tx_, n_ = n0 + img;
+        const bool okp = img < p.NI && n_ < p.N && u_ < PA.OHt && v_ < PA.OWt;
+        const int oy = u_ * 2 + PA.ooy, ox = v_ * 2;
+        const unsigned plane = (unsigned)(p.OHf * p.OWf);
+        if (okp && (unsigned)oy < (unsigned)p.OHf) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rl = (lane >> 4) + 4 * i;
+                const int m = mbase + rl;
+                if (m < p.K) {
+                    const u32x4_t v = *(const u32x4_t*)(reg + rl * EP + j * 16);
+                    const unsigned idx = (unsigned)(n_ * p.K + m) * plane + (unsigned)(oy * p.OWf + ox);
+                    *(u32x4_t*)((bf16_t*)p.out + idx) = v;
+                }
+            }
+        }
+        return;
+    }
     if (p.epi_wide == 2) {
         const bool hb = p.bias != nullptr;
         const float* bp = hb ? p.bias : (const float*)p.in;

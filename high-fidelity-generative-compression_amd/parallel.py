@@ -79,7 +79,10 @@ class BucketedGradReducer:
         self.works = []
         # exposed communication: GPU time the launching stream spends in finish() waiting for collectives that the backward
         # pass did not hide (event pairs, read by exposed_comm_ms() after a synchronize); off unless measure_exposed(True)
-        self._measure, self._ev_pairs, self._bucket_ev = False, [], []
+        # ... and, separately (measure_timeline), one event pair per bucket around its collective: that mode makes the reduce stream
+        # wait for every collective before the next bucket's cast / collective is issued, i.e. it changes the schedule of the
+        # reduce stream - never on during a timed headline
+        self._measure, self._ev_pairs, self._timeline, self._bucket_ev, self._bucket_ev_last = False, [], False, [], []
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('HIFIC_FORCE_DIST') == '1')
         self.eager = bool(eager)
         self._reset()
@@ -87,6 +90,8 @@ class BucketedGradReducer:
             arena.on_write = self._on_write
 
     def _reset(self):
+        if self._bucket_ev:                                  # keep the LAST backward's events only (bounded)
+            self._bucket_ev_last, self._bucket_ev = self._bucket_ev, []
         self.count = [0] * len(self.expected)
         self.remaining = [b[2] for b in self.buckets]      # slots of each bucket still short of their write count
         self.launched = [False] * len(self.buckets)
@@ -128,7 +133,7 @@ class BucketedGradReducer:
                 red.wait_stream(st)
             with torch.cuda.stream(red):
                 wire = self._to_stage(lo, hi) if bf16 else grad
-                if self._measure:
+                if self._timeline:
                     # per-bucket timeline (bench.py `rccl.buckets_timeline`): issue = the reduce stream reaches the collective
                     # (every producer stream has delivered the bucket), done = the collective has finished.  The reduce stream
                     # is made to wait for the collective here, which changes nothing for the compute streams.
@@ -187,12 +192,19 @@ class BucketedGradReducer:
 
 
     def measure_exposed(self, on=True):
-        self._measure, self._ev_pairs, self._bucket_ev = bool(on), [], []
+        """Event pair around the waits of finish() (exposed_comm_ms); does not change what runs where."""
+        self._measure, self._ev_pairs = bool(on), []
+
+    def measure_timeline(self, on=True):
+        """Per-bucket issue / duration events (bucket_timeline).  Serialises the reduce stream behind every collective: use in a
+        short separate pass, not while timing."""
+        self._timeline, self._bucket_ev, self._bucket_ev_last = bool(on), [], []
 
     def bucket_timeline(self):
-        """[(bucket, MiB on the wire, issue ms after the first bucket's issue, duration ms)] of the LAST measured backward;
-        call after a device synchronize.  Empty unless measure_exposed(True) and the collectives ran on the reduce stream."""
-        ev, self._bucket_ev = self._bucket_ev, []
+        """[(bucket, MiB on the wire, issue ms after the first bucket's issue, duration ms)] of the LAST backward run under
+        measure_timeline(True); call after a device synchronize.  Empty when the collectives did not run on the reduce stream."""
+        ev = self._bucket_ev or self._bucket_ev_last
+        self._bucket_ev, self._bucket_ev_last = [], []
         if not ev:
             return []
         nb = len(self.buckets)

@@ -22,7 +22,7 @@ def _worker(rank, world, port, eager, q):
         arena = optim.ParamArena(ps)
         red = parallel.BucketedGradReducer(arena, bucket_mbytes=0.25, eager=eager)
         assert red.world == world and len(red.buckets) >= 3
-        red.measure_exposed(True)        # the measurement hooks of bench.py's multi-rank line must not disturb the reduction
+        red.measure_exposed(True); red.measure_timeline(True)        # the measurement hooks of bench.py's multi-rank line must not disturb the reduction
         for it in range(2):                                  # two backward passes: bookkeeping must reset
             for i in reversed(range(len(ps))):               # backward order
                 s = ps[i]._hific_slot
