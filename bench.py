@@ -1067,6 +1067,21 @@ def main():
                 out["parity"] = parity_leg(args, dev)
             except Exception as e:                      # the throughput line must survive a checker failure
                 out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+        # the small-layer launches as one class: hyperprior nets, LPIPS 15 x 15 layers, the
+        # Discriminator's context / output convs, the 960 -> 220 layer and their gradients - grids of 32-400 workgroups bound by
+        # neither roofline
+        small_keys = [k for k in prof if k in ("gconv_kernel<bf16,64,1,4,1,1>", "gconv_kernel<bf16,64,2,2,1,2>",
+                                                "gconv_kernel<bf16,64,2,2,2,2>", "gconv_sp9_kernel<2,4> narrow",
+                                                "gconv_sp9_kernel<1,1> narrow", "gconv_sp9_kernel<2,4,rfx> narrow",
+                                                "wgrad_kernel<bf16>")]
+        if small_keys:
+            ms_s = sum(prof[k]["ms_per_step"] for k in small_keys)
+            n_s = sum(prof[k]["launches_per_step"] for k in small_keys)
+            gf_s = sum(prof[k]["gflop_per_launch"] * prof[k]["launches_per_step"] for k in small_keys)
+            out["roofline"]["small_layers"] = {
+                "kernels": small_keys, "launches_per_step": round(n_s, 1), "ms_per_step": round(ms_s, 3),
+                "tflops": round(gf_s / ms_s, 1) if ms_s > 0 else None,
+                "frac_of_mfma_peak": round(gf_s / ms_s / peak, 4) if ms_s > 0 else None}
         pp = practical_peak()
         if pp is not None:
             out["roofline"]["practical_peak"] = pp

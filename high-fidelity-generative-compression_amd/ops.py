@@ -290,7 +290,7 @@ def _pack_stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _pack_streams.get(idx)
     if st is None:
-        st = _pack_streams[idx] = torch.cuda.Stream(device=device)
+        st = _pack_streams[idx] = torch.cuda.Stream(device=device, priority=_SIDE_PRIO)
     return st
 
 
@@ -568,6 +568,9 @@ _SIDE_ON = os.environ.get("HIFIC_SIDE_WGRAD", "1") not in ("0", "")
 # for ~0.2 ms after the main stream has finished the D-turn's data-gradient chain (tools/r05/tail.py), but two or three streams
 # measured the same cycle time within noise (1572 / 1570 / 1574 images/s, three runs each: round 5)
 _N_SIDE = max(1, int(os.environ.get("HIFIC_SIDE_STREAMS", "1")))
+# stream priority of the weight-gradient (side) and pack streams (HIP: lower number = higher priority; 0 = default): a positive
+# value lets the critical-path kernels of the main stream win the CUs (experiment knob, round 6)
+_SIDE_PRIO = int(os.environ.get("HIFIC_SIDE_PRIO", "0"))
 _side_streams = {}            # device index -> [streams]
 _side_state = {"pending": False, "cb": False, "rr": 0}
 
@@ -650,7 +653,7 @@ class _SideLaunch:
         dev = tensors[0].device
         sides = _side_streams.get(dev.index)
         if sides is None:
-            sides = _side_streams[dev.index] = [torch.cuda.Stream(device=dev) for _ in range(_N_SIDE)]
+            sides = _side_streams[dev.index] = [torch.cuda.Stream(device=dev, priority=_SIDE_PRIO) for _ in range(_N_SIDE)]
         if key is not None:
             side = sides[((int(key.index) * 2654435761) >> 16) % len(sides)]      # (weights sit at every other index)
         else:

@@ -72,6 +72,15 @@ def main():
             hbm += (2 * fs + wsz) * 1024 * c / steps
     print(f"\nkernel time per step: {total / steps / 1e3:.3f} ms over {steps:.0f} steady-state steps ({skip} warm-up cycles dropped); "
           f"HBM traffic per step (counter averages x launches): {hbm / 1e9:.2f} GB")
+    # the three totals VERDICT round 5 (item 2) asks for, steady state, every kernel (also the rows below the 0.2 % cut):
+    import re
+    gemm = lambda n: bool(re.search(r"gconv_|wgrad_(s1|s2|kernel|im2col|c3|pipe)", n)) and "finalize" not in n and "reduce" not in n
+    nl = sum(c for c, _, _ in tr.values()) / steps
+    gl = sum(c for n, (c, _, _) in tr.items() if gemm(n)) / steps
+    gms = sum(t for n, (_, t, _) in tr.items() if gemm(n)) / steps / 1e3
+    short = sum(c for c, _, a in tr.values() if a < 10.0) / steps
+    print(f"launches per step: {nl:.0f} (GEMM-class {gl:.0f} = {gms:.2f} ms; non-GEMM {nl - gl:.0f} = "
+          f"{total / steps / 1e3 - gms:.2f} ms; {short:.0f} launches of kernels that average under 10 us)")
 
 
 if __name__ == "__main__":
