@@ -7,7 +7,7 @@
 
 // ---- ticket buffers (common.h "tickets"): stream -> caller-owned zeroed counters ---------------------------------------------
 namespace {
-struct TicketSlot { hipStream_t st; unsigned* buf; int n; };
+struct TicketSlot { hipStream_t st; int dev; unsigned* buf; int n; };     // (device, stream): the null stream is handle 0 on every device
 TicketSlot g_tickets[64];
 int g_ntickets = 0;
 std::mutex g_ticket_mu;
@@ -17,8 +17,10 @@ unsigned* hific_tickets(hipStream_t st, int need) {
     std::lock_guard<std::mutex> lk(g_ticket_mu);
     if (g_tickets_on < 0) { const char* e = getenv("HIFIC_TICKETS"); g_tickets_on = (e && e[0] == '0') ? 0 : 1; }
     if (!g_tickets_on) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     for (int i = 0; i < g_ntickets; ++i)
-        if (g_tickets[i].st == st) return g_tickets[i].n >= need ? g_tickets[i].buf : nullptr;
+        if (g_tickets[i].st == st && g_tickets[i].dev == dev) return g_tickets[i].n >= need ? g_tickets[i].buf : nullptr;
     return nullptr;
 }
 
@@ -31,8 +33,10 @@ int hific_version(void) { return 100; }
 int hific_set_ticket_buffer(hipStream_t stream, void* buf, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_ticket_mu);
     g_tickets_on = -1;                                   // re-read HIFIC_TICKETS (tests flip it)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return HIFIC_ERR_ARG;     // the buffer belongs to the CURRENT device
     int at = -1;
-    for (int i = 0; i < g_ntickets; ++i) if (g_tickets[i].st == stream) at = i;
+    for (int i = 0; i < g_ntickets; ++i) if (g_tickets[i].st == stream && g_tickets[i].dev == dev) at = i;
     if (!buf) {
         if (at >= 0) g_tickets[at] = g_tickets[--g_ntickets];
         return HIFIC_OK;
@@ -42,7 +46,7 @@ int hific_set_ticket_buffer(hipStream_t stream, void* buf, size_t bytes) {
         if (g_ntickets >= 64) return HIFIC_ERR_UNSUPPORTED;
         at = g_ntickets++;
     }
-    g_tickets[at] = TicketSlot{stream, (unsigned*)buf, (int)(bytes / 4)};
+    g_tickets[at] = TicketSlot{stream, dev, (unsigned*)buf, (int)(bytes / 4)};
     return HIFIC_OK;
 }
 

@@ -1072,6 +1072,24 @@ __global__ void loss_combine_bwd_kernel(const float* __restrict__ g, const float
     else if (i < 3 + B) grads[i] = kP * gg / (float)B;
 }
 
+// Reflect (ReflectionPad2d semantics) or zero padding of [planes, H, W] -> [planes, H + pt + pb, W + pl + pr]: the EVALUATION
+// path's pad-to-a-multiple-of-16 (src/helpers/utils.py:50-62) - the training path never materialises a padded tensor.
+template <typename T>
+__global__ void pad2d_kernel(const T* __restrict__ x, T* __restrict__ y, long long planes, int H, int W, int pt, int pl, int Ho,
+                             int Wo, int reflect) {
+    const long long total = planes * Ho * Wo;
+    EW_LOOP(i, total) {
+        const int xo = (int)(i % Wo);
+        const long long j = i / Wo;
+        const int yo = (int)(j % Ho);
+        const long long pc = j / Ho;
+        int yi = yo - pt, xi = xo - pl;
+        bool in = (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W;
+        if (reflect) { yi = reflect_idx(yi, H); xi = reflect_idx(xi, W); in = true; }
+        y[i] = in ? x[(pc * H + yi) * W + xi] : (T)0;
+    }
+}
+
 extern "C" {
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
@@ -1191,6 +1209,18 @@ int hific_loss_combine_bwd(const float* g, const float* aux, int B, float kM, fl
                            hipStream_t st) {
     if (!g || !aux || B <= 0 || !grads) return HIFIC_ERR_ARG;
     hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(cdiv(3 + B, 64)), dim3(64), 0, st, g, aux, B, kM, kP, beta, grads);
+    return hific_launch_status();
+}
+
+int hific_pad2d(const void* x, void* y, long long planes, int H, int W, int pt, int pl, int pb, int pr, int reflect, int dtype,
+                hipStream_t st) {
+    if (!x || !y || planes <= 0 || H <= 0 || W <= 0 || pt < 0 || pl < 0 || pb < 0 || pr < 0) return HIFIC_ERR_ARG;
+    if (reflect && (pt >= H || pb >= H || pl >= W || pr >= W)) return HIFIC_ERR_ARG;
+    const int Ho = H + pt + pb, Wo = W + pl + pr;
+    const long long total = planes * Ho * Wo;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(pad2d_kernel<float>, EW_GRID(total), dim3(256), 0, st, (const float*)x, (float*)y, planes, H, W, pt, pl, Ho, Wo, reflect),
+        hipLaunchKernelGGL(pad2d_kernel<bf16_t>, EW_GRID(total), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, planes, H, W, pt, pl, Ho, Wo, reflect));
     return hific_launch_status();
 }
 

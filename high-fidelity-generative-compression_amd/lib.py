@@ -44,6 +44,7 @@ SIGNATURES = {
     "hific_scale_shift": (I, [P, P, L, F, F, I, P]),
     "hific_add": (I, [P, P, P, L, I, P]),
     "hific_cast": (I, [P, I, P, I, L, P]),
+    "hific_pad2d": (I, [P, P, L, I, I, I, I, I, I, I, I, P]),
     "hific_add_split": (I, [P, I, P, I, P, P, I, I, I, I, P]),
     "hific_split3": (I, [P, P, L, I, L, I, I, P]),
     "hific_axpby_f32": (I, [P, P, P, F, F, L, P]),
@@ -202,7 +203,8 @@ def workspace(device, min_bytes=0):
             # the stream's ticket counters (include/hific_hip.h "tickets"): zeroed once, self-cleaning afterwards
             tk = torch.zeros(_TICKET_BYTES, dtype=torch.uint8, device=device)
             _tickets[key] = tk
-            call("hific_set_ticket_buffer", key[1], tk.data_ptr(), tk.numel())
+            with torch.cuda.device(key[0]):                  # the registry is keyed by (current device, stream)
+                call("hific_set_ticket_buffer", key[1], tk.data_ptr(), tk.numel())
     return ws
 
 
@@ -216,13 +218,14 @@ def set_tickets(on):
     global _TICKETS_ON
     _TICKETS_ON = bool(on)
     for key, ws in _workspaces.items():
-        if on:
-            tk = _tickets.get(key)
-            if tk is None:
-                tk = _tickets[key] = torch.zeros(_TICKET_BYTES, dtype=torch.uint8, device=ws.device)
-            call("hific_set_ticket_buffer", key[1], tk.data_ptr(), tk.numel())
-        else:
-            call("hific_set_ticket_buffer", key[1], None, 0)
+        with torch.cuda.device(key[0]):
+            if on:
+                tk = _tickets.get(key)
+                if tk is None:
+                    tk = _tickets[key] = torch.zeros(_TICKET_BYTES, dtype=torch.uint8, device=ws.device)
+                call("hific_set_ticket_buffer", key[1], tk.data_ptr(), tk.numel())
+            else:
+                call("hific_set_ticket_buffer", key[1], None, 0)
 
 
 def exported_symbols():

@@ -56,7 +56,8 @@ int hific_device_info(int device, char* name64, int* cus, int* lds_per_cu);
  * workgroup run the second stage (agent-scope release / acquire around an atomic counter; the counters are zero again when
  * the launch ends).  Without a registered buffer (or with HIFIC_TICKETS=0) every entry point keeps its two-launch form: same
  * results (the scalar, channel and tap sums bit for bit; the ChannelNorm parameter sums in another, fixed, summation order).
- * One buffer per stream: launches of one stream are ordered, launches of different streams must not share counters.
+ * One buffer per (current device, stream) - the null stream is handle 0 on every device, so the registry is keyed by both; call
+ * with the buffer's device current.  Launches of one stream are ordered, launches of different streams must not share counters.
  * 16 KiB per stream is enough for every entry point. */
 int hific_set_ticket_buffer(hipStream_t stream, void* buf, size_t bytes);
 
@@ -150,6 +151,10 @@ int hific_cast(const void* a, int src_dtype, void* o, int dst_dtype, long long n
  * source channel 16 g + j -> channels 32 g + j (hi) and 32 g + 16 + j (lo), padding channels zero; activations and weights
  * alike.  A convolution whose flags carry bit 3 reads both operands in this layout and issues hi*hi + hi*lo + lo*hi per
  * 16-channel slice pair itself: 2C instead of 3C staged channels for the same three MFMAs. */
+/* Reflect (ReflectionPad2d) or zero padding of [planes, H, W] into [planes, H + pt + pb, W + pl + pr]: the EVALUATION path pads
+ * images and latents to a multiple of 16 / 4 before compressing (src/helpers/utils.py:50-62, src/model.py:276-284). */
+int hific_pad2d(const void* x, void* y, long long planes, int H, int W, int pt, int pl, int pb, int pr, int reflect, int dtype,
+                hipStream_t stream);
 /* Sum of two activations held as split-bf16 images (the head skip of the exact Generator chain, src/network/generator.py:161):
  * y3 (layout lo) and the nominal bf16 y [N,C,HW] of (a_hi + a_lo) + (b_hi + b_lo); layouts 0 = (hi, lo, hi) over 3C channels,
  * 2 = pair layout. */

@@ -114,3 +114,17 @@ def test_lpips_tap_sums_bit_identical_and_counters_self_clean(hific, dev):
     assert all(torch.equal(o, a) for o in outs)
     key = next(k for k in lib._tickets)
     assert int(lib._tickets[key].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("shape,factor", [((2, 3, 37, 50), 16), ((1, 220, 7, 9), 4), ((2, 3, 64, 64), 16)])
+def test_pad_factor_on_the_device_equals_reflection_pad(hific, dev, shape, factor):
+    """helpers.utils.pad_factor (src/helpers/utils.py:50-62, the EVALUATION path's pad to a multiple of 16 / 4) through
+    hific_pad2d: bit-identical to F.pad(mode='reflect'), no-op when already aligned."""
+    import torch.nn.functional as F
+    from hific_amd.helpers import utils
+    x = torch.randn(*shape, device=dev)
+    y = utils.pad_factor(x, x.shape[2:], factor)
+    H, W = shape[2], shape[3]
+    ph, pw = (factor - H % factor) % factor, (factor - W % factor) % factor
+    ref = F.pad(x, (0, pw, 0, ph), mode="reflect") if (ph or pw) else x
+    assert y.shape == ref.shape and torch.equal(y, ref)
