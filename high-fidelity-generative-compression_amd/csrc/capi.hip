@@ -103,6 +103,10 @@ int hific_conv2d_fwd(const void* x, const float* w, const float* w_scale, const 
         if (!w_scale || resid) return HIFIC_ERR_ARG;
         g.oscale = w_scale; w_scale = nullptr;
     }
+    if (flags & 32) {            // split-in-pack: w is [K, C / 3, R, S]; the pack forms the (hi, hi, lo) image (bit 2 layout)
+        if (!(flags & 4) || (flags & 8) || dtype != HIFIC_BF16 || C % 3 != 0 || (C / 3) % 64 != 0 || w_scale) return HIFIC_ERR_ARG;
+        g.wsplit = 1;
+    }
     return gc_conv_fwd(g, x, w, w_scale, bias, y, resid, act, dtype, flags & 1, (flags >> 1) & 1, a, stream);
 }
 
@@ -178,6 +182,10 @@ int hific_conv2d_pack_plan(int kind, int N, int C, int H, int W, int K, int R, i
     const float* fake_w = (const float*)job;       // never dereferenced in a plan-only call
     g.red_split = (flags & 8) ? 2 : 0;                          // (the plan - and so the pack layout - depends on it)
     if (flags & 16) g.oscale = fake_w;                          // ... and on the epilogue-scale form (kernel choice)
+    if (flags & 32) {                                           // ... and on split-in-pack (source strides of the job)
+        if (kind != 0 || (flags & 8) || C % 3 != 0 || (C / 3) % 64 != 0) return HIFIC_ERR_ARG;
+        g.wsplit = 1;
+    }
     if (kind == 0) return gc_conv_fwd(g, job, fake_w, nullptr, nullptr, job, nullptr, ACT_NONE, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
     return gc_conv_bwd_data(g, job, fake_w, nullptr, job, dtype, flags & 1, (flags >> 1) & 1, a, nullptr);
 }

@@ -41,6 +41,10 @@ struct GcParams {
     // virtual channels (few-channel layers, see launch_gconv_fewc): reduction channel cc = c * csplit + j reads weight
     // column vcol_s[j]; output row mm = k * msplit + j reads weight column vrow_s[j] (0: off)
     int csplit, msplit;
+    // split-in-pack (round 6): the weight tensor has wsplit_C real reduction channels and the packed image 3 * wsplit_C =
+    // (hi, hi, lo) of them (hific_split3 which = 1), formed by the pack pass itself - no float32 (hi, hi, lo) weight image is
+    // materialised (16 B written + 12 B re-read per weight and optimizer step).  wsplit_C % 64 == 0; 0 = off.
+    int wsplit_C;
     short vcol_s[16];
     int epi_wide;        // wide-store epilogue through LDS (gc_epilogue_wide): legality checked by the plan
     int wstage;          // wide-load staging (stage_W): bf16 NCHW input, IW % 8 == 0, 16-byte aligned (set by the plan)
@@ -98,6 +102,7 @@ struct ConvGeom {
     int red_split = 0;   // 1: C is 3x the layer's channels (split-bf16 operands, hific_split3): count 1/3 of the FLOPs
                          // 2: C is the pair layout (2 * C16) of the native split kernels; red_C = the layer's real channels
     int red_C = 0;
+    int wsplit = 0;                  // 1: `w` is the layer's real [K, C / 3, R, S] weight, the pack forms (hi, hi, lo) (flags bit 5)
     const float* oscale = nullptr;   // see GcParams::oscale (conv2d fwd / bwd-data flags bit 4)
     int OH() const { return (H + pt + pb - R) / stride + 1; }
     int OW() const { return (W + pl + pr - S) / stride + 1; }

@@ -1301,6 +1301,10 @@ int gc_conv_fwd(const ConvGeom& g, const void* x, const float* w, const float* w
     p.oscale = g.oscale;
     const double cred = g.red_split == 2 ? (g.red_C > 0 ? g.red_C : g.C / 2) : (g.red_split ? g.C / 3.0 : g.C);
     p.aflops = 2.0 * g.K * cred * (double)RS * g.N * g.OH() * g.OW();
+    if (g.wsplit) {          // `w` has C / 3 channels per row: the pack reads it three times (hi, hi, lo)
+        p.wsplit_C = g.C / 3;
+        return launch_gconv(p, dtype, w, w_scale, (long long)(g.C / 3) * RS, RS, g.S, 1, ws, st);
+    }
     return launch_gconv(p, dtype, w, w_scale, (long long)g.C * RS, RS, g.S, 1, ws, st);
 }
 

@@ -54,7 +54,11 @@ __device__ __forceinline__ void pack_w2_body(const GcParams& p, const float* __r
         const int cvalid = (p.C - c0 < 64 ? p.C - c0 : 64) * RS;
         const float inv_rs = 1.0f / (float)RS, inv_n = 1.0f / (float)n;
         const int total = mb * n;
-        const float* wrow = w + (long long)c0 * sc;
+        // split-in-pack (GcParams::wsplit_C): the 64 packed channels c0.. are channels c0 % Cr.. of the real weight, as hi (parts
+        // 0, 1) or lo (part 2) of their bf16 split; Cr % 64 == 0, so a block never straddles two parts
+        const int Cr = p.wsplit_C;
+        const int wpart = Cr ? c0 / Cr : 0;
+        const float* wrow = w + (long long)(Cr ? c0 - wpart * Cr : c0) * sc;
         // 16-byte loads when every m row of the block is 16-byte aligned (C * RS % 4 == 0: all layers but the 3-channel ones):
         // four floats per lane and request instead of one (the pack ran at 2.4-3.1 TB/s with 4-byte loads; Adam streams at 4.7)
         const bool vec4 = ((sm & 3) == 0) && ((((size_t)wrow) & 15) == 0);
@@ -86,6 +90,7 @@ __device__ __forceinline__ void pack_w2_body(const GcParams& p, const float* __r
                             float x = 0.f;
                             if (rowok && whole) x = vv[e] * sc_;
                             else if (rowok && ie < cvalid) x = wrow[(long long)(m0 + ml) * sm + ie] * sc_;   // (channel tail of the last block)
+                            if (Cr) { const float h_ = bf2f(f2bf(x)); x = wpart < 2 ? h_ : x - h_; }
                             pk_lds[c * pitch + ml * RS + (ie - c * RS)] = x;
                         }
                     }
@@ -110,7 +115,9 @@ __device__ __forceinline__ void pack_w2_body(const GcParams& p, const float* __r
                     const int i = j - ml * n;
                     const int c = (int)(((float)i + 0.5f) * inv_rs);
                     const bool ok = m0 + ml < p.K && i < cvalid;
-                    pk_lds[c * pitch + ml * RS + (i - c * RS)] = ok ? v[u] * sc_ : 0.f;
+                    float x = ok ? v[u] * sc_ : 0.f;
+                    if (Cr) { const float h_ = bf2f(f2bf(x)); x = wpart < 2 ? h_ : x - h_; }
+                    pk_lds[c * pitch + ml * RS + (i - c * RS)] = x;
                 }
             }
         }
@@ -262,7 +269,8 @@ static int gc_pack_weights(GcParams& p, long long wp_elems, const float* w, cons
         const bool contiguous = (sr == p.tap_sw && ss == 1 && RS > 0);
         job.sm = sm; job.sc = sc; job.sr = sr; job.ss = ss; job.RS = RS; job.MB = 1; job.dtype = DT<T>::code;
         job.wp_bytes = (long long)wp_bytes;
-        if (contiguous && sc == RS && !p.csplit && !p.msplit && !env_int("HIFIC_OLD_PACK", 0)) {
+        if (p.wsplit_C && !(contiguous && sc == RS && !p.csplit && !p.msplit) ) return HIFIC_ERR_UNSUPPORTED;   // mode 0 only
+        if (contiguous && sc == RS && !p.csplit && !p.msplit && (p.wsplit_C || !env_int("HIFIC_OLD_PACK", 0))) {
             int MB = 40960 / (64 * RS * 4); if (MB > 16) MB = 16; if (MB < 1) MB = 1;
             job.mode = 0; job.MB = MB; job.gx = p.Cpad / 64 + (p.Cpad % 64 ? 1 : 0); job.gy = cdiv(p.Kpad, MB);
             job.lds_bytes = (int)((size_t)64 * ((MB * RS) | 1) * sizeof(float));

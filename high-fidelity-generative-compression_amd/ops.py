@@ -516,6 +516,22 @@ def _exact_flags(layout, C):
     return (1 << 1) | ((1 << 3) | (C << 8) if layout == SPLIT_PAIR else (1 << 2))
 
 
+# split-in-pack (hific_conv2d_fwd flags bit 5, round 6): for a 3C-layout exact nn.Conv2d whose channel count is a multiple of 64
+# (the residual trunk, the 960 -> 220 Encoder layer) the packed (hi, hi, lo) operand is formed by the weight-pack pass from the
+# float32 master weight itself - no derived [K, 3C, R, S] float32 image (SplitWeightCache) is written and re-read after every
+# optimizer step (34 -> 10 bytes per weight and step).  HIFIC_SPLIT_IN_PACK=0 restores the derived image.
+_SPLIT_IN_PACK = os.environ.get("HIFIC_SPLIT_IN_PACK", "1") not in ("0", "")
+
+
+def _split_in_pack(weight, layout, transposed=False):
+    return _SPLIT_IN_PACK and layout == SPLIT_3C and not transposed and weight.shape[1] % 64 == 0 and _PACK_CACHE_ON
+
+
+def set_split_in_pack(on):
+    global _SPLIT_IN_PACK
+    _SPLIT_IN_PACK = bool(on)
+
+
 def _wcache(weight, kind, geom, cd, flags, w_scale=None, transposed=False):
     """Cache arguments of a forward-type conv call; spectral-norm convs (w_scale changes every forward) bypass it."""
     if w_scale is not None or not weight.is_cuda:
@@ -780,8 +796,11 @@ class Conv2dFn(Function):
             if Cx != (pair_channels(C) if lay == SPLIT_PAIR else 3 * C):
                 raise lib.HificError(f"conv2d(exact): split image has {Cx} channels, layout {lay} of {C} channels needs "
                                      f"{pair_channels(C) if lay == SPLIT_PAIR else 3 * C}")
-            w3 = split_weights.get(weight, transposed=False, layout=lay)
             flags = _exact_flags(lay, C)
+            if _split_in_pack(weight, lay):
+                w3, flags = weight, flags | 32               # the pack pass forms (hi, hi, lo) from the master weight
+            else:
+                w3 = split_weights.get(weight, transposed=False, layout=lay)
             wc = _wcache(w3, 0, (N, Cx, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode), cd, flags & 0xff, None)
             call("hific_conv2d_fwd", ptr(x3), ptr(w3), None, ptr(bias), None, ptr(y),
                  N, Cx, H, W, K, R, S, stride, pt, pl, pb, pr, pad_mode, _act_code(act), cd, flags, wsp, wsb, *wc, stream())
@@ -1047,7 +1066,10 @@ class ExactConvNormFn(Function):
         assert tuple(x3.shape) == (N, Cx, H, W) and x3.dtype == torch.bfloat16
         flags = _exact_flags(lay_in, C)
         wsp, wsb = _ws(x)
-        w3 = split_weights.get(weight, transposed=transposed, layout=lay_in)
+        if _split_in_pack(weight, lay_in, transposed):
+            w3, flags = weight, flags | 32                   # the pack pass forms (hi, hi, lo) from the master weight
+        else:
+            w3 = split_weights.get(weight, transposed=transposed, layout=lay_in)
         if transposed:
             stride, pad, outpad = geom
             Cw, K, R, S = weight.shape

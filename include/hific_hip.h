@@ -16,7 +16,10 @@
  *   - `flags` on conv entry points, meaningful for HIFIC_BF16 only: bit0 = the input activation tensor is float32,
  *     bit1 = the output activation tensor is float32 (entropy-model boundary stays float32); forward entry points only:
  *     bit2 = C is the 3C split-bf16 reduction (hific_split3 which 0/1; profiler FLOP count only), bit3 = both operands are in
- *     the pair layout (hific_split3 which 2; C = 2 * C16, native split kernel), bits 8.. = the layer's real channel count
+ *     the pair layout (hific_split3 which 2; C = 2 * C16, native split kernel), bits 8.. = the layer's real channel count;
+ *     hific_conv2d_fwd / hific_conv2d_pack_plan(kind 0) only, with bit2: bit5 = split-in-pack - `w` is the layer's REAL float32
+ *     weight [K, C / 3, R, S] ((C / 3) % 64 == 0) and the weight-pack pass forms the (hi, hi, lo) image over the 3C reduction
+ *     channels itself (bit for bit what hific_split3 which = 1 + the ordinary pack produce, without the derived float32 tensor)
  *   - thread-safe for distinct streams as long as the workspaces are distinct
  *   - NO collective entry point (SURVEY section 8b proposed `hific_allreduce_bucket`): the data-parallel exchange is one
  *     all-reduce per contiguous gradient-arena slice, which is exactly ncclAllReduce(ptr, count, dtype, sum, comm, stream) -

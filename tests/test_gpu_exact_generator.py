@@ -218,3 +218,35 @@ def test_generator_conv_norm_nodes_are_bit_identical_to_separate_ops(hific, dev,
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
     hific.set_compute_dtype(torch.float32)
+
+
+def test_split_in_pack_is_bit_identical_to_the_derived_weight_image(hific, dev, sd):
+    """hific_conv2d_fwd flags bit 5 (ops._split_in_pack): the (hi, hi, lo) packed operand of a 3C exact convolution formed by the
+    pack pass from the float32 master weight - same bits as hific_split3(which = 1) followed by the ordinary pack: the exact
+    Generator chain (960-channel trunk: split-in-pack applies) gives identical outputs and gradients either way, also after
+    the weights change (the pack is re-made from the master weight)."""
+    from hific_amd import ops
+    y = (O.make_noise(3, (2, 220, 8, 8)) * 4)
+    ops.set_exact_training(True)
+    res = []
+    for on in (True, False):
+        ops.set_split_in_pack(on)
+        ops.pack_cache.clear(); ops.split_weights.clear()
+        try:
+            gen = _gen(hific, dev, sd)
+            outs = []
+            for step in range(2):
+                yd = y.to(dev).requires_grad_(True)
+                x = gen(yd)
+                x.sum().backward()
+                outs.append((x.detach().clone(), yd.grad.clone()))
+                with torch.no_grad():                       # a torch-visible in-place update: the version counters move
+                    for p_ in gen.parameters():
+                        p_.mul_(1.0 + 1e-3)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_split_in_pack(True)
+        res.append(outs)
+    for (xa, ga), (xb, gb) in zip(*res):
+        assert torch.equal(xa, xb) and torch.equal(ga, gb)
+    assert not torch.equal(res[0][0][0], res[0][1][0])       # the update really changed the result
