@@ -128,3 +128,44 @@ def test_pad_factor_on_the_device_equals_reflection_pad(hific, dev, shape, facto
     ph, pw = (factor - H % factor) % factor, (factor - W % factor) % factor
     ref = F.pad(x, (0, pw, 0, ph), mode="reflect") if (ph or pw) else x
     assert y.shape == ref.shape and torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("target_rate,gan", [(None, True), (1e3, True), (None, False)], ids=["gan_lambda_A", "gan_lambda_B", "no_gan"])
+def test_fused_loss_composition_equals_the_torch_glue(hific, dev, monkeypatch, target_rate, gan):
+    """ops.LossCombineFn (hific_loss_combine_fwd / _bwd: k_M mse + k_P mean(lpips) + lambda(q_bpp) n_bpp [+ beta G_loss] with the
+    rate rule of src/loss/losses.py:8-28 on the device) against the reference-shaped composition on zero-dimensional torch
+    tensors (Model.compression_loss + `loss + beta * G_loss`): same loss to float32 rounding, same gradients for every
+    parameter - both branches of the rate rule (q_bpp above / below the target) and the model without a Discriminator."""
+    import hific_amd
+    from hific_amd import model as model_mod
+    from hific_amd.default_config import make_args, hific_args, mse_lpips_args, ModelTypes
+    from oracle import hific_oracle as O
+    hific.set_compute_dtype(torch.float32)
+    kw = dict(batch_size=2, image_dims=(3, 128, 128), latent_dims=(220, 8, 8), n_residual_blocks=2)
+    if target_rate is not None:
+        kw["target_rate"] = target_rate
+    args = make_args(hific_args if gan else mse_lpips_args, **kw)
+    x = O.make_image(1, 2, 128, 128).to(dev)
+    nh, nl = O.make_noise(6, (2, 320, 2, 2)).to(dev), O.make_noise(7, (2, 220, 8, 8)).to(dev)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(model_mod, "_FUSED_LOSS", fused)
+        torch.manual_seed(0)
+        m = hific_amd.Model(args, model_type=ModelTypes.COMPRESSION_GAN if gan else ModelTypes.COMPRESSION,
+                            device_rate_select=True, allow_random_lpips_backbone=True)
+        m.load_state_dict(O.make_state_dict(seed=0, gan=gan, n_res=2), strict=True)
+        m.perceptual_loss.load_backbone_state_dict(O.make_alex_backbone())
+        m = m.to(dev).train()
+        noises = [nh, nl]
+        m.Hyperprior._draw_noise = lambda t: noises.pop(0)
+        losses = m(x, train_generator=True, writeout=False)
+        assert m._fused_loss_ok(x) == fused
+        losses["compression"].backward()
+        torch.cuda.synchronize()
+        res.append((float(losses["compression"].detach()), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (la, ga), (lb, gb) = res
+    assert abs(la - lb) <= 2e-6 * abs(lb), (la, lb)
+    assert set(ga) == set(gb)
+    for k in ga:
+        scale = float(gb[k].abs().max()) + 1e-30
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * scale, (k, float((ga[k] - gb[k]).abs().max()) / scale)
