@@ -169,3 +169,32 @@ def test_fused_loss_composition_equals_the_torch_glue(hific, dev, monkeypatch, t
     for k in ga:
         scale = float(gb[k].abs().max()) + 1e-30
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * scale, (k, float((ga[k] - gb[k]).abs().max()) / scale)
+
+
+def test_spectral_norm_backward_uses_the_uv_of_its_own_forward(hific, dev):
+    """The batched power iteration writes copies of the post-iteration (u, v) behind [sigma, 1/sigma]
+    (hific_spectral_norm_fwd_batch do_iter bit 1) and SNConv2dFn / D1StageFn save THOSE: a second training forward (which
+    iterates the buffers in place) between a forward and its backward must not change that backward - as with torch's
+    spectral_norm, which clones u and v (src/network/discriminator.py:46-62)."""
+    from hific_amd.network.discriminator import Discriminator
+    from oracle import hific_oracle as O
+    hific.set_compute_dtype(torch.float32)
+    sd = O.make_state_dict(seed=0, gan=True, n_res=2)
+    real = O.make_image(9, 2, 64, 64).to(dev)
+    gen = O.make_image(12, 2, 64, 64).to(dev)
+    lat = (O.make_noise(10, (2, 220, 4, 4)) * 4).to(dev)
+    grads = []
+    for twice in (False, True):
+        D = Discriminator((3, 64, 64), (220, 4, 4), C=220)
+        D.load_state_dict({k[len("Discriminator."):]: v for k, v in sd.items() if k.startswith("Discriminator.")}, strict=True)
+        D = D.to(dev).train()
+        g = gen.clone().requires_grad_(True)
+        _, logits = D.forward_pairs(real, g, lat)
+        if twice:
+            with torch.no_grad():
+                D.forward_pairs(real, gen, lat)            # iterates weight_u / weight_v in place once more
+        logits.sum().backward()
+        torch.cuda.synchronize()
+        grads.append([g.grad.clone()] + [p.grad.clone() for p in D.parameters()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
