@@ -827,6 +827,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("HIFIC_FORCE_DIST") == "1"   # the latter: 1-rank RCCL smoke test
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a five-line version banner to
+    # fd 1 when its first communicator comes up): everything but the line itself goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
+        os.dup2(2, 1)
+
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if use_dist:
@@ -923,7 +935,7 @@ def main():
             "gemm_class_ms_per_step": round(sum(v["ms_per_step"] for v in prof.values()), 3),
         }
         if os.environ.get("HIFIC_BENCH_ROOFLINE_ONLY") == "1":      # kernel experiments: headline + per-kernel table, nothing else
-            print(json.dumps(out), flush=True)
+            emit(out)
             return
         del model, opts, reducers, step, run_step
         hific_ops.pack_cache.clear(); hific_ops.split_weights.clear()
@@ -1099,7 +1111,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
 
