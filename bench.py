@@ -244,12 +244,15 @@ def scale_report(args, step, reducers, opts, world, rank, dev, fence, ms_step):
         for k, r in reducers.items():
             r.active = False
             r.arena.on_write = None
+        # the model's own collective (global mean of q_bpp for the rate rule, two per cycle) has no partner either
+        scalars_were = parallel.set_scalar_collectives(False)
         step(); step()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(n):
             step()
         torch.cuda.synchronize()
         solo = (time.perf_counter() - t0) / n * 1e3
+        parallel.set_scalar_collectives(scalars_were)
         for k, r in reducers.items():
             r.active = was[k]
             if r.active and r.eager:
@@ -839,13 +842,21 @@ def main():
         print(json.dumps(obj), flush=True)
         os.dup2(2, 1)
 
+    # HIFIC_BENCH_REHEARSAL=1: the multi-rank control flow on a ONE-GPU box - every rank on cuda:0, gloo as the transport (RCCL
+    # refuses two ranks on one device).  Same reducers, same collectives in the same order, same report; the numbers mean nothing.
+    rehearsal = os.environ.get("HIFIC_BENCH_REHEARSAL") == "1" and world > 1
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def fence():
         torch.cuda.synchronize()
@@ -869,7 +880,8 @@ def main():
     rccl = None
     if use_dist:
         # the job the driver launched is the job the collectives run in
-        assert dist.get_backend() == "nccl" and dist.get_world_size() == world == int(os.environ.get("WORLD_SIZE", "1")), \
+        assert dist.get_backend() == ("gloo" if rehearsal else "nccl") and \
+            dist.get_world_size() == world == int(os.environ.get("WORLD_SIZE", "1")), \
             (dist.get_backend(), dist.get_world_size(), world, os.environ.get("WORLD_SIZE"))
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -878,7 +890,7 @@ def main():
         exp_ms = sum(r.exposed_comm_ms() for r in reducers.values()) / (args.steps + args.warmup)
         t = torch.tensor([exp_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        rccl = {"backend": "nccl (RCCL)", "rccl_ranks": world,
+        rccl = {"backend": "gloo (REHEARSAL on one device: control flow only)" if rehearsal else "nccl (RCCL)", "rccl_ranks": world,
                 "buckets": {k: len(r.buckets) for k, r in reducers.items()},
                 "bucket_mbytes": float(os.environ.get("HIFIC_BUCKET_MB", 128)),
                 "gradient_payload": next(iter(reducers.values())).payload,

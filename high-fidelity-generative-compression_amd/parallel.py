@@ -221,10 +221,21 @@ class BucketedGradReducer:
         return ms
 
 
+_SCALAR_COLLECTIVES = True
+
+
+def set_scalar_collectives(on):
+    """Measurement runs that step ONE rank of a job alone (bench.py scale_report: the other ranks are parked in a barrier) must
+    not issue the model's own collective either: off = allreduce_scalar_mean is the identity.  Returns the previous setting."""
+    global _SCALAR_COLLECTIVES
+    was, _SCALAR_COLLECTIVES = _SCALAR_COLLECTIVES, bool(on)
+    return was
+
+
 def allreduce_scalar_mean(t, process_group=None):
     """Global-batch mean of a 0-d loss term (the rate-penalty branch: every rank must pick the same lambda,
     SURVEY section 8e).  Identity when torch.distributed is not initialised or the world has one rank."""
-    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+    if _SCALAR_COLLECTIVES and dist.is_initialized() and dist.get_world_size(process_group) > 1:
         t = t.detach().clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
         t /= dist.get_world_size(process_group)

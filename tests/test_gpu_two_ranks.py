@@ -171,3 +171,30 @@ def test_two_ranks_gan_equal_the_mean_of_the_shards(hific, dev, tmp_path):
         del model, arenas
     assert abs(sharded["mean_loss"] - sum(losses) / WORLD) < 1e-5 * abs(losses[0])
     _compare(sharded["grads"], acc, 2e-5, "compression_gan: 2 ranks vs mean of the two shards' gradients")
+
+
+def test_bench_multi_rank_control_flow_rehearsal():
+    """`bench.py` as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`),
+    rehearsed on ONE GPU: HIFIC_BENCH_REHEARSAL=1 puts every rank on cuda:0 with gloo as the transport (RCCL refuses two ranks
+    on one device).  Same reducers, same collectives in the same order, same report: a collective that one rank issues and
+    another does not (as the rate rule's global q_bpp mean did inside scale_report's rank-0-alone pass) hangs here, under the
+    timeout, instead of on the 8-GPU node.  stdout must be the one JSON line, with the multi-rank block filled in."""
+    import json
+    import subprocess
+    env = dict(os.environ, HIFIC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("HIFIC_FORCE_DIST", None)
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 32
+    r = d["rccl"]
+    assert r["rccl_ranks"] == 2 and "REHEARSAL" in r["backend"]
+    assert set(r["payload_sweep_ms_per_step"]) == {"f32", "bf16"}
+    assert r["one_rank_same_box_ms_per_step"] > 0 and r["weak_scaling_eff"] > 0
+    assert all(len(v) >= 1 for v in r["buckets_timeline"].values())
