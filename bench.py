@@ -847,10 +847,11 @@ def main():
     rehearsal = os.environ.get("HIFIC_BENCH_REHEARSAL") == "1" and world > 1
     if rehearsal:
         local = 0
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (read when the runtime comes up: before the first device call)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:

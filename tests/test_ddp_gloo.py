@@ -190,3 +190,42 @@ def test_bucketed_allreduce_world2(hific, eager):
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _worker_solo_rank(rank, world, port, q):
+    """bench.py scale_report: rank 0 steps ALONE (reducers off) while the other ranks wait in a barrier.  With the scalar
+    collectives off, rank 0's allreduce_scalar_mean calls issue nothing, so the next collective every rank takes part in (the
+    barrier) still pairs up; back on, the global mean is the global mean again."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hific_amd import parallel
+        if rank == 0:
+            was = parallel.set_scalar_collectives(False)
+            assert was is True
+            for _ in range(5):
+                t = torch.tensor(3.0)
+                assert float(parallel.allreduce_scalar_mean(t)) == 3.0
+            assert parallel.set_scalar_collectives(was) is False
+        dist.barrier()
+        m = parallel.allreduce_scalar_mean(torch.tensor(float(rank + 1)))
+        assert abs(float(m) - (world + 1) / 2.0) < 1e-6
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_can_step_alone_without_issuing_collectives_world2(hific):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29870 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_worker_solo_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
