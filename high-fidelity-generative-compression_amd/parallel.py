@@ -13,6 +13,8 @@ rest of backward.  Bucket size defaults to 128 MiB ($HIFIC_BUCKET_MB): four of t
 weight tensors per collective, six collectives for the 726 MB of amortisation-model gradients - few, large transfers
 for the per-link-bound xGMI ring, and the first one still starts after ~1/5 of the residual stack's backward (measured
 with one rank, where the collective is a pure copy: 8 MiB 28.6 ms, 32 MiB 28.15, 128 MiB 27.8, 512 MiB 27.8 per cycle).
+The slice sealed LAST (it holds the first layers of the model) is split again, [<= 2 MiB | <= 32 MiB | rest] from slot 0 upward
+($HIFIC_BUCKET_TAIL_MB): what is on the wire when backward ends is exposed, so that piece is kept small.
 Collectives are issued from a dedicated reduce stream that waits for the producing streams (ops.producer_streams), so
 the backward pass never waits for its own weight gradients.  The division by world size is folded into the
 fused Adam kernel (grad_scale).
@@ -42,9 +44,16 @@ _NONBLOCK = os.environ.get("HIFIC_REDUCE_NONBLOCK", "1") not in ("0", "")
 
 
 class BucketedGradReducer:
-    def __init__(self, arena, bucket_mbytes=128, process_group=None, eager=True, expected_writes=None, payload=None):
+    def __init__(self, arena, bucket_mbytes=128, process_group=None, eager=True, expected_writes=None, payload=None,
+                 tail_mbytes=None):
         """expected_writes: {parameter or slot index: writes per backward} for slots written more than once.
-        payload: "f32" (default) or "bf16" (module docstring); $HIFIC_GRAD_PAYLOAD when None."""
+        payload: "f32" (default) or "bf16" (module docstring); $HIFIC_GRAD_PAYLOAD when None.
+        tail_mbytes: caps (MiB) of the LAST-sealed buckets, from the start of the arena upward ($HIFIC_BUCKET_TAIL_MB, default
+        "2,32"; eager arenas only).  Whatever is on the wire when backward ends is exposed: with plain 128 MiB slices that is the
+        bucket holding the first layers of the model (67 MiB for the amortisation arena: the Encoder, the Generator's head and
+        the first residual convolution - 0.37 ms on an 8-GPU ring).  Split as [first layers <= 2 MiB | <= 32 MiB | rest], the rest
+        seals when the Generator's head is done, the 32 MiB piece in the middle of the Encoder's backward, and only ~1 MiB is
+        left for the end."""
         self.arena = arena
         payload = payload or os.environ.get("HIFIC_GRAD_PAYLOAD", "f32")
         if payload not in ("f32", "bf16"):
@@ -70,6 +79,30 @@ class BucketedGradReducer:
                 self.slot_bucket[i] = b
             self.buckets.append((arena.offsets[lo_slot], hi_elem, hi_slot - lo_slot))
             hi_slot = lo_slot
+        if tail_mbytes is None:
+            tail_mbytes = [float(v) for v in os.environ.get("HIFIC_BUCKET_TAIL_MB", "2,32").split(",") if v.strip()]
+        tail_caps = [int(float(v) * (1 << 20) / 4) for v in tail_mbytes if float(v) > 0]
+        if eager and tail_caps and self.buckets:
+            lo_e, hi_e, n_last = self.buckets.pop()             # the bucket that holds slot 0: sealed last
+            b0 = len(self.buckets)
+            ends = lambda i: hi_e if i == n_last else arena.offsets[i]      # element offset where slot i starts / the bucket ends
+            pieces, start = [], 0
+            for cap in tail_caps:
+                end = start
+                while end < n_last and ends(end + 1) - arena.offsets[start] <= cap:
+                    end += 1
+                if end == n_last:                               # everything left fits under this cap: no further split
+                    break
+                if end > start:
+                    pieces.append((start, end))
+                    start = end
+            pieces.append((start, n_last))
+            for lo_s, hi_s in reversed(pieces):                 # list order = backward order (end of the arena first)
+                b = len(self.buckets)
+                for i in range(lo_s, hi_s):
+                    self.slot_bucket[i] = b
+                self.buckets.append((arena.offsets[lo_s], ends(hi_s), hi_s - lo_s))
+            assert self.buckets[-1][0] == lo_e and len(self.buckets) >= b0 + 1
         self.expected = [1] * nslots
         if expected_writes:
             index_of = {id(p): i for i, p in enumerate(arena.params)}

@@ -229,3 +229,20 @@ def test_one_rank_can_step_alone_without_issuing_collectives_world2(hific):
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_tail_split_buckets_reduce_to_the_same_sums_world2(hific, monkeypatch):
+    """The last-sealed bucket split into [first layers | next | rest] ($HIFIC_BUCKET_TAIL_MB): a different cut of the same arena,
+    the same sums.  1 MiB buckets over (300, 70000, 5, 130000, 64) floats: [3, 4] | [1, 2] | [0]."""
+    monkeypatch.setenv("HIFIC_BUCKET_MB", "1.0")
+    monkeypatch.setenv("HIFIC_BUCKET_TAIL_MB", "0.002,0.3")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29810 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, True, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res

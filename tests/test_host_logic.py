@@ -295,3 +295,33 @@ def test_pack_cache_unpin_releases_only_the_entries_that_graph_pinned(hific):
     assert all(e.pinned == 1 for e in pc.entries.values())
     pc.unpin(p2)
     assert not any(e.pinned for e in pc.entries.values())
+
+
+def test_reducer_bucket_layout_with_a_split_tail(hific):
+    """BucketedGradReducer cuts the arena from its END in bucket_mbytes slices (backward order) and splits the slice that holds
+    slot 0 - the one sealed last, whose all-reduce nothing can hide - by tail_mbytes caps counted from slot 0 upward.  Every
+    layout is a partition of the arena into contiguous slot ranges; deferred arenas are not split."""
+    import torch
+    from hific_amd import optim, parallel
+    sizes = (300, 70000, 5, 130000, 64, 9000, 200000)
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    arena = optim.ParamArena(ps)
+
+    def layout(**kw):
+        red = parallel.BucketedGradReducer(arena, **kw)
+        cover = 0
+        for b, (lo, hi, n) in enumerate(red.buckets):
+            slots = [i for i in range(len(sizes)) if red.slot_bucket[i] == b]
+            assert len(slots) == n and slots == list(range(slots[0], slots[0] + n)) and arena.offsets[slots[0]] == lo
+            cover += hi - lo
+        assert cover == arena.numel
+        return [[i for i in range(len(sizes)) if red.slot_bucket[i] == b] for b in range(len(red.buckets))]
+
+    assert layout(bucket_mbytes=2.0, tail_mbytes=()) == [[0, 1, 2, 3, 4, 5, 6]]
+    assert layout(bucket_mbytes=1.0, tail_mbytes=()) == [[4, 5, 6], [0, 1, 2, 3]]
+    # caps 2 KiB | 0.3 MiB from slot 0: [0] | [1, 2] | rest of that slice
+    assert layout(bucket_mbytes=1.0, tail_mbytes=(0.002, 0.3)) == [[4, 5, 6], [3], [1, 2], [0]]
+    # a cap the whole slice fits under splits nothing; a cap smaller than the first slot is skipped
+    assert layout(bucket_mbytes=1.0, tail_mbytes=(4.0,)) == [[4, 5, 6], [0, 1, 2, 3]]
+    assert layout(bucket_mbytes=1.0, tail_mbytes=(0.0001, 0.3)) == [[4, 5, 6], [3], [0, 1, 2]]
+    assert layout(bucket_mbytes=1.0, tail_mbytes=(0.002, 0.3), eager=False) == [[4, 5, 6], [0, 1, 2, 3]]
