@@ -894,6 +894,7 @@ def main():
         rccl = {"backend": "gloo (REHEARSAL on one device: control flow only)" if rehearsal else "nccl (RCCL)", "rccl_ranks": world,
                 "buckets": {k: len(r.buckets) for k, r in reducers.items()},
                 "bucket_mbytes": float(os.environ.get("HIFIC_BUCKET_MB", 128)),
+                "bucket_tail_mbytes": os.environ.get("HIFIC_BUCKET_TAIL_MB", "2,32"),
                 "gradient_payload": next(iter(reducers.values())).payload,
                 "gradient_mbytes_per_step": {k: round(r.arena.numel * 4 / 2 ** 20, 1) for k, r in reducers.items()},
                 "exposed_comm_ms": round(float(t.item()), 3),
